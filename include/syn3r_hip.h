@@ -1,0 +1,152 @@
+/*
+ * syn3r_hip.h — C-ABI of libsyn3r_hip.so: the MI355X (gfx950) hot path of SYN3R.
+ *
+ * The reference (DecaYale/SYN3R) is pure Python; it has no FFI of its own
+ * (SURVEY.md §8b).  Every entry point below states which reference Python
+ * function (file:line under /root/reference) it replaces.  A maintainer binds
+ * these with ctypes (INTEGRATION.md shows the stubs); syn3r_amd/_lib.py is that
+ * binding for this repo.
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, no torch types.
+ *   - every pointer is a DEVICE pointer unless the parameter is documented
+ *     "host"; small matrices (4x4 poses, 3x3 intrinsics) are passed BY VALUE
+ *     through host pointers and copied into kernel arguments.
+ *   - the caller owns every buffer; the library never allocates or frees
+ *     user tensors.  Scratch comes from a caller-provided workspace whose size
+ *     is returned by the matching *_workspace_bytes query.
+ *   - every call is asynchronous on the hipStream_t passed as `stream`
+ *     (a void* here so that the header needs no HIP include).
+ *   - return value: 0 = ok, negative = error (SYN3R_E_*); the message is
+ *     available from syn3r_last_error() (thread-local).
+ *   - no global mutable state besides the thread-local error string.
+ */
+#ifndef SYN3R_HIP_H
+#define SYN3R_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SYN3R_OK 0
+#define SYN3R_E_INVALID (-1)   /* bad argument (null pointer, non-positive size, unsupported mode) */
+#define SYN3R_E_WORKSPACE (-2) /* workspace too small */
+#define SYN3R_E_HIP (-3)       /* a HIP runtime call failed */
+
+/* dtype tags for entry points that accept fp16 or fp32 activations */
+#define SYN3R_F32 0
+#define SYN3R_F16 1
+
+const char* syn3r_last_error(void);
+/* library/ABI version: major*10000 + minor*100 + patch */
+int syn3r_version(void);
+/* name of the GPU architecture the code objects were built for ("gfx950") */
+const char* syn3r_arch(void);
+
+/* ------------------------------------------------------------------------
+ * Geometry (solver_utils/)
+ * ------------------------------------------------------------------------ */
+
+/*
+ * inverse_warp + consistency_check_with_depth, fused.
+ * Replaces solver_utils/forward_warp.py:187-279 (inverse_warp) and the
+ * consistency.py:44-91 call it makes at forward_warp.py:257.
+ *
+ * Batched over `nb` target views that share one source view:
+ *   img          [3,H,W]   f32  source image (closest view)
+ *   depth        [H,W]     f32  source depth
+ *   depth_pseudo [nb,H,W]  f32  target-view depths
+ *   pose12       host [nb,16] f32 row-major  pose1 @ inverse(pose2)   (forward_warp.py:217)
+ *   pose21       host [nb,16] f32 row-major  pose2 @ inverse(pose1)   (consistency.py:37 on the way back)
+ *   K, Kinv      host [9] f32 row-major      intrinsics and torch.inverse(K) (consistency.py:21)
+ *   bandwidth    reprojection bandwidth (20 or 10 in the reference)
+ * Outputs (all [nb,...]):
+ *   warped_img [nb,3,H,W] f32, warped_depth [nb,H,W] f32,
+ *   mask_warp, mask_depth, mask, mask_inv, mask_depth_strict, mask_reproj : [nb,H,W] u8 (0/1, = torch.bool)
+ *   warped_masked_img [nb,3,H,W] f32, soft_mask_reproj [nb,H,W] f32,
+ *   reproj_error [nb,H,W] f32 (may be NULL; the reference does not return it)
+ * workspace: syn3r_inverse_warp_workspace_bytes(nb) bytes (min/max slots).
+ */
+size_t syn3r_inverse_warp_workspace_bytes(int nb);
+int syn3r_inverse_warp(const float* img, const float* depth, const float* depth_pseudo,
+                       const float* pose12, const float* pose21, const float* K, const float* Kinv,
+                       float bandwidth, int nb, int H, int W,
+                       float* warped_img, float* warped_depth, uint8_t* mask_warp, uint8_t* mask_depth,
+                       uint8_t* mask, float* warped_masked_img, uint8_t* mask_inv,
+                       uint8_t* mask_depth_strict, uint8_t* mask_reproj, float* soft_mask_reproj,
+                       float* reproj_error, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * consistency_check_with_depth alone (solver_utils/consistency.py:44-91).
+ *   T12 = pose2 @ inverse(pose1), T21 = pose1 @ inverse(pose2) (host, [16] f32 row-major)
+ *   K1inv = inverse(K1); K1, K2 host [9].
+ *   depth1, depth2 [H,W] f32 -> err [H,W] f32
+ */
+int syn3r_reproj_error(const float* depth1, const float* depth2, const float* T12, const float* T21,
+                       const float* K1, const float* K1inv, const float* K2, int H, int W, float* err,
+                       void* stream);
+
+/*
+ * forward_warp: depth-weighted bilinear splat.
+ * Replaces solver_utils/forward_warp.py:141-182 (forward_warp),
+ * :7-38 (compute_transformed_points) and :42-127 (bilinear_splatting).
+ * float64 throughout, as the numpy reference.
+ *   frame1 [H,W,3] f64 (0..255), mask1 [H,W] u8 or NULL, depth1 [H,W] f64
+ *   T host [16] f64 = transformation2 @ inv(transformation1); K1inv, K2 host [9] f64
+ * Outputs: warped [H,W,3] u8, mask2 [H,W] u8, flow12 [H,W,2] f64
+ * workspace: syn3r_forward_warp_workspace_bytes(H,W) (f64 accumulators (H+2)x(W+2)x4 + scalars).
+ * Accumulation uses f64 hardware atomics (order-dependent in the last bits; the
+ * u8 output is insensitive to that except at exact .5 ties).
+ */
+size_t syn3r_forward_warp_workspace_bytes(int H, int W);
+int syn3r_forward_warp(const double* frame1, const uint8_t* mask1, const double* depth1, const double* T,
+                       const double* K1inv, const double* K2, int H, int W, uint8_t* warped, uint8_t* mask2,
+                       double* flow12, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Modified Euler scheduler (diffusers/schedulers/scheduling_euler_discrete.py)
+ * ------------------------------------------------------------------------ */
+
+/*
+ * step_interp (scheduling_euler_discrete.py:633-814), fused:
+ * v-prediction x0, per-frame quantile mask (radix select instead of the
+ * reference's full sort + host sync), closed-form guidance gradient
+ * (SURVEY.md §8a S2), Euler update.
+ *   model_output [F,C,h,w]  vdtype (SYN3R_F16 / SYN3R_F32)
+ *   sample       [F,C,h,w]  sdtype (upcast to f32 as :711)
+ *   cond         [F,C,h,w]  f32 = temp_cond_latents[1]
+ *   mask         [F-2,C,h,w] f32 (the reference's `mask`; valid = (1-mask)>0.5)
+ *   lambda_row   host [F] f64 = lambda_ts[step_i]  (F <= 64)
+ *   sigma f32 = sigmas[step_i]; dt f32 = sigmas[step_i+1] - sigma (:800)
+ *   c_out f32 = -sigma/(sigma^2+1)^0.5, denom f32 = sigma^2+1, sqrt_sigma f32 = sigma^0.5,
+ *                 all computed by the caller with the reference's own 0-dim fp32
+ *                 CPU tensor arithmetic (:728,:792) so that the roundings agree
+ * Outputs:
+ *   prev_sample [F,C,h,w] vdtype; pred_x0 [F,C,h,w] f32 (may be NULL);
+ *   grad [F,C,h,w] f32 (only when compute_grad; else may be NULL)
+ * workspace: syn3r_step_workspace_bytes(F,C,h,w).
+ */
+size_t syn3r_step_workspace_bytes(int F, int C, int h, int w);
+int syn3r_step_interp(const void* model_output, int vdtype, const void* sample, int sdtype,
+                      const float* cond, const float* mask, const double* lambda_row, float sigma,
+                      float dt, float c_out, float denom, float sqrt_sigma, float lr, int compute_grad,
+                      void* prev_sample, float* pred_x0, float* grad, int F, int C, int h, int w,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * step_interp_prob_uncertain (scheduling_euler_discrete.py:1343-1515):
+ * same quantile, soft replacement of x0 by the conditioning latents, first
+ * and last frame hard-set, Euler update.  Arguments as syn3r_step_interp.
+ */
+int syn3r_step_replace(const void* model_output, int vdtype, const void* sample, int sdtype,
+                       const float* cond, const float* mask, const double* lambda_row, float sigma,
+                       float dt, float c_out, float denom, void* prev_sample, float* pred_x0,
+                       int F, int C, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYN3R_HIP_H */

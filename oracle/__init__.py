@@ -1,0 +1,13 @@
+"""CPU oracle for the SYN3R hot path — TEST INFRASTRUCTURE ONLY.
+
+Plain numpy restatements of the reference algorithms (each function cites the
+reference file:line it follows).  Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s cpu_baseline leg may import this package; the product package
+`syn3r_amd` never does and has no CPU fallback.
+
+Pinning status:
+  geometry (warp_oracle)      pinned by tests/golden/warp_*.npz   (generated from the reference, oracle/gen_golden.py)
+  scheduler (scheduler_oracle) pinned by tests/golden/sched_*.npz  (generated from the reference)
+  rasteriser (raster_oracle)  PARITY UNPINNED — the reference's CUDA rasteriser source is an
+                              un-vendored submodule; restates the published 3DGS algorithm
+"""

@@ -1,0 +1,144 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (this container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+Imports the reference's own Python from /root/reference (SURVEY.md Appendix B
+recipe: two attribute shims for pip version skew, `.to('cuda')` redirected to
+the CPU for inverse_warp only), feeds it seeded synthetic inputs and stores the
+inputs' recipe (seed + shapes) and the reference's outputs.  Nothing from the
+reference travels to the GPU box: only these data fixtures do.  The inputs are
+rebuilt in tests from `golden_inputs.py` (same seeds), so the fixtures hold
+outputs only.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HF_HUB_OFFLINE", "1")
+os.environ.setdefault("TRANSFORMERS_OFFLINE", "1")
+sys.dont_write_bytecode = True
+REF = Path("/root/reference")
+sys.path[:0] = [str(REF / "thirdparty/diffusers/src"), str(REF)]
+
+import torch  # noqa: E402
+
+from oracle import golden_inputs as GI  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+
+
+def _import_reference():
+    import huggingface_hub
+    import transformers.utils as tu
+    if not hasattr(huggingface_hub, "cached_download"):
+        huggingface_hub.cached_download = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("offline"))
+    if not hasattr(tu, "FLAX_WEIGHTS_NAME"):
+        tu.FLAX_WEIGHTS_NAME = "flax_model.msgpack"
+    from diffusers import EulerDiscreteScheduler
+    from solver_utils.consistency import consistency_check_with_depth
+    from solver_utils.forward_warp import forward_warp, inverse_warp
+    return EulerDiscreteScheduler, consistency_check_with_depth, forward_warp, inverse_warp
+
+
+@contextlib.contextmanager
+def cuda_to_cpu():
+    """inverse_warp hard-codes .to('cuda') (forward_warp.py:225-256)."""
+    orig = torch.Tensor.to
+
+    def to(self, *a, **k):
+        a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+        if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+            k["device"] = "cpu"
+        return orig(self, *a, **k)
+
+    torch.Tensor.to = to
+    try:
+        yield
+    finally:
+        torch.Tensor.to = orig
+
+
+def gen_warp(consistency, forward_warp, inverse_warp):
+    for name in GI.WARP_CASES:
+        c = GI.warp_case(name)
+        sy, sx = c["stride"]
+        out = {}
+        with cuda_to_cpu():
+            d = inverse_warp(torch.from_numpy(c["img"]), torch.from_numpy(c["depth"])[None],
+                             torch.from_numpy(c["depth_pseudo"])[None], torch.from_numpy(c["pose1"]),
+                             torch.from_numpy(c["pose2"]), torch.from_numpy(c["K"]), bg_mask=None,
+                             bandwidth=c["bandwidth"])
+        for k, v in d.items():
+            if v is None:
+                continue
+            out["iw_" + k] = v.numpy()[..., ::sy, ::sx]
+        err = consistency(torch.from_numpy(c["depth_pseudo"]), torch.from_numpy(c["pose2"]), torch.from_numpy(c["K"]),
+                          torch.from_numpy(c["depth"]), torch.from_numpy(c["pose1"]), torch.from_numpy(c["K"]))
+        out["reproj_error"] = err.numpy()[::sy, ::sx]
+        frame = (c["img"].transpose(1, 2, 0) * 255.0).astype(np.float64)
+        warped, mask2, flow = forward_warp(frame, None, c["depth"].astype(np.float64), c["pose1"].astype(np.float64),
+                                           c["pose2"].astype(np.float64), c["K"].astype(np.float64), None)
+        out["fw_warped"] = warped[::sy, ::sx]
+        out["fw_mask"] = mask2[::sy, ::sx]
+        out["fw_flow"] = flow[::sy, ::sx]
+        np.savez_compressed(GOLD / f"warp_{name}.npz", **out)
+        print("warp", name, {k: v.shape for k, v in out.items()})
+
+
+def gen_sched(EulerDiscreteScheduler):
+    sch = EulerDiscreteScheduler(**GI.SCHED_CONFIG)
+    sch.set_timesteps(100)
+    np.savez_compressed(GOLD / "sched_sigmas.npz", sigmas=sch.sigmas.numpy(), timesteps=sch.timesteps.numpy(),
+                        init_noise_sigma=np.float32(sch.init_noise_sigma))
+    sch25 = EulerDiscreteScheduler(**GI.SCHED_CONFIG)
+    sch25.set_timesteps(25)
+    np.savez_compressed(GOLD / "sched_sigmas25.npz", sigmas=sch25.sigmas.numpy(), timesteps=sch25.timesteps.numpy())
+    for name in GI.SCHED_CASES:
+        c = GI.sched_case(name)
+        s = c["stride"]
+        t = sch.timesteps[c["step_i"]]
+        out = {}
+        v = torch.from_numpy(c["model_output"])
+        x = torch.from_numpy(c["sample"])
+        cond = torch.from_numpy(c["temp_cond"])
+        mask = torch.from_numpy(c["mask"])
+        lam = torch.from_numpy(c["lambda_ts"])
+        # guidance-gradient variant, exactly as the pipeline drives it (…post.py:727-774): sample is a leaf
+        for cg in (True, False):
+            sch.is_scale_input_called = True
+            xs = x.clone().requires_grad_(cg)
+            with torch.enable_grad() if cg else torch.no_grad():
+                r = sch.step_interp(v, t, xs, cond, mask, lam, step_i=c["step_i"], lr=0.02, compute_grad=cg)
+            tag = "g1" if cg else "g0"
+            out[f"interp_{tag}_prev"] = r.prev_sample.detach().numpy()[..., ::s, ::s]
+            out[f"interp_{tag}_x0"] = r.pred_original_sample.detach().numpy()[..., ::s, ::s]
+            if cg:
+                out["interp_g1_grad"] = r.grad.detach().numpy()[..., ::s, ::s]
+                out["interp_g1_grad_std"] = np.float64(r.grad.detach().double().std())
+        with torch.no_grad():
+            r = sch.step_interp_prob_uncertain(v, t, x.clone(), cond, mask, lam, step_i=c["step_i"])
+        out["replace_prev"] = r.prev_sample.numpy()[..., ::s, ::s]
+        out["replace_x0"] = r.pred_original_sample.numpy()[..., ::s, ::s]
+        np.savez_compressed(GOLD / f"sched_{name}.npz", **out)
+        print("sched", name, {k: getattr(v_, "shape", ()) for k, v_ in out.items()})
+
+
+def main():
+    GOLD.mkdir(parents=True, exist_ok=True)
+    Sch, consistency, forward_warp, inverse_warp = _import_reference()
+    which = sys.argv[1:] or ["warp", "sched"]
+    if "warp" in which:
+        gen_warp(consistency, forward_warp, inverse_warp)
+    if "sched" in which:
+        gen_sched(Sch)
+
+
+if __name__ == "__main__":
+    main()

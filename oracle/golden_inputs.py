@@ -1,0 +1,110 @@
+"""Seeded synthetic inputs shared by oracle/gen_golden.py (which feeds them to the
+reference) and tests/ (which feed them to the oracle and to the HIP path).
+Test infrastructure only.  numpy's PCG64 `default_rng(seed)` streams are stable
+across numpy versions, so fixtures store outputs only.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+f32 = np.float32
+
+SCHED_CONFIG = dict(
+    num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+    prediction_type="v_prediction", interpolation_type="linear", use_karras_sigmas=True, sigma_min=0.002,
+    sigma_max=700.0, timestep_spacing="leading", timestep_type="continuous", steps_offset=1,
+)
+
+
+def _rot_y(deg):
+    a = np.deg2rad(deg)
+    R = np.eye(4, dtype=np.float64)
+    R[0, 0], R[0, 2], R[2, 0], R[2, 2] = np.cos(a), np.sin(a), -np.sin(a), np.cos(a)
+    return R
+
+
+def _rot_x(deg):
+    a = np.deg2rad(deg)
+    R = np.eye(4, dtype=np.float64)
+    R[1, 1], R[1, 2], R[2, 1], R[2, 2] = np.cos(a), -np.sin(a), np.sin(a), np.cos(a)
+    return R
+
+
+def _depth(H, W, sx=97.0, sy=53.0, base=2.0):
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    return (base + 0.5 * np.sin(xs / sx) + 0.3 * np.cos(ys / sy)).astype(f32)
+
+
+WARP_CASES = {
+    # name: (H, W, focal, translation, yaw_deg, pitch_deg, bandwidth, stride, seed, holes)
+    "small": (64, 96, 80.0, (0.05, 0.0, 0.02), 0.5, 0.0, 20, (1, 1), 0, False),
+    "small_bw10": (48, 80, 60.0, (-0.21, 0.07, 0.05), -3.0, 1.5, 10, (1, 1), 1, True),
+    "full": (576, 1024, 800.0, (0.05, 0.0, 0.02), 0.5, 0.0, 20, (9, 11), 0, False),
+}
+
+
+def warp_case(name):
+    H, W, focal, t, yaw, pitch, bw, stride, seed, holes = WARP_CASES[name]
+    rng = np.random.default_rng(seed)
+    img = rng.random((3, H, W), dtype=f32)
+    sc = W / 1024.0
+    depth = _depth(H, W, 97.0 * sc, 53.0 * sc)
+    depth_pseudo = _depth(H, W, 91.0 * sc, 57.0 * sc, base=2.02)
+    if holes:  # zero-depth (unrendered) regions in both views
+        depth[5:12, 10:30] = 0.0
+        depth_pseudo[30:36, 50:70] = 0.0
+    K = np.array([[focal, 0, W / 2.0], [0, focal, H / 2.0], [0, 0, 1]], dtype=f32)
+    pose1 = (_rot_x(0.3) @ np.eye(4)).astype(f32)
+    pose1[:3, 3] = np.array([0.01, -0.02, 0.0], dtype=f32)
+    T2 = _rot_y(yaw) @ _rot_x(pitch)
+    T2[:3, 3] = np.array(t)
+    pose2 = (T2 @ pose1.astype(np.float64)).astype(f32)
+    return dict(img=img, depth=depth, depth_pseudo=depth_pseudo, pose1=pose1, pose2=pose2, K=K, bandwidth=bw,
+                stride=stride, H=H, W=W)
+
+
+SCHED_CASES = {
+    # name: (h, w, dtype, step_i, lambda_kind, mask_kind, stride, seed)
+    "tiny_f32": (10, 18, "float32", 10, "binary", "pixel", 1, 11),
+    "tiny_f16": (10, 18, "float16", 50, "uniform", "pixel", 1, 12),
+    "chan_mask": (12, 16, "float32", 80, "uniform", "channel", 1, 13),
+    "tile_f16": (40, 72, "float16", 3, "binary", "pixel", 3, 14),
+    "full_f16": (72, 128, "float16", 42, "binary", "pixel", 5, 15),
+}
+
+
+def sched_case(name, F=25, C=4):
+    h, w, dt, step_i, lam_kind, mask_kind, stride, seed = SCHED_CASES[name]
+    return sched_inputs(h, w, dt, step_i, lam_kind, mask_kind, stride, seed, F, C)
+
+
+def sched_inputs(h, w, dt, step_i, lam_kind, mask_kind, stride, seed, F=25, C=4):
+    rng = np.random.default_rng(seed)
+    # sigma at that step sets the sample scale (x = x0 + sigma * eps)
+    sig = karras_sigmas(100)[step_i]
+    x0 = rng.standard_normal((1, F, C, h, w)).astype(f32) / f32(5.6)
+    sample = (x0 + sig * rng.standard_normal((1, F, C, h, w)).astype(f32)).astype(dt)
+    model_output = rng.standard_normal((1, F, C, h, w)).astype(f32).astype(dt)
+    cond = (x0[0] + 0.05 * rng.standard_normal((F, C, h, w)).astype(f32)).astype(f32)
+    temp_cond = np.stack([np.zeros_like(cond), cond], 0)
+    if mask_kind == "pixel":
+        m = rng.random((1, F - 2, 1, h, w), dtype=f32)
+        mask = np.broadcast_to(m, (1, F - 2, C, h, w)).copy()
+    else:
+        mask = rng.random((1, F - 2, C, h, w), dtype=f32)
+    if lam_kind == "binary":
+        lam = (rng.random((100, F)) > 0.5).astype(np.float64)
+    else:
+        lam = rng.random((100, F))
+    lam[:, 0] = 1.0
+    lam[:, -1] = 1.0
+    return dict(model_output=model_output, sample=sample, temp_cond=temp_cond, mask=mask, lambda_ts=lam,
+                step_i=step_i, stride=stride, F=F, C=C, h=h, w=w)
+
+
+def karras_sigmas(n, sigma_min=0.002, sigma_max=700.0, rho=7.0):
+    """Karras schedule, float32, with the trailing zero (scheduling_euler_discrete.py:399-423,370)."""
+    ramp = np.linspace(0, 1, n)
+    lo, hi = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
+    s = (hi + ramp * (lo - hi)) ** rho
+    return np.concatenate([s.astype(f32), np.zeros(1, f32)])

@@ -1,0 +1,131 @@
+"""ctypes binding of libsyn3r_hip.so (the C-ABI in include/syn3r_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or a call is made
+with tensors that are not on a HIP device, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libsyn3r_hip.so"
+_lib = None
+
+c_f = C.c_float
+c_i = C.c_int
+c_p = C.c_void_p
+c_sz = C.c_size_t
+
+F32, F16 = 0, 1
+
+# name -> (restype, argtypes); mirrors include/syn3r_hip.h declaration by declaration
+SIGNATURES = {
+    "syn3r_last_error": (C.c_char_p, []),
+    "syn3r_version": (c_i, []),
+    "syn3r_arch": (C.c_char_p, []),
+    "syn3r_inverse_warp_workspace_bytes": (c_sz, [c_i]),
+    "syn3r_inverse_warp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i,
+                                 c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "syn3r_reproj_error": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "syn3r_forward_warp_workspace_bytes": (c_sz, [c_i, c_i]),
+    "syn3r_forward_warp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "syn3r_step_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "syn3r_step_interp": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_i,
+                                c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "syn3r_step_replace": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_f, c_f, c_f, c_f,
+                                 c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+}
+
+
+class Syn3rError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library (once) and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise Syn3rError(
+            f"{_LIB_PATH} is missing: build it with `python -m syn3r_amd.build` "
+            "(there is no CPU fallback for the SYN3R hot path)")
+    lib = C.CDLL(str(_LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().syn3r_last_error().decode("utf-8", "replace")
+        raise Syn3rError(f"{what} failed (code {rc}): {msg}")
+
+
+def require_gpu(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise Syn3rError("syn3r_amd HIP path needs tensors on a HIP device (no CPU fallback); "
+                             f"got a tensor on {t.device}")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise Syn3rError(f"tensors on different devices: {dev} vs {t.device}")
+    if dev is None:
+        raise Syn3rError("no tensors given")
+    return dev
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise Syn3rError("non-contiguous tensor passed to the C-ABI")
+    return t.data_ptr()
+
+
+def stream_ptr(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def dtype_tag(t: torch.Tensor) -> int:
+    if t.dtype == torch.float16:
+        return F16
+    if t.dtype == torch.float32:
+        return F32
+    raise Syn3rError(f"unsupported dtype {t.dtype}")
+
+
+def host_f32(values) -> "C.Array":
+    flat = [float(v) for v in values]
+    return (C.c_float * len(flat))(*flat)
+
+
+def host_f64(values) -> "C.Array":
+    flat = [float(v) for v in values]
+    return (C.c_double * len(flat))(*flat)
+
+
+_ws_cache: dict = {}
+
+
+def workspace(dev: torch.device, nbytes: int, tag: str = "") -> torch.Tensor:
+    """A reusable per-(device, stream, tag) scratch buffer of at least nbytes."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = buf
+    return buf

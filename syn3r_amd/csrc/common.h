@@ -1,0 +1,77 @@
+// Shared host-side helpers for libsyn3r_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/syn3r_hip.h"
+
+namespace syn3r {
+
+void set_error(const char* fmt, ...);
+
+inline int check_hip(hipError_t e, const char* what) {
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return SYN3R_E_HIP;
+    }
+    return SYN3R_OK;
+}
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// 4x4 / 3x3 matrices travel to kernels by value.
+struct Mat4f { float m[16]; };
+struct Mat3f { float m[9]; };
+struct Mat4d { double m[16]; };
+struct Mat3d { double m[9]; };
+
+}  // namespace syn3r
+
+#define SYN3R_REQUIRE(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            syn3r::set_error(__VA_ARGS__);       \
+            return SYN3R_E_INVALID;              \
+        }                                        \
+    } while (0)
+
+#define SYN3R_LAUNCH_CHECK(name)                                        \
+    do {                                                                \
+        hipError_t e__ = hipGetLastError();                             \
+        if (e__ != hipSuccess) return syn3r::check_hip(e__, name);      \
+    } while (0)
+
+// Wave-level reductions (64 lanes).
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

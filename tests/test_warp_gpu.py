@@ -1,0 +1,143 @@
+"""HIP geometry kernels vs the CPU oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import golden_inputs as GI
+from oracle import warp_oracle as WO
+from tests.test_oracle_golden import assert_mostly_close, frac_mismatch
+
+pytestmark = pytest.mark.gpu
+
+BOOL_KEYS = ("mask_warp", "mask_depth", "mask", "mask_inv", "mask_depth_strict", "mask_reproj")
+
+
+def run_inverse(c, dev, pose2=None):
+    from syn3r_amd.solver_utils.forward_warp import inverse_warp
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    out = inverse_warp(t(c["img"]), t(c["depth"])[None], t(c["depth_pseudo"])[None], t(c["pose1"]),
+                       t(c["pose2"] if pose2 is None else pose2), t(c["K"]), bg_mask=None, bandwidth=c["bandwidth"])
+    return {k: (v.cpu().numpy() if v is not None else None) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("name", list(GI.WARP_CASES))
+def test_inverse_warp_vs_oracle_and_golden(name, gpu, golden_dir):
+    c = GI.warp_case(name)
+    o = WO.inverse_warp(c["img"], c["depth"], c["depth_pseudo"], c["pose1"], c["pose2"], c["K"], c["bandwidth"])
+    h = run_inverse(c, gpu)
+    assert h["warped_bg_mask"] is None
+    assert h["warped_depth"].shape == (1, c["H"], c["W"]) and h["mask"].dtype == np.bool_
+    for k in ("warped_img", "warped_depth", "warped_masked_img"):
+        assert frac_mismatch(h[k], o[k]) < 2e-3, k
+    np.testing.assert_allclose(h["soft_mask_reproj"], o["soft_mask_reproj"], atol=2e-4)
+    for k in BOOL_KEYS:
+        assert frac_mismatch(h[k], o[k]) < 2e-3, k
+    g = np.load(golden_dir / f"warp_{name}.npz")
+    sy, sx = c["stride"]
+    for k in ("warped_img", "warped_depth", "warped_masked_img"):
+        assert frac_mismatch(h[k][..., ::sy, ::sx], g["iw_" + k]) < 2e-3, k
+    np.testing.assert_allclose(h["soft_mask_reproj"][::sy, ::sx], g["iw_soft_mask_reproj"], atol=2e-4)
+    for k in BOOL_KEYS:
+        assert frac_mismatch(h[k][::sy, ::sx], g["iw_" + k]) < 2e-3, k
+
+
+@pytest.mark.parametrize("name", list(GI.WARP_CASES))
+def test_reproj_error_vs_oracle_and_golden(name, gpu, golden_dir):
+    from syn3r_amd.solver_utils.consistency import consistency_check_with_depth
+    c = GI.warp_case(name)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    err = consistency_check_with_depth(t(c["depth_pseudo"]), t(c["pose2"]), t(c["K"]), t(c["depth"]), t(c["pose1"]),
+                                       t(c["K"])).cpu().numpy()
+    ref = WO.consistency_check_with_depth(c["depth_pseudo"], c["pose2"], c["K"], c["depth"], c["pose1"], c["K"])
+    fin = np.isfinite(ref)
+    assert np.array_equal(fin, np.isfinite(err))
+    assert_mostly_close(err[fin], ref[fin], atol=2e-3, rtol=1e-4, hard=0.5)
+    g = np.load(golden_dir / f"warp_{name}.npz")["reproj_error"]
+    sy, sx = c["stride"]
+    e = err[::sy, ::sx]
+    fin = np.isfinite(g)
+    assert_mostly_close(e[fin], g[fin], atol=2e-3, rtol=1e-4, hard=0.5)
+
+
+def test_inverse_warp_batch_matches_single(gpu):
+    from syn3r_amd.solver_utils.forward_warp import inverse_warp, inverse_warp_batch
+    c = GI.warp_case("small_bw10")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    poses = np.stack([c["pose2"], c["pose1"], c["pose2"]])
+    dps = np.stack([c["depth_pseudo"], c["depth"], c["depth_pseudo"] * 1.01]).astype(np.float32)
+    out = inverse_warp_batch(t(c["img"]), t(c["depth"]), t(dps), t(c["pose1"]), t(poses), t(c["K"]), bandwidth=10)
+    for b in range(3):
+        single = inverse_warp(t(c["img"]), t(c["depth"])[None], t(dps[b])[None], t(c["pose1"]), t(poses[b]), t(c["K"]),
+                              bandwidth=10)
+        for k, v in single.items():
+            if v is not None:
+                assert torch.equal(out[k][b], v), (b, k)
+
+
+def test_inverse_warp_identity_and_out_of_bounds(gpu):
+    """Edge cases: identical poses (reference's half-pixel quirk: error stays sub-pixel, not zero)
+    and a pose that sends every pixel out of the source image."""
+    c = GI.warp_case("small")
+    h = run_inverse(c, gpu, pose2=c["pose1"])
+    o = WO.inverse_warp(c["img"], c["depth"], c["depth_pseudo"], c["pose1"], c["pose1"], c["K"], c["bandwidth"])
+    assert h["mask_warp"].all()
+    assert frac_mismatch(h["mask_reproj"], o["mask_reproj"]) < 2e-3
+    far = c["pose1"].copy()
+    far[0, 3] += 100.0
+    h = run_inverse(c, gpu, pose2=far)
+    assert not h["mask_warp"].any() and not h["mask"].any() and h["mask_inv"].all()
+    assert (h["warped_img"] == 0).all() and (h["warped_depth"] == 0).all()
+
+
+def test_inverse_warp_rejects_bad_input(gpu):
+    from syn3r_amd import _lib
+    from syn3r_amd.solver_utils.forward_warp import inverse_warp
+    c = GI.warp_case("small")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    with pytest.raises(NotImplementedError):
+        inverse_warp(t(c["img"]), t(c["depth"])[None], t(c["depth_pseudo"])[None], t(c["pose1"]), t(c["pose2"]),
+                     t(c["K"]), bg_mask=t(c["depth"]))
+    with pytest.raises(ValueError):
+        inverse_warp(t(c["img"])[:, :10], t(c["depth"])[None], t(c["depth_pseudo"])[None], t(c["pose1"]),
+                     t(c["pose2"]), t(c["K"]))
+    with pytest.raises(_lib.Syn3rError):
+        inverse_warp(torch.from_numpy(c["img"]), t(c["depth"])[None], t(c["depth_pseudo"])[None], t(c["pose1"]),
+                     t(c["pose2"]), t(c["K"]))
+
+
+@pytest.mark.parametrize("name", list(GI.WARP_CASES))
+def test_forward_warp_vs_oracle_and_golden(name, gpu, golden_dir):
+    from syn3r_amd.solver_utils.forward_warp import forward_warp
+    c = GI.warp_case(name)
+    frame = (c["img"].transpose(1, 2, 0) * 255.0).astype(np.float64)
+    args = (frame, None, c["depth"].astype(np.float64), c["pose1"].astype(np.float64), c["pose2"].astype(np.float64),
+            c["K"].astype(np.float64), None)
+    warped, mask2, flow = forward_warp(*args)
+    ow, om, of = WO.forward_warp(*args)
+    assert warped.dtype == np.uint8 and mask2.dtype == np.bool_ and flow.dtype == np.float64
+    np.testing.assert_allclose(flow, of, atol=1e-9, rtol=1e-12)
+    assert np.array_equal(mask2, om)
+    d = np.abs(warped.astype(int) - ow.astype(int))
+    assert d.max() <= 1 and np.mean(d > 0) < 1e-3
+    g = np.load(golden_dir / f"warp_{name}.npz")
+    sy, sx = c["stride"]
+    np.testing.assert_allclose(flow[::sy, ::sx], g["fw_flow"], atol=1e-9, rtol=1e-12)
+    assert np.array_equal(mask2[::sy, ::sx], g["fw_mask"])
+    d = np.abs(warped[::sy, ::sx].astype(int) - g["fw_warped"].astype(int))
+    assert d.max() <= 1 and np.mean(d > 0) < 1e-3
+
+
+def test_forward_warp_mask_and_shape_asserts(gpu):
+    from syn3r_amd.solver_utils.forward_warp import forward_warp
+    c = GI.warp_case("small")
+    frame = (c["img"].transpose(1, 2, 0) * 255.0).astype(np.float64)
+    m = np.zeros((c["H"], c["W"]), bool)
+    m[:, : c["W"] // 2] = True
+    a = (c["depth"].astype(np.float64), c["pose1"].astype(np.float64), c["pose2"].astype(np.float64),
+         c["K"].astype(np.float64), None)
+    warped, mask2, _ = forward_warp(frame, m, *a)
+    ow, om, _ = WO.forward_warp(frame, m, *a)
+    assert np.array_equal(mask2, om) and np.abs(warped.astype(int) - ow.astype(int)).max() <= 1
+    assert not mask2.all()
+    with pytest.raises(AssertionError):
+        forward_warp(frame[:, :, :2], None, *a)
