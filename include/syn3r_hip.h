@@ -146,6 +146,81 @@ int syn3r_step_replace(const void* model_output, int vdtype, const void* sample,
                        float dt, float c_out, float denom, void* prev_sample, float* pred_x0,
                        int F, int C, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Gaussian rasteriser (diff-gaussian-rasterization-confidence)
+ *
+ * The reference consumes it through gsTrainer.render_view(cam) ->
+ * {'render','depth','alpha'} (model/diffusionGS.py:154,166) and differentiates
+ * it inside gsTrainer.training()/finetune() (:139,1640).  Its CUDA source is an
+ * un-vendored submodule: these entry points follow the
+ * published 3DGS rasteriser interface (forward: preprocess + tile binning +
+ * radix sort + blend; backward: blend backward + preprocess backward).
+ *
+ * Layouts: means3D [N,3], scales [N,3], rotations [N,4] (r,x,y,z), opacities [N],
+ * shs [N,sh_coeffs,3], confidence [N] or NULL (=1); all f32, device.
+ * viewmatrix / projmatrix: host [16] f32, column-major (the transposed
+ * world_view_transform / full_proj_transform of FSGS cameras); campos host [3].
+ * State buffers (geom, binning, image) are caller-owned byte buffers sized by
+ * the *_bytes queries; they carry the forward's intermediates to the backward.
+ * ------------------------------------------------------------------------ */
+size_t syn3r_raster_geom_bytes(int N);
+size_t syn3r_raster_image_bytes(int H, int W);
+size_t syn3r_raster_binning_bytes(long long P);
+
+/*
+ * Stage 1: project every Gaussian, count the tiles it touches, prefix-sum.
+ * radii [N] i32 out.  If num_rendered_host != NULL the number of
+ * (Gaussian, tile) pairs P is copied to it and the stream is synchronised
+ * (the reference implementation performs the same device->host read to size
+ * its binning buffers).
+ */
+int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, const float* means3D, const float* scales,
+                            const float* rotations, const float* opacities, const float* shs,
+                            const float* confidence, float scale_modifier, const float* viewmatrix,
+                            const float* projmatrix, const float* campos, float tanfovx, float tanfovy, int H,
+                            int W, int* radii, void* geom, size_t geom_bytes, long long* num_rendered_host,
+                            void* stream);
+
+/*
+ * Stage 2: duplicate (tile<<32 | depth) keys, sort, find tile ranges, blend.
+ * bg host [3].  out_color [3,H,W], out_depth [1,H,W] (sum of alpha*T*z),
+ * out_alpha [1,H,W] (1 - final transmittance).  *point_list_out (host pointer
+ * to a device pointer, may be NULL) receives the sorted Gaussian-index list
+ * inside `binning`, needed by the backward.
+ */
+int syn3r_raster_render(int N, int H, int W, const float* bg, const int* radii, void* geom, size_t geom_bytes,
+                        void* binning, size_t binning_bytes, void* image, size_t image_bytes, long long P,
+                        float* out_color, float* out_depth, float* out_alpha, unsigned** point_list_out,
+                        void* stream);
+
+/*
+ * Backward of both stages.  dL_dcolor [3,H,W]; dL_ddepth, dL_dalpha [H,W] or NULL.
+ * Outputs: dL_dmeans3D [N,3], dL_dscales [N,3], dL_drotations [N,4],
+ * dL_dopacities [N], dL_dshs [N,sh_coeffs,3], dL_dmeans2D [N,3] (NDC-space
+ * gradient of the projected mean, used by densification), dL_dconfidence [N] or NULL.
+ */
+size_t syn3r_raster_backward_workspace_bytes(int N);
+int syn3r_raster_backward(int N, int sh_degree, int sh_coeffs, long long P, const float* means3D,
+                          const float* scales, const float* rotations, const float* opacities, const float* shs,
+                          const float* confidence, float scale_modifier, const float* viewmatrix,
+                          const float* projmatrix, const float* campos, float tanfovx, float tanfovy, int H, int W,
+                          const float* bg, const int* radii, void* geom, size_t geom_bytes,
+                          const unsigned* point_list, void* image, size_t image_bytes, const float* dL_dcolor,
+                          const float* dL_ddepth, const float* dL_dalpha, float* dL_dmeans3D, float* dL_dscales,
+                          float* dL_drotations, float* dL_dopacities, float* dL_dshs, float* dL_dmeans2D,
+                          float* dL_dconfidence, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits) — the
+ * tile/depth sort of the rasteriser (cub::DeviceRadixSort::SortPairs in the
+ * published implementation).  Ping-pongs between the two buffer pairs;
+ * *result_in_tmp (host) tells which pair holds the sorted output.
+ */
+size_t syn3r_sort_pairs_workspace_bytes(long long n);
+int syn3r_sort_pairs(unsigned long long* keys, unsigned* vals, unsigned long long* keys_tmp, unsigned* vals_tmp,
+                     long long n, int nbits, void* workspace, size_t workspace_bytes, int* result_in_tmp,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

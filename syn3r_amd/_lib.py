@@ -17,6 +17,7 @@ c_f = C.c_float
 c_i = C.c_int
 c_p = C.c_void_p
 c_sz = C.c_size_t
+c_ll = C.c_longlong
 
 F32, F16 = 0, 1
 
@@ -36,6 +37,19 @@ SIGNATURES = {
                                 c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "syn3r_step_replace": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_f, c_f, c_f, c_f,
                                  c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "syn3r_raster_geom_bytes": (c_sz, [c_i]),
+    "syn3r_raster_image_bytes": (c_sz, [c_i, c_i]),
+    "syn3r_raster_binning_bytes": (c_sz, [c_ll]),
+    "syn3r_raster_preprocess": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_f, c_f,
+                                      c_i, c_i, c_p, c_p, c_sz, C.POINTER(c_ll), c_p]),
+    "syn3r_raster_render": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p, c_sz, c_p, c_sz, c_ll, c_p, c_p, c_p,
+                                  C.POINTER(c_p), c_p]),
+    "syn3r_raster_backward_workspace_bytes": (c_sz, [c_i]),
+    "syn3r_raster_backward": (c_i, [c_i, c_i, c_i, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_f, c_f,
+                                    c_i, c_i, c_p, c_p, c_p, c_sz, c_p, c_p, c_sz, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                    c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "syn3r_sort_pairs_workspace_bytes": (c_sz, [c_ll]),
+    "syn3r_sort_pairs": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_i, c_p, c_sz, C.POINTER(c_i), c_p]),
 }
 
 

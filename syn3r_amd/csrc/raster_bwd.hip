@@ -1,0 +1,404 @@
+// Gaussian rasteriser, backward: per-tile back-to-front traversal of the blend, then the
+// per-Gaussian chain rule through EWA projection, SH colour and covariance construction.
+//
+// Replaces the rasteriser backward inside gsTrainer.training()/finetune() (call sites
+// model/diffusionGS.py:139,1640); restates the published 3DGS backward (see raster_common.h;
+// reference CUDA source absent).  Gradients are validated against autograd
+// through oracle/raster_oracle.py.
+//
+// MI355X mapping: per splat a wavefront has up to 64 pixel contributions to 10 quantities.
+// They are summed with a 17-shuffle butterfly (16 padded values over 64 lanes: 8+4+2+1
+// exchange steps halve the live values while doubling the lanes summed, then 2 quad steps),
+// which leaves value k on lane 4k; those 16 lanes issue ONE atomic wave-instruction onto a
+// contiguous 64-byte gradient record (MI355X float atomics want contiguous segments,
+// MI355X_MICROARCH.md "Global float atomics").  Wavefronts where no pixel contributes skip
+// the splat entirely.
+#include "common.h"
+#include "raster_common.h"
+
+using namespace syn3r;
+
+namespace syn3r {
+void raster_fill_camera(Camera& cam, const float* view, const float* proj, const float* campos, float tanfovx,
+                        float tanfovy, int H, int W);
+}
+
+namespace {
+
+// 64-byte per-Gaussian gradient record written by the blend backward
+constexpr int kGradSlots = 16;
+enum { G_R = 0, G_G, G_B, G_DEPTH, G_MX, G_MY, G_CXX, G_CXY, G_CYY, G_OP, G_USED = 10 };
+
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8, k = bid / 8;
+    unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}
+
+// Sum v[k] over the 64 lanes; on return lane 4k holds the total of value k in the return value.
+__device__ __forceinline__ float butterfly16(float (&v)[16], int lane) {
+    float w8[8], w4[4], w2[2];
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float send = b5 ? v[k] : v[k + 8];
+        float keep = b5 ? v[k + 8] : v[k];
+        w8[k] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float send = b4 ? w8[k] : w8[k + 4];
+        float keep = b4 ? w8[k + 4] : w8[k];
+        w4[k] = keep + __shfl_xor(send, 16, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float send = b3 ? w4[k] : w4[k + 2];
+        float keep = b3 ? w4[k + 2] : w4[k];
+        w2[k] = keep + __shfl_xor(send, 8, 64);
+    }
+    float send = b2 ? w2[0] : w2[1];
+    float keep = b2 ? w2[1] : w2[0];
+    float w1 = keep + __shfl_xor(send, 4, 64);
+    w1 += __shfl_xor(w1, 1, 64);
+    w1 += __shfl_xor(w1, 2, 64);
+    return w1;   // value index = bit2 + 2*bit3 + 4*bit4 + 8*bit5 = lane >> 2
+}
+
+__global__ void __launch_bounds__(kTilePix) k_render_bwd(
+    int H, int W, int gx, int gy, const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list,
+    const Splat* __restrict__ splats, float bg0, float bg1, float bg2, const unsigned* __restrict__ n_contrib,
+    const float* __restrict__ final_T, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+    const float* __restrict__ dL_dalpha_out, float* __restrict__ grad_rec) {
+    __shared__ float4 sm[kTilePix * 3];
+    __shared__ unsigned sid[kTilePix];
+    const unsigned tile = xcd_remap(blockIdx.x, (unsigned)(gx * gy));
+    const int tx = tile % gx, ty = tile / gx;
+    const int lx = threadIdx.x % kTileX, ly = threadIdx.x / kTileX;
+    const int px = tx * kTileX + lx, py = ty * kTileY + ly;
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const int lane = threadIdx.x & 63;
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+    const int rounds = (total + kTilePix - 1) / kTilePix;
+    const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
+
+    const float T_final = inside ? final_T[pix] : 0.0f;
+    float T = T_final;
+    const int last_contributor = inside ? (int)n_contrib[pix] : 0;
+    int contributor = total;
+    float gr = 0.f, gg = 0.f, gb = 0.f, gD = 0.f, gA = 0.f;
+    if (inside) {
+        gr = dL_dcolor[pix]; gg = dL_dcolor[hw + pix]; gb = dL_dcolor[2 * hw + pix];
+        gD = dL_ddepth ? dL_ddepth[pix] : 0.0f;
+        gA = dL_dalpha_out ? dL_dalpha_out[pix] : 0.0f;
+    }
+    const float bg_dot = bg0 * gr + bg1 * gg + bg2 * gb;
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f;
+    float last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f, last_d = 0.f;
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+
+    int todo = total;
+    for (int rd = 0; rd < rounds; ++rd, todo -= kTilePix) {
+        __syncthreads();
+        int progress = rd * kTilePix + threadIdx.x;
+        if (progress < total) {
+            unsigned gid = point_list[range.y - progress - 1];   // back to front
+            const float4* src = (const float4*)(splats + gid);
+            sm[threadIdx.x * 3 + 0] = src[0];
+            sm[threadIdx.x * 3 + 1] = src[1];
+            sm[threadIdx.x * 3 + 2] = src[2];
+            sid[threadIdx.x] = gid;
+        }
+        __syncthreads();
+        int cnt = min(kTilePix, todo);
+        for (int j = 0; j < cnt; ++j) {
+            --contributor;
+            float4 a = sm[j * 3], b = sm[j * 3 + 1], c = sm[j * 3 + 2];
+            float dx = a.x - fx, dy = a.y - fy;
+            float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+            float G = __expf(power);
+            float alpha = fminf(kAlphaMax, b.y * G);
+            bool active = (contributor < last_contributor) && (power <= 0.0f) && (alpha >= kAlphaMin);
+            if (__ballot(active) == 0ull) continue;   // wave-uniform
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = 0.0f;
+            if (active) {
+                T = T / (1.0f - alpha);
+                float wgt = alpha * T;
+                // colour / depth recursion of the contribution behind this splat
+                acc_r = last_alpha * last_r + (1.0f - last_alpha) * acc_r;
+                acc_g = last_alpha * last_g + (1.0f - last_alpha) * acc_g;
+                acc_b = last_alpha * last_b + (1.0f - last_alpha) * acc_b;
+                acc_d = last_alpha * last_d + (1.0f - last_alpha) * acc_d;
+                last_r = b.z; last_g = b.w; last_b = c.x; last_d = c.y;
+                float dL_da = (b.z - acc_r) * gr + (b.w - acc_g) * gg + (c.x - acc_b) * gb + (c.y - acc_d) * gD;
+                dL_da *= T;
+                last_alpha = alpha;
+                float inv1ma = 1.0f / (1.0f - alpha);
+                dL_da += (-T_final * inv1ma) * bg_dot;   // background term of the colour output
+                dL_da += (T_final * inv1ma) * gA;        // alpha output  A = 1 - T_final
+                float dL_dG = b.y * dL_da;
+                float gdx = G * dx, gdy = G * dy;
+                float dG_ddelx = -gdx * a.z - gdy * a.w;
+                float dG_ddely = -gdy * b.x - gdx * a.w;
+                v[G_R] = wgt * gr; v[G_G] = wgt * gg; v[G_B] = wgt * gb; v[G_DEPTH] = wgt * gD;
+                v[G_MX] = dL_dG * dG_ddelx * ddelx_dx;
+                v[G_MY] = dL_dG * dG_ddely * ddely_dy;
+                v[G_CXX] = -0.5f * gdx * dx * dL_dG;
+                v[G_CXY] = -gdx * dy * dL_dG;
+                v[G_CYY] = -0.5f * gdy * dy * dL_dG;
+                v[G_OP] = G * dL_da;
+            }
+            float s = butterfly16(v, lane);
+            if ((lane & 3) == 0 && (lane >> 2) < G_USED)
+                unsafeAtomicAdd(grad_rec + (size_t)sid[j] * kGradSlots + (lane >> 2), s);
+        }
+    }
+}
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__constant__ float B_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                              -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float B_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                              -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return {x, y, z}; }
+__device__ __forceinline__ F3 operator*(float s, F3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// SH colour backward: writes dL_dsh (M x 3) and returns dL_dmean through the view direction
+__device__ F3 sh_backward(int D, int M, F3 pos, const float* campos, const float* __restrict__ sh, unsigned clamped,
+                          F3 dL_dRGB, float* __restrict__ dL_dsh) {
+    F3 dir_o = f3(pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]);
+    float len2 = dot(dir_o, dir_o);
+    float inv = 1.0f / sqrtf(len2);
+    float x = dir_o.x * inv, y = dir_o.y * inv, z = dir_o.z * inv;
+    if (clamped & 1u) dL_dRGB.x = 0.0f;
+    if (clamped & 2u) dL_dRGB.y = 0.0f;
+    if (clamped & 4u) dL_dRGB.z = 0.0f;
+    auto c = [&](int k) { return f3(sh[3 * k], sh[3 * k + 1], sh[3 * k + 2]); };
+    auto put = [&](int k, float s) {
+        dL_dsh[3 * k] = s * dL_dRGB.x; dL_dsh[3 * k + 1] = s * dL_dRGB.y; dL_dsh[3 * k + 2] = s * dL_dRGB.z;
+    };
+    F3 dx = f3(0, 0, 0), dy = f3(0, 0, 0), dz = f3(0, 0, 0);
+    put(0, SH_C0);
+    if (D > 0) {
+        put(1, -SH_C1 * y); put(2, SH_C1 * z); put(3, -SH_C1 * x);
+        dx = -SH_C1 * c(3); dy = -SH_C1 * c(1); dz = SH_C1 * c(2);
+        if (D > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            put(4, B_C2[0] * xy); put(5, B_C2[1] * yz); put(6, B_C2[2] * (2.f * zz - xx - yy));
+            put(7, B_C2[3] * xz); put(8, B_C2[4] * (xx - yy));
+            dx = dx + (B_C2[0] * y) * c(4) + (B_C2[2] * 2.f * -x) * c(6) + (B_C2[3] * z) * c(7) + (B_C2[4] * 2.f * x) * c(8);
+            dy = dy + (B_C2[0] * x) * c(4) + (B_C2[1] * z) * c(5) + (B_C2[2] * 2.f * -y) * c(6) + (B_C2[4] * 2.f * -y) * c(8);
+            dz = dz + (B_C2[1] * y) * c(5) + (B_C2[2] * 2.f * 2.f * z) * c(6) + (B_C2[3] * x) * c(7);
+            if (D > 2) {
+                put(9, B_C3[0] * y * (3.f * xx - yy)); put(10, B_C3[1] * xy * z);
+                put(11, B_C3[2] * y * (4.f * zz - xx - yy)); put(12, B_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+                put(13, B_C3[4] * x * (4.f * zz - xx - yy)); put(14, B_C3[5] * z * (xx - yy));
+                put(15, B_C3[6] * x * (xx - 3.f * yy));
+                dx = dx + (B_C3[0] * 3.f * 2.f * xy) * c(9) + (B_C3[1] * yz) * c(10) + (B_C3[2] * -2.f * xy) * c(11) +
+                     (B_C3[3] * -3.f * 2.f * xz) * c(12) + (B_C3[4] * (-3.f * xx + 4.f * zz - yy)) * c(13) +
+                     (B_C3[5] * 2.f * xz) * c(14) + (B_C3[6] * 3.f * (xx - yy)) * c(15);
+                dy = dy + (B_C3[0] * 3.f * (xx - yy)) * c(9) + (B_C3[1] * xz) * c(10) +
+                     (B_C3[2] * (-3.f * yy + 4.f * zz - xx)) * c(11) + (B_C3[3] * -3.f * 2.f * yz) * c(12) +
+                     (B_C3[4] * -2.f * xy) * c(13) + (B_C3[5] * -2.f * yz) * c(14) + (B_C3[6] * -3.f * 2.f * xy) * c(15);
+                dz = dz + (B_C3[1] * xy) * c(10) + (B_C3[2] * 4.f * 2.f * yz) * c(11) +
+                     (B_C3[3] * 3.f * (2.f * zz - xx - yy)) * c(12) + (B_C3[4] * 4.f * 2.f * xz) * c(13) +
+                     (B_C3[5] * (xx - yy)) * c(14);
+            }
+        }
+    }
+    for (int k = (D + 1) * (D + 1); k < M; ++k) put(k, 0.0f);
+    F3 dL_ddir = f3(dot(dx, dL_dRGB), dot(dy, dL_dRGB), dot(dz, dL_dRGB));
+    // d(v/|v|): (g - vhat (vhat . g)) / |v|
+    F3 vh = f3(x, y, z);
+    float vg = dot(vh, dL_ddir);
+    return f3((dL_ddir.x - x * vg) * inv, (dL_ddir.y - y * vg) * inv, (dL_ddir.z - z * vg) * inv);
+}
+
+__global__ void __launch_bounds__(256) k_preprocess_bwd(
+    int N, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+    const float* __restrict__ rots, const float* __restrict__ opacities, const float* __restrict__ shs,
+    const float* __restrict__ conf, float scale_mod, Camera cam, const int* __restrict__ radii, GeomState g,
+    const float* __restrict__ grad_rec, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dscales,
+    float* __restrict__ dL_drots, float* __restrict__ dL_dopacity, float* __restrict__ dL_dshs,
+    float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconf) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float* osh = dL_dshs + (size_t)i * M * 3;
+    if (radii[i] <= 0) {
+        for (int k = 0; k < 3; ++k) { dL_dmeans3D[3 * i + k] = 0.f; dL_dscales[3 * i + k] = 0.f; dL_dmeans2D[3 * i + k] = 0.f; }
+        for (int k = 0; k < 4; ++k) dL_drots[4 * i + k] = 0.f;
+        dL_dopacity[i] = 0.f;
+        if (dL_dconf) dL_dconf[i] = 0.f;
+        for (int k = 0; k < 3 * M; ++k) osh[k] = 0.f;
+        return;
+    }
+    const float* gr = grad_rec + (size_t)i * kGradSlots;
+    F3 p = f3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+    const float* v = cam.view;
+    F3 t = f3(v[0] * p.x + v[4] * p.y + v[8] * p.z + v[12], v[1] * p.x + v[5] * p.y + v[9] * p.z + v[13],
+              v[2] * p.x + v[6] * p.y + v[10] * p.z + v[14]);
+
+    // ---- conic -> 2D covariance
+    const float* cv = g.cov3D + 6 * (size_t)i;
+    float c0 = cv[0], c1 = cv[1], c2 = cv[2], c3 = cv[3], c4 = cv[4], c5 = cv[5];
+    float limx = kFovGuard * cam.tanfovx, limy = kFovGuard * cam.tanfovy;
+    float txtz = t.x / t.z, tytz = t.y / t.z;
+    float tx = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+    float ty = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+    float x_mul = (txtz < -limx || txtz > limx) ? 0.0f : 1.0f;
+    float y_mul = (tytz < -limy || tytz > limy) ? 0.0f : 1.0f;
+    float J00 = cam.focal_x / t.z, J02 = -(cam.focal_x * tx) / (t.z * t.z);
+    float J11 = cam.focal_y / t.z, J12 = -(cam.focal_y * ty) / (t.z * t.z);
+    float W00 = v[0], W01 = v[4], W02 = v[8], W10 = v[1], W11 = v[5], W12 = v[9], W20 = v[2], W21 = v[6], W22 = v[10];
+    float T00 = J00 * W00 + J02 * W20, T01 = J00 * W01 + J02 * W21, T02 = J00 * W02 + J02 * W22;
+    float T10 = J11 * W10 + J12 * W20, T11 = J11 * W11 + J12 * W21, T12 = J11 * W12 + J12 * W22;
+    float a0 = c0 * T00 + c1 * T01 + c2 * T02, a1 = c1 * T00 + c3 * T01 + c4 * T02, a2 = c2 * T00 + c4 * T01 + c5 * T02;
+    float b0 = c0 * T10 + c1 * T11 + c2 * T12, b1 = c1 * T10 + c3 * T11 + c4 * T12, b2 = c2 * T10 + c4 * T11 + c5 * T12;
+    float A = T00 * a0 + T01 * a1 + T02 * a2 + kLowPass;
+    float B = T00 * b0 + T01 * b1 + T02 * b2;
+    float C = T10 * b0 + T11 * b1 + T12 * b2 + kLowPass;
+    float den = A * C - B * B;
+    float den2inv = 1.0f / (den * den + 0.0000001f);
+    float gxx = gr[G_CXX], gxy = gr[G_CXY], gyy = gr[G_CYY];
+    float dL_dA = 0.f, dL_dB = 0.f, dL_dC = 0.f;
+    if (den2inv != 0.0f) {
+        dL_dA = den2inv * (-C * C * gxx + B * C * gxy + (den - A * C) * gyy);
+        dL_dC = den2inv * ((den - A * C) * gxx + A * B * gxy - A * A * gyy);
+        dL_dB = den2inv * (2.f * B * C * gxx - (den + 2.f * B * B) * gxy + 2.f * A * B * gyy);
+    }
+    // dL/dSigma (stored upper triangle; off-diagonals count both symmetric entries)
+    float dS0 = T00 * T00 * dL_dA + T00 * T10 * dL_dB + T10 * T10 * dL_dC;
+    float dS3 = T01 * T01 * dL_dA + T01 * T11 * dL_dB + T11 * T11 * dL_dC;
+    float dS5 = T02 * T02 * dL_dA + T02 * T12 * dL_dB + T12 * T12 * dL_dC;
+    float dS1 = 2.f * T00 * T01 * dL_dA + (T00 * T11 + T01 * T10) * dL_dB + 2.f * T10 * T11 * dL_dC;
+    float dS2 = 2.f * T00 * T02 * dL_dA + (T00 * T12 + T02 * T10) * dL_dB + 2.f * T10 * T12 * dL_dC;
+    float dS4 = 2.f * T02 * T01 * dL_dA + (T01 * T12 + T02 * T11) * dL_dB + 2.f * T11 * T12 * dL_dC;
+    // dL/dT, T = J W (2x3)
+    float dT00 = 2.f * a0 * dL_dA + b0 * dL_dB, dT01 = 2.f * a1 * dL_dA + b1 * dL_dB, dT02 = 2.f * a2 * dL_dA + b2 * dL_dB;
+    float dT10 = 2.f * b0 * dL_dC + a0 * dL_dB, dT11 = 2.f * b1 * dL_dC + a1 * dL_dB, dT12 = 2.f * b2 * dL_dC + a2 * dL_dB;
+    float dJ00 = W00 * dT00 + W01 * dT01 + W02 * dT02;
+    float dJ02 = W20 * dT00 + W21 * dT01 + W22 * dT02;
+    float dJ11 = W10 * dT10 + W11 * dT11 + W12 * dT12;
+    float dJ12 = W20 * dT10 + W21 * dT11 + W22 * dT12;
+    float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+    float dtx = x_mul * -cam.focal_x * tz2 * dJ02;
+    float dty = y_mul * -cam.focal_y * tz2 * dJ12;
+    float dtz = -cam.focal_x * tz2 * dJ00 - cam.focal_y * tz2 * dJ11 + (2.f * cam.focal_x * tx) * tz3 * dJ02 +
+                (2.f * cam.focal_y * ty) * tz3 * dJ12;
+    // depth output: d(view z)/d(mean)
+    dtz += gr[G_DEPTH];
+    F3 dmean = f3(W00 * dtx + W10 * dty + W20 * dtz, W01 * dtx + W11 * dty + W21 * dtz, W02 * dtx + W12 * dty + W22 * dtz);
+
+    // ---- screen-space mean (NDC) -> mean
+    const float* pj = cam.proj;
+    float hx = pj[0] * p.x + pj[4] * p.y + pj[8] * p.z + pj[12];
+    float hy = pj[1] * p.x + pj[5] * p.y + pj[9] * p.z + pj[13];
+    float hw = pj[3] * p.x + pj[7] * p.y + pj[11] * p.z + pj[15];
+    float mw = 1.0f / (hw + 0.0000001f);
+    float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
+    float g2x = gr[G_MX], g2y = gr[G_MY];
+    dmean.x += (pj[0] * mw - pj[3] * mul1) * g2x + (pj[1] * mw - pj[3] * mul2) * g2y;
+    dmean.y += (pj[4] * mw - pj[7] * mul1) * g2x + (pj[5] * mw - pj[7] * mul2) * g2y;
+    dmean.z += (pj[8] * mw - pj[11] * mul1) * g2x + (pj[9] * mw - pj[11] * mul2) * g2y;
+    dL_dmeans2D[3 * i] = g2x; dL_dmeans2D[3 * i + 1] = g2y; dL_dmeans2D[3 * i + 2] = 0.f;
+
+    // ---- colour -> SH and mean
+    F3 dm_sh = sh_backward(D, M, p, cam.campos, shs + (size_t)i * M * 3, g.clamped[i], f3(gr[G_R], gr[G_G], gr[G_B]), osh);
+    dmean = dmean + dm_sh;
+    dL_dmeans3D[3 * i] = dmean.x; dL_dmeans3D[3 * i + 1] = dmean.y; dL_dmeans3D[3 * i + 2] = dmean.z;
+
+    // ---- opacity / confidence (blend used opacity * confidence)
+    float cf = conf ? conf[i] : 1.0f;
+    dL_dopacity[i] = gr[G_OP] * cf;
+    if (dL_dconf) dL_dconf[i] = gr[G_OP] * opacities[i];
+
+    // ---- Sigma = M M^T, M = R S  -> scale, rotation
+    float sx = scale_mod * scales[3 * i], sy = scale_mod * scales[3 * i + 1], sz = scale_mod * scales[3 * i + 2];
+    float qr = rots[4 * i], qx = rots[4 * i + 1], qy = rots[4 * i + 2], qz = rots[4 * i + 3];
+    float R00 = 1.f - 2.f * (qy * qy + qz * qz), R01 = 2.f * (qx * qy - qr * qz), R02 = 2.f * (qx * qz + qr * qy);
+    float R10 = 2.f * (qx * qy + qr * qz), R11 = 1.f - 2.f * (qx * qx + qz * qz), R12 = 2.f * (qy * qz - qr * qx);
+    float R20 = 2.f * (qx * qz - qr * qy), R21 = 2.f * (qy * qz + qr * qx), R22 = 1.f - 2.f * (qx * qx + qy * qy);
+    float m00 = R00 * sx, m01 = R01 * sy, m02 = R02 * sz;
+    float m10 = R10 * sx, m11 = R11 * sy, m12 = R12 * sz;
+    float m20 = R20 * sx, m21 = R21 * sy, m22 = R22 * sz;
+    // full symmetric gradient G (off-diagonals halved); dL/dM = 2 G M
+    float G00 = dS0, G11 = dS3, G22 = dS5, G01 = 0.5f * dS1, G02 = 0.5f * dS2, G12 = 0.5f * dS4;
+    float dM00 = 2.f * (G00 * m00 + G01 * m10 + G02 * m20), dM01 = 2.f * (G00 * m01 + G01 * m11 + G02 * m21),
+          dM02 = 2.f * (G00 * m02 + G01 * m12 + G02 * m22);
+    float dM10 = 2.f * (G01 * m00 + G11 * m10 + G12 * m20), dM11 = 2.f * (G01 * m01 + G11 * m11 + G12 * m21),
+          dM12 = 2.f * (G01 * m02 + G11 * m12 + G12 * m22);
+    float dM20 = 2.f * (G02 * m00 + G12 * m10 + G22 * m20), dM21 = 2.f * (G02 * m01 + G12 * m11 + G22 * m21),
+          dM22 = 2.f * (G02 * m02 + G12 * m12 + G22 * m22);
+    dL_dscales[3 * i] = scale_mod * (dM00 * R00 + dM10 * R10 + dM20 * R20);
+    dL_dscales[3 * i + 1] = scale_mod * (dM01 * R01 + dM11 * R11 + dM21 * R21);
+    dL_dscales[3 * i + 2] = scale_mod * (dM02 * R02 + dM12 * R12 + dM22 * R22);
+    float dR00 = dM00 * sx, dR01 = dM01 * sy, dR02 = dM02 * sz;
+    float dR10 = dM10 * sx, dR11 = dM11 * sy, dR12 = dM12 * sz;
+    float dR20 = dM20 * sx, dR21 = dM21 * sy, dR22 = dM22 * sz;
+    dL_drots[4 * i] = 2.f * (-qz * dR01 + qy * dR02 + qz * dR10 - qx * dR12 - qy * dR20 + qx * dR21);
+    dL_drots[4 * i + 1] = 2.f * (qy * dR01 + qz * dR02 + qy * dR10 - 2.f * qx * dR11 - qr * dR12 + qz * dR20 + qr * dR21 -
+                                 2.f * qx * dR22);
+    dL_drots[4 * i + 2] = 2.f * (-2.f * qy * dR00 + qx * dR01 + qr * dR02 + qx * dR10 + qz * dR12 - qr * dR20 + qz * dR21 -
+                                 2.f * qy * dR22);
+    dL_drots[4 * i + 3] = 2.f * (-2.f * qz * dR00 - qr * dR01 + qx * dR02 + qr * dR10 - 2.f * qz * dR11 + qy * dR12 +
+                                 qx * dR20 + qy * dR21);
+}
+
+}  // namespace
+
+extern "C" size_t syn3r_raster_backward_workspace_bytes(int N) {
+    return N > 0 ? align256((size_t)N * kGradSlots * sizeof(float)) : 0;
+}
+
+extern "C" int syn3r_raster_backward(int N, int sh_degree, int sh_coeffs, long long P, const float* means3D,
+                                     const float* scales, const float* rotations, const float* opacities,
+                                     const float* shs, const float* confidence, float scale_modifier,
+                                     const float* viewmatrix, const float* projmatrix, const float* campos,
+                                     float tanfovx, float tanfovy, int H, int W, const float* bg, const int* radii,
+                                     void* geom, size_t geom_bytes_, const unsigned* point_list, void* image,
+                                     size_t image_bytes_, const float* dL_dcolor, const float* dL_ddepth,
+                                     const float* dL_dalpha, float* dL_dmeans3D, float* dL_dscales,
+                                     float* dL_drotations, float* dL_dopacities, float* dL_dshs, float* dL_dmeans2D,
+                                     float* dL_dconfidence, void* workspace, size_t workspace_bytes, void* stream_) {
+    SYN3R_REQUIRE(N > 0 && H > 0 && W > 0 && P >= 0, "raster_backward: bad sizes N=%d H=%d W=%d P=%lld", N, H, W, P);
+    SYN3R_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && sh_coeffs >= (sh_degree + 1) * (sh_degree + 1),
+                  "raster_backward: bad SH configuration");
+    SYN3R_REQUIRE(means3D && scales && rotations && opacities && shs && viewmatrix && projmatrix && campos && bg && radii,
+                  "raster_backward: null input");
+    SYN3R_REQUIRE(dL_dcolor && dL_dmeans3D && dL_dscales && dL_drotations && dL_dopacities && dL_dshs && dL_dmeans2D,
+                  "raster_backward: null gradient buffer");
+    SYN3R_REQUIRE(P == 0 || point_list, "raster_backward: point list required");
+    size_t need = syn3r_raster_backward_workspace_bytes(N);
+    if (!geom || geom_bytes_ < geom_bytes(N) || !image || image_bytes_ < image_bytes(H, W) || !workspace ||
+        workspace_bytes < need) {
+        set_error("raster_backward: state/workspace buffer too small");
+        return SYN3R_E_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    GeomState g = carve_geom(geom, N);
+    ImageState im = carve_image(image, H, W);
+    Camera cam;
+    raster_fill_camera(cam, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W);
+    float* grad_rec = (float*)workspace;
+    int rc = check_hip(hipMemsetAsync(grad_rec, 0, need, stream), "memset grads");
+    if (rc) return rc;
+    const unsigned tiles = (unsigned)(cam.grid_x * cam.grid_y);
+    if (P > 0)
+        hipLaunchKernelGGL(k_render_bwd, dim3(tiles), dim3(kTilePix), 0, stream, H, W, cam.grid_x, cam.grid_y, im.ranges,
+                           point_list, g.splats, bg[0], bg[1], bg[2], im.n_contrib, im.final_T, dL_dcolor, dL_ddepth,
+                           dL_dalpha, grad_rec);
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
+                       scales, rotations, opacities, shs, confidence, scale_modifier, cam, radii, g, grad_rec,
+                       dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacities, dL_dshs, dL_dmeans2D, dL_dconfidence);
+    SYN3R_LAUNCH_CHECK("raster_backward launch");
+    return SYN3R_OK;
+}

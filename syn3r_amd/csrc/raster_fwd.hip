@@ -1,0 +1,456 @@
+// Gaussian rasteriser, forward: projection (EWA), tile binning, depth sort, front-to-back
+// alpha blend with colour / depth / alpha outputs and a per-Gaussian confidence factor.
+//
+// Replaces the reference's `gsTrainer.render_view(cam)` hot kernels (call sites
+// model/diffusionGS.py:154,166); the CUDA source is an un-vendored submodule
+// (SURVEY.md §8c), so this follows the published 3DGS algorithm — see
+// raster_common.h.  PARITY UNPINNED against the CUDA build; pinned against
+// oracle/raster_oracle.py.
+//
+// MI355X mapping: one 16x16 tile = one 256-thread workgroup = 4 wavefronts, a
+// wavefront covers 4 rows x 16 pixels.  Sorted splats are staged through LDS in
+// batches of 256 as 48-byte records (3 x 16-byte loads per lane, broadcast reads
+// in the blend loop).  Tiles are dealt to XCDs in contiguous chunks so that
+// neighbouring tiles (which share splats) hit the same L2.
+#include "common.h"
+#include "raster_common.h"
+
+using namespace syn3r;
+
+namespace syn3r {
+
+size_t geom_bytes(int N) {
+    size_t n = (size_t)N;
+    size_t b = 256;                         // header
+    b += align256(n * 4);                   // depths
+    b += align256(n * 8);                   // means2D
+    b += align256(n * 24);                  // cov3D
+    b += align256(n * 16);                  // conic_opacity
+    b += align256(n * 12);                  // rgb
+    b += align256(n * 4);                   // clamped
+    b += align256(n * 4);                   // tiles_touched
+    b += align256(n * 4);                   // point_offsets
+    b += align256(n * sizeof(Splat));       // splats
+    b += scan_scratch_bytes(n);
+    return b;
+}
+
+GeomState carve_geom(void* buf, int N) {
+    size_t n = (size_t)N;
+    char* p = (char*)buf;
+    GeomState g;
+    g.header = (unsigned*)p; p += 256;
+    g.depths = (float*)p; p += align256(n * 4);
+    g.means2D = (float*)p; p += align256(n * 8);
+    g.cov3D = (float*)p; p += align256(n * 24);
+    g.conic_opacity = (float*)p; p += align256(n * 16);
+    g.rgb = (float*)p; p += align256(n * 12);
+    g.clamped = (unsigned*)p; p += align256(n * 4);
+    g.tiles_touched = (unsigned*)p; p += align256(n * 4);
+    g.point_offsets = (unsigned*)p; p += align256(n * 4);
+    g.splats = (Splat*)p; p += align256(n * sizeof(Splat));
+    g.scan_scratch = p;
+    return g;
+}
+
+size_t image_bytes(int H, int W) {
+    size_t tiles = (size_t)((W + kTileX - 1) / kTileX) * ((H + kTileY - 1) / kTileY);
+    size_t px = (size_t)H * W;
+    return align256(tiles * 8) + align256(px * 4) + align256(px * 4);
+}
+
+ImageState carve_image(void* buf, int H, int W) {
+    size_t tiles = (size_t)((W + kTileX - 1) / kTileX) * ((H + kTileY - 1) / kTileY);
+    size_t px = (size_t)H * W;
+    char* p = (char*)buf;
+    ImageState s;
+    s.ranges = (uint2*)p; p += align256(tiles * 8);
+    s.n_contrib = (unsigned*)p; p += align256(px * 4);
+    s.final_T = (float*)p;
+    return s;
+}
+
+size_t binning_bytes(long long P) {
+    size_t n = (size_t)(P > 0 ? P : 1);
+    return 2 * align256(n * 8) + 2 * align256(n * 4) + sort_scratch_bytes(n) + 256;
+}
+
+BinningState carve_binning(void* buf, long long P) {
+    size_t n = (size_t)(P > 0 ? P : 1);
+    char* p = (char*)buf;
+    BinningState b;
+    b.keys_a = (unsigned long long*)p; p += align256(n * 8);
+    b.keys_b = (unsigned long long*)p; p += align256(n * 8);
+    b.vals_a = (unsigned*)p; p += align256(n * 4);
+    b.vals_b = (unsigned*)p; p += align256(n * 4);
+    b.sort_scratch = p;
+    return b;
+}
+
+}  // namespace syn3r
+
+namespace {
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                               -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                               -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+__device__ __forceinline__ float3 xf43(const float* m, float3 p) {
+    return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+__device__ __forceinline__ float4 xf44(const float* m, float3 p) {
+    return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14], m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
+}
+
+__device__ __forceinline__ float ndc2pix(float v, int S) { return ((v + 1.0f) * (float)S - 1.0f) * 0.5f; }
+
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int& x0, int& y0, int& x1,
+                                          int& y1) {
+    x0 = min(gx, max(0, (int)((px - radius) / kTileX)));
+    y0 = min(gy, max(0, (int)((py - radius) / kTileY)));
+    x1 = min(gx, max(0, (int)((px + radius + kTileX - 1) / kTileX)));
+    y1 = min(gy, max(0, (int)((py + radius + kTileY - 1) / kTileY)));
+}
+
+// view-dependent colour from spherical harmonics (degree D <= 3), +0.5, clamped at 0
+__device__ float3 sh_to_rgb(int D, int M, float3 pos, const float* campos, const float* __restrict__ sh,
+                            unsigned& clamped) {
+    float3 dir = make_float3(pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]);
+    float inv = 1.0f / sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+    dir.x *= inv; dir.y *= inv; dir.z *= inv;
+    auto c = [&](int k) { return make_float3(sh[3 * k], sh[3 * k + 1], sh[3 * k + 2]); };
+    auto mad = [](float3& a, float s, float3 b) { a.x += s * b.x; a.y += s * b.y; a.z += s * b.z; };
+    float3 res = make_float3(0, 0, 0);
+    mad(res, SH_C0, c(0));
+    if (D > 0) {
+        float x = dir.x, y = dir.y, z = dir.z;
+        mad(res, -SH_C1 * y, c(1));
+        mad(res, SH_C1 * z, c(2));
+        mad(res, -SH_C1 * x, c(3));
+        if (D > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            mad(res, SH_C2[0] * xy, c(4));
+            mad(res, SH_C2[1] * yz, c(5));
+            mad(res, SH_C2[2] * (2.0f * zz - xx - yy), c(6));
+            mad(res, SH_C2[3] * xz, c(7));
+            mad(res, SH_C2[4] * (xx - yy), c(8));
+            if (D > 2) {
+                mad(res, SH_C3[0] * y * (3.0f * xx - yy), c(9));
+                mad(res, SH_C3[1] * xy * z, c(10));
+                mad(res, SH_C3[2] * y * (4.0f * zz - xx - yy), c(11));
+                mad(res, SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), c(12));
+                mad(res, SH_C3[4] * x * (4.0f * zz - xx - yy), c(13));
+                mad(res, SH_C3[5] * z * (xx - yy), c(14));
+                mad(res, SH_C3[6] * x * (xx - 3.0f * yy), c(15));
+            }
+        }
+    }
+    res.x += 0.5f; res.y += 0.5f; res.z += 0.5f;
+    clamped = (res.x < 0.0f ? 1u : 0u) | (res.y < 0.0f ? 2u : 0u) | (res.z < 0.0f ? 4u : 0u);
+    return make_float3(fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f));
+}
+
+__global__ void __launch_bounds__(256) k_preprocess(int N, int D, int M, const float* __restrict__ means3D,
+                                                    const float* __restrict__ scales,
+                                                    const float* __restrict__ rots,
+                                                    const float* __restrict__ opacities,
+                                                    const float* __restrict__ shs, const float* __restrict__ conf,
+                                                    float scale_mod, Camera cam, int* __restrict__ radii,
+                                                    GeomState g) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    radii[i] = 0;
+    g.tiles_touched[i] = 0;
+    float3 p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+    float3 t = xf43(cam.view, p);
+    if (t.z <= kNearClip) return;
+    float4 ph = xf44(cam.proj, p);
+    float pw = 1.0f / (ph.w + 0.0000001f);
+    float ndcx = ph.x * pw, ndcy = ph.y * pw;
+
+    // 3D covariance  Sigma = R S^2 R^T  (q = (r, x, y, z), not renormalised here)
+    float sx = scale_mod * scales[3 * i], sy = scale_mod * scales[3 * i + 1], sz = scale_mod * scales[3 * i + 2];
+    float qr = rots[4 * i], qx = rots[4 * i + 1], qy = rots[4 * i + 2], qz = rots[4 * i + 3];
+    float R00 = 1.f - 2.f * (qy * qy + qz * qz), R01 = 2.f * (qx * qy - qr * qz), R02 = 2.f * (qx * qz + qr * qy);
+    float R10 = 2.f * (qx * qy + qr * qz), R11 = 1.f - 2.f * (qx * qx + qz * qz), R12 = 2.f * (qy * qz - qr * qx);
+    float R20 = 2.f * (qx * qz - qr * qy), R21 = 2.f * (qy * qz + qr * qx), R22 = 1.f - 2.f * (qx * qx + qy * qy);
+    float m00 = R00 * sx, m01 = R01 * sy, m02 = R02 * sz;   // M = R S
+    float m10 = R10 * sx, m11 = R11 * sy, m12 = R12 * sz;
+    float m20 = R20 * sx, m21 = R21 * sy, m22 = R22 * sz;
+    float c0 = m00 * m00 + m01 * m01 + m02 * m02;   // Sigma = M M^T
+    float c1 = m00 * m10 + m01 * m11 + m02 * m12;
+    float c2 = m00 * m20 + m01 * m21 + m02 * m22;
+    float c3 = m10 * m10 + m11 * m11 + m12 * m12;
+    float c4 = m10 * m20 + m11 * m21 + m12 * m22;
+    float c5 = m20 * m20 + m21 * m21 + m22 * m22;
+    float* cv = g.cov3D + 6 * (size_t)i;
+    cv[0] = c0; cv[1] = c1; cv[2] = c2; cv[3] = c3; cv[4] = c4; cv[5] = c5;
+
+    // EWA: cov2D = (J W) Sigma (J W)^T, W = rotation part of the view matrix
+    float limx = kFovGuard * cam.tanfovx, limy = kFovGuard * cam.tanfovy;
+    float tx = fminf(limx, fmaxf(-limx, t.x / t.z)) * t.z;
+    float ty = fminf(limy, fmaxf(-limy, t.y / t.z)) * t.z;
+    float J00 = cam.focal_x / t.z, J02 = -(cam.focal_x * tx) / (t.z * t.z);
+    float J11 = cam.focal_y / t.z, J12 = -(cam.focal_y * ty) / (t.z * t.z);
+    const float* v = cam.view;   // W[r][c] = v[c*4+r]
+    float T00 = J00 * v[0] + J02 * v[2], T01 = J00 * v[4] + J02 * v[6], T02 = J00 * v[8] + J02 * v[10];
+    float T10 = J11 * v[1] + J12 * v[2], T11 = J11 * v[5] + J12 * v[6], T12 = J11 * v[9] + J12 * v[10];
+    float a0 = c0 * T00 + c1 * T01 + c2 * T02, a1 = c1 * T00 + c3 * T01 + c4 * T02, a2 = c2 * T00 + c4 * T01 + c5 * T02;
+    float b0 = c0 * T10 + c1 * T11 + c2 * T12, b1 = c1 * T10 + c3 * T11 + c4 * T12, b2 = c2 * T10 + c4 * T11 + c5 * T12;
+    float cxx = T00 * a0 + T01 * a1 + T02 * a2 + kLowPass;
+    float cxy = T00 * b0 + T01 * b1 + T02 * b2;
+    float cyy = T10 * b0 + T11 * b1 + T12 * b2 + kLowPass;
+
+    float det = cxx * cyy - cxy * cxy;
+    if (det == 0.0f) return;
+    float det_inv = 1.0f / det;
+    float conx = cyy * det_inv, cony = -cxy * det_inv, conz = cxx * det_inv;
+    float mid = 0.5f * (cxx + cyy);
+    float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+    float lambda1 = mid + sq, lambda2 = mid - sq;
+    int radius = (int)ceilf(3.0f * sqrtf(fmaxf(lambda1, lambda2)));
+    float px = ndc2pix(ndcx, cam.W), py = ndc2pix(ndcy, cam.H);
+    int x0, y0, x1, y1;
+    tile_rect(px, py, radius, cam.grid_x, cam.grid_y, x0, y0, x1, y1);
+    int area = (x1 - x0) * (y1 - y0);
+    if (area == 0) return;
+
+    unsigned cl;
+    float3 rgb = sh_to_rgb(D, M, p, cam.campos, shs + (size_t)i * M * 3, cl);
+    float op = opacities[i];
+    float cf = conf ? conf[i] : 1.0f;
+    g.depths[i] = t.z;
+    radii[i] = radius;
+    g.means2D[2 * (size_t)i] = px;
+    g.means2D[2 * (size_t)i + 1] = py;
+    float* co = g.conic_opacity + 4 * (size_t)i;
+    co[0] = conx; co[1] = cony; co[2] = conz; co[3] = op;
+    g.rgb[3 * (size_t)i] = rgb.x; g.rgb[3 * (size_t)i + 1] = rgb.y; g.rgb[3 * (size_t)i + 2] = rgb.z;
+    g.clamped[i] = cl;
+    g.tiles_touched[i] = (unsigned)area;
+    Splat s;
+    s.x = px; s.y = py; s.cxx = conx; s.cxy = cony; s.cyy = conz; s.opacity = op * cf;
+    s.r = rgb.x; s.g = rgb.y; s.b = rgb.z; s.depth = t.z; s.pad0 = 0.f; s.pad1 = 0.f;
+    g.splats[i] = s;
+}
+
+__global__ void __launch_bounds__(256) k_dup_keys(int N, const float* __restrict__ means2D,
+                                                  const float* __restrict__ depths,
+                                                  const unsigned* __restrict__ offsets,
+                                                  const int* __restrict__ radii, int gx, int gy,
+                                                  unsigned long long* __restrict__ keys,
+                                                  unsigned* __restrict__ vals) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    int r = radii[i];
+    if (r <= 0) return;
+    unsigned off = offsets[i];
+    int x0, y0, x1, y1;
+    tile_rect(means2D[2 * (size_t)i], means2D[2 * (size_t)i + 1], r, gx, gy, x0, y0, x1, y1);
+    unsigned dbits = __float_as_uint(depths[i]);
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            unsigned long long key = ((unsigned long long)(unsigned)(y * gx + x) << 32) | dbits;
+            keys[off] = key;
+            vals[off] = (unsigned)i;
+            ++off;
+        }
+}
+
+__global__ void __launch_bounds__(256) k_tile_ranges(long long P, const unsigned long long* __restrict__ keys,
+                                                     uint2* __restrict__ ranges) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    unsigned cur = (unsigned)(keys[i] >> 32);
+    if (i == 0) ranges[cur].x = 0;
+    else {
+        unsigned prev = (unsigned)(keys[i - 1] >> 32);
+        if (cur != prev) {
+            ranges[prev].y = (unsigned)i;
+            ranges[cur].x = (unsigned)i;
+        }
+    }
+    if (i == P - 1) ranges[cur].y = (unsigned)P;
+}
+
+// contiguous-chunk-per-XCD remap of a 1-D block id (bijective for any block count)
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8, k = bid / 8;
+    unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}
+
+__global__ void __launch_bounds__(kTilePix) k_render(int H, int W, int gx, int gy, const uint2* __restrict__ ranges,
+                                                     const unsigned* __restrict__ point_list,
+                                                     const Splat* __restrict__ splats, float bg0, float bg1,
+                                                     float bg2, unsigned* __restrict__ n_contrib,
+                                                     float* __restrict__ final_T, float* __restrict__ out_color,
+                                                     float* __restrict__ out_depth, float* __restrict__ out_alpha) {
+    __shared__ float4 sm[kTilePix * 3];
+    const unsigned tile = xcd_remap(blockIdx.x, (unsigned)(gx * gy));
+    const int tx = tile % gx, ty = tile / gx;
+    const int lx = threadIdx.x % kTileX, ly = threadIdx.x / kTileX;
+    const int px = tx * kTileX + lx, py = ty * kTileY + ly;
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+    const int rounds = (total + kTilePix - 1) / kTilePix;
+
+    bool done = !inside;
+    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dp = 0.f;
+    unsigned contributor = 0, last = 0;
+    int todo = total;
+    for (int rd = 0; rd < rounds; ++rd, todo -= kTilePix) {
+        if (__syncthreads_count(done) == kTilePix) break;
+        int idx = rd * kTilePix + threadIdx.x;
+        if (idx < total) {
+            unsigned gid = point_list[range.x + idx];
+            const float4* src = (const float4*)(splats + gid);
+            sm[threadIdx.x * 3 + 0] = src[0];
+            sm[threadIdx.x * 3 + 1] = src[1];
+            sm[threadIdx.x * 3 + 2] = src[2];
+        }
+        __syncthreads();
+        int cnt = min(kTilePix, todo);
+        for (int j = 0; !done && j < cnt; ++j) {
+            ++contributor;
+            float4 a = sm[j * 3], b = sm[j * 3 + 1], c = sm[j * 3 + 2];
+            // a = (x, y, cxx, cxy)  b = (cyy, opacity, r, g)  c = (b, depth, -, -)
+            float dx = a.x - fx, dy = a.y - fy;
+            float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+            if (power > 0.0f) continue;
+            float alpha = fminf(kAlphaMax, b.y * __expf(power));
+            if (alpha < kAlphaMin) continue;
+            float test_T = T * (1.0f - alpha);
+            if (test_T < kTransmittanceMin) { done = true; continue; }
+            float w = alpha * T;
+            Cr += b.z * w; Cg += b.w * w; Cb += c.x * w; Dp += c.y * w;
+            T = test_T;
+            last = contributor;
+        }
+    }
+    if (inside) {
+        size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = Cr + T * bg0;
+        out_color[hw + pix] = Cg + T * bg1;
+        out_color[2 * hw + pix] = Cb + T * bg2;
+        out_depth[pix] = Dp;
+        out_alpha[pix] = 1.0f - T;
+    }
+}
+
+int bits_for(unsigned v) {
+    int b = 0;
+    while (v) { ++b; v >>= 1; }
+    return b;
+}
+
+void fill_camera(Camera& cam, const float* view, const float* proj, const float* campos, float tanfovx, float tanfovy,
+                 int H, int W) {
+    for (int i = 0; i < 16; ++i) { cam.view[i] = view[i]; cam.proj[i] = proj[i]; }
+    for (int i = 0; i < 3; ++i) cam.campos[i] = campos[i];
+    cam.tanfovx = tanfovx; cam.tanfovy = tanfovy;
+    cam.focal_x = W / (2.0f * tanfovx);
+    cam.focal_y = H / (2.0f * tanfovy);
+    cam.H = H; cam.W = W;
+    cam.grid_x = (W + kTileX - 1) / kTileX;
+    cam.grid_y = (H + kTileY - 1) / kTileY;
+}
+
+}  // namespace
+
+namespace syn3r {
+void raster_fill_camera(Camera& cam, const float* view, const float* proj, const float* campos, float tanfovx,
+                        float tanfovy, int H, int W) {
+    fill_camera(cam, view, proj, campos, tanfovx, tanfovy, H, W);
+}
+}  // namespace syn3r
+
+extern "C" size_t syn3r_raster_geom_bytes(int N) { return N > 0 ? geom_bytes(N) : 0; }
+extern "C" size_t syn3r_raster_image_bytes(int H, int W) { return (H > 0 && W > 0) ? image_bytes(H, W) : 0; }
+extern "C" size_t syn3r_raster_binning_bytes(long long P) { return P >= 0 ? binning_bytes(P) : 0; }
+
+extern "C" int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, const float* means3D,
+                                       const float* scales, const float* rotations, const float* opacities,
+                                       const float* shs, const float* confidence, float scale_modifier,
+                                       const float* viewmatrix, const float* projmatrix, const float* campos,
+                                       float tanfovx, float tanfovy, int H, int W, int* radii, void* geom,
+                                       size_t geom_bytes_, long long* num_rendered_host, void* stream_) {
+    SYN3R_REQUIRE(N > 0 && H > 0 && W > 0, "raster_preprocess: bad sizes N=%d H=%d W=%d", N, H, W);
+    SYN3R_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && sh_coeffs >= (sh_degree + 1) * (sh_degree + 1),
+                  "raster_preprocess: sh_degree %d needs >= %d coefficients, got %d", sh_degree,
+                  (sh_degree + 1) * (sh_degree + 1), sh_coeffs);
+    SYN3R_REQUIRE(means3D && scales && rotations && opacities && shs && viewmatrix && projmatrix && campos && radii,
+                  "raster_preprocess: null argument");
+    SYN3R_REQUIRE(tanfovx > 0 && tanfovy > 0, "raster_preprocess: bad field of view");
+    if (!geom || geom_bytes_ < geom_bytes(N)) {
+        set_error("raster_preprocess: geometry buffer %zu < %zu", geom_bytes_, geom_bytes(N));
+        return SYN3R_E_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    GeomState g = carve_geom(geom, N);
+    Camera cam;
+    fill_camera(cam, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W);
+    hipLaunchKernelGGL(k_preprocess, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
+                       scales, rotations, opacities, shs, confidence, scale_modifier, cam, radii, g);
+    int rc = exclusive_scan_u32(g.tiles_touched, g.point_offsets, (size_t)N, g.header, g.scan_scratch, stream);
+    if (rc) return rc;
+    SYN3R_LAUNCH_CHECK("raster_preprocess launch");
+    if (num_rendered_host) {
+        unsigned total = 0;
+        rc = check_hip(hipMemcpyAsync(&total, g.header, 4, hipMemcpyDeviceToHost, stream), "num_rendered copy");
+        if (rc) return rc;
+        rc = check_hip(hipStreamSynchronize(stream), "num_rendered sync");
+        if (rc) return rc;
+        *num_rendered_host = (long long)total;
+    }
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const int* radii, void* geom,
+                                   size_t geom_bytes_, void* binning, size_t binning_bytes_, void* image,
+                                   size_t image_bytes_, long long P, float* out_color, float* out_depth,
+                                   float* out_alpha, unsigned** point_list_out, void* stream_) {
+    SYN3R_REQUIRE(N > 0 && H > 0 && W > 0 && P >= 0 && P < (1ll << 31), "raster_render: bad sizes N=%d H=%d W=%d P=%lld",
+                  N, H, W, P);
+    SYN3R_REQUIRE(bg && radii && out_color && out_depth && out_alpha, "raster_render: null argument");
+    if (!geom || geom_bytes_ < geom_bytes(N) || !image || image_bytes_ < image_bytes(H, W) || !binning ||
+        binning_bytes_ < binning_bytes(P)) {
+        set_error("raster_render: state buffer too small (geom %zu/%zu image %zu/%zu binning %zu/%zu)", geom_bytes_,
+                  geom_bytes(N), image_bytes_, image_bytes(H, W), binning_bytes_, binning_bytes(P));
+        return SYN3R_E_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    GeomState g = carve_geom(geom, N);
+    ImageState im = carve_image(image, H, W);
+    BinningState bn = carve_binning(binning, P);
+    const int gx = (W + kTileX - 1) / kTileX, gy = (H + kTileY - 1) / kTileY;
+    const size_t tiles = (size_t)gx * gy;
+    int rc = check_hip(hipMemsetAsync(im.ranges, 0, tiles * 8, stream), "memset ranges");
+    if (rc) return rc;
+    unsigned* point_list = bn.vals_a;
+    if (P > 0) {
+        hipLaunchKernelGGL(k_dup_keys, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, g.means2D, g.depths,
+                           g.point_offsets, radii, gx, gy, bn.keys_a, bn.vals_a);
+        int in_b = 0;
+        rc = radix_sort_pairs(bn.keys_a, bn.vals_a, bn.keys_b, bn.vals_b, (size_t)P, 32 + bits_for((unsigned)tiles),
+                              bn.sort_scratch, stream, &in_b);
+        if (rc) return rc;
+        const unsigned long long* keys = in_b ? bn.keys_b : bn.keys_a;
+        point_list = in_b ? bn.vals_b : bn.vals_a;
+        hipLaunchKernelGGL(k_tile_ranges, dim3(ceil_div(P, 256)), dim3(256), 0, stream, P, keys, im.ranges);
+    }
+    hipLaunchKernelGGL(k_render, dim3((unsigned)tiles), dim3(kTilePix), 0, stream, H, W, gx, gy, im.ranges, point_list,
+                       g.splats, bg[0], bg[1], bg[2], im.n_contrib, im.final_T, out_color, out_depth, out_alpha);
+    SYN3R_LAUNCH_CHECK("raster_render launch");
+    if (point_list_out) *point_list_out = point_list;
+    return SYN3R_OK;
+}

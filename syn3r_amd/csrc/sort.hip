@@ -1,0 +1,275 @@
+// Device-wide exclusive scan and stable LSD radix sort of (u64 key, u32 value)
+// pairs, hand-written for 64-lane wavefronts.
+//
+// Role in the hot path: the reference rasteriser (diff-gaussian-rasterization-
+// confidence, un-vendored) sorts (tile<<32 | depth-bits) keys with
+// cub::DeviceRadixSort::SortPairs; a stable LSD radix sort gives the identical
+// order (ties keep duplication order = Gaussian index order).
+//
+// Structure per 8-bit pass:
+//   k_hist    per-block digit histogram (LDS atomics)        -> hist[digit][block]
+//   scan      3-kernel exclusive scan over hist (digit-major) -> global bases
+//   k_scatter keys stay in registers; per-wave digit histograms, cross-wave
+//             prefix, then per-round wave-level match (8 ballots) gives each key
+//             its stable rank; scatter to base + rank.
+// HBM-bound: (8+4) B read + (8+4) B written per pair per pass, + one key read in k_hist.
+#include "common.h"
+#include "raster_common.h"
+
+using namespace syn3r;
+
+namespace syn3r {
+
+// ---------------------------------------------------------------- scan (u32, exclusive)
+constexpr int kScanThreads = 1024;
+constexpr int kScanItems = 4;                      // per thread
+constexpr int kScanChunk = kScanThreads * kScanItems;  // 4096 per block
+
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* smem /*[16+1]*/, unsigned& total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        unsigned t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) smem[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+        unsigned s = lane < (int)(blockDim.x >> 6) ? smem[lane] : 0;
+        unsigned si = s;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            unsigned t = __shfl_up(si, o, 64);
+            if (lane >= o) si += t;
+        }
+        if (lane < 16) smem[lane] = si - s;   // exclusive wave offsets
+        if (lane == 15) smem[16] = si;        // block total
+    }
+    __syncthreads();
+    unsigned res = incl - v + smem[wv];
+    total = smem[16];
+    __syncthreads();
+    return res;
+}
+
+// phase 1: per-chunk sums
+__global__ void __launch_bounds__(kScanThreads) k_scan_sums(const unsigned* __restrict__ in, size_t n,
+                                                           unsigned* __restrict__ sums) {
+    __shared__ unsigned smem[17];
+    size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * kScanItems;
+    unsigned s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) s += (base + k < n) ? in[base + k] : 0;
+    unsigned total;
+    block_exclusive_scan(s, smem, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// phase 2: one block scans the chunk sums in place (exclusive); writes the grand total to *total_out
+__global__ void __launch_bounds__(kScanThreads) k_scan_top(unsigned* __restrict__ sums, int nchunks,
+                                                          unsigned* __restrict__ total_out) {
+    __shared__ unsigned smem[17];
+    unsigned carry = 0;
+    for (int start = 0; start < nchunks; start += kScanThreads) {
+        int i = start + threadIdx.x;
+        unsigned v = i < nchunks ? sums[i] : 0;
+        unsigned total;
+        unsigned ex = block_exclusive_scan(v, smem, total);
+        if (i < nchunks) sums[i] = ex + carry;
+        carry += total;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+// phase 3: per-chunk exclusive scan + chunk offset
+__global__ void __launch_bounds__(kScanThreads) k_scan_final(const unsigned* __restrict__ in, size_t n,
+                                                            const unsigned* __restrict__ sums,
+                                                            unsigned* __restrict__ out) {
+    __shared__ unsigned smem[17];
+    size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * kScanItems;
+    unsigned v[kScanItems];
+    unsigned s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    unsigned total;
+    unsigned ex = block_exclusive_scan(s, smem, total) + sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < n) out[base + k] = ex;
+        ex += v[k];
+    }
+}
+
+size_t scan_scratch_bytes(size_t n) {
+    size_t chunks = (n + kScanChunk - 1) / kScanChunk;
+    return ((chunks * 4 + 255) / 256) * 256 + 256;
+}
+
+// out[i] = sum(in[0..i-1]); *total_out = sum of all (device pointer, may be null). in may alias out.
+int exclusive_scan_u32(const unsigned* in, unsigned* out, size_t n, unsigned* total_out, void* scratch,
+                       hipStream_t stream) {
+    if (n == 0) {
+        if (total_out) return check_hip(hipMemsetAsync(total_out, 0, 4, stream), "memset");
+        return SYN3R_OK;
+    }
+    size_t chunks = (n + kScanChunk - 1) / kScanChunk;
+    if (chunks > (1u << 30)) { set_error("scan: too many elements"); return SYN3R_E_INVALID; }
+    unsigned* sums = (unsigned*)scratch;
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)chunks), dim3(kScanThreads), 0, stream, in, n, sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanThreads), 0, stream, sums, (int)chunks, total_out);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)chunks), dim3(kScanThreads), 0, stream, in, n, sums, out);
+    return SYN3R_OK;
+}
+
+// ---------------------------------------------------------------- radix sort
+constexpr int kSortThreads = 256;
+constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kSortRounds = 16;                               // keys per thread
+constexpr int kSortChunk = kSortThreads * kSortRounds;        // 4096 keys per block
+constexpr int kWaveChunk = 64 * kSortRounds;                  // 1024 keys per wave, contiguous
+
+__global__ void __launch_bounds__(kSortThreads) k_hist(const unsigned long long* __restrict__ keys, size_t n,
+                                                      int shift, unsigned* __restrict__ hist, unsigned nblocks) {
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    size_t base = (size_t)blockIdx.x * kSortChunk;
+#pragma unroll 4
+    for (int r = 0; r < kSortRounds; ++r) {
+        size_t i = base + (size_t)r * kSortThreads + threadIdx.x;
+        if (i < n) atomicAdd(&h[(unsigned)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(kSortThreads) k_scatter(const unsigned long long* __restrict__ keys_in,
+                                                         const unsigned* __restrict__ vals_in,
+                                                         unsigned long long* __restrict__ keys_out,
+                                                         unsigned* __restrict__ vals_out, size_t n, int shift,
+                                                         const unsigned* __restrict__ bases, unsigned nblocks) {
+    __shared__ unsigned wh[kSortWaves][256];   // per-wave digit counts, then running offsets
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < kSortWaves * 256; i += kSortThreads) (&wh[0][0])[i] = 0;
+    __syncthreads();
+
+    // wave w owns keys [w*1024, (w+1)*1024) of the block's chunk; round r covers 64 consecutive keys
+    const size_t wbase = (size_t)blockIdx.x * kSortChunk + (size_t)wv * kWaveChunk;
+    unsigned long long key[kSortRounds];
+    unsigned val[kSortRounds];
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        size_t i = wbase + (size_t)r * 64 + lane;
+        bool ok = i < n;
+        key[r] = ok ? keys_in[i] : ~0ull;
+        val[r] = ok ? vals_in[i] : 0u;
+        if (ok) atomicAdd(&wh[wv][(unsigned)(key[r] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    // digit d (= threadIdx.x): turn per-wave counts into per-wave starting offsets in the output
+    {
+        unsigned d = threadIdx.x;
+        unsigned run = bases[(size_t)d * nblocks + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) {
+            unsigned c = wh[w][d];
+            wh[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        size_t i = wbase + (size_t)r * 64 + lane;
+        bool ok = i < n;
+        unsigned d = (unsigned)(key[r] >> shift) & 255u;
+        // lanes of this wave with the same digit (invalid lanes form their own group)
+        unsigned long long peers = __ballot(ok);
+        if (!ok) peers = ~peers;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            unsigned long long m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        unsigned rank = __popcll(peers & lt);
+        unsigned cnt = __popcll(peers);
+        int leader = __ffsll((long long)peers) - 1;
+        unsigned base = 0;
+        if (ok && lane == leader) {
+            base = wh[wv][d];
+            wh[wv][d] = base + cnt;
+        }
+        base = __shfl(base, leader, 64);
+        if (ok) {
+            keys_out[base + rank] = key[r];
+            vals_out[base + rank] = val[r];
+        }
+        __syncthreads();  // orders this round's LDS update before the next round's read (all waves run 16 rounds)
+    }
+}
+
+size_t sort_scratch_bytes(size_t n) {
+    size_t nblocks = (n + kSortChunk - 1) / kSortChunk;
+    if (nblocks == 0) nblocks = 1;
+    size_t hist = ((256 * nblocks * 4 + 255) / 256) * 256;
+    return hist + scan_scratch_bytes(256 * nblocks);
+}
+
+// Sorts bits [0, nbits) of the keys; nbits is rounded up to a multiple of 8.
+// Ping-pongs between (keys_a, vals_a) and (keys_b, vals_b); returns which buffer holds the result.
+int radix_sort_pairs(unsigned long long* keys_a, unsigned* vals_a, unsigned long long* keys_b, unsigned* vals_b,
+                     size_t n, int nbits, void* scratch, hipStream_t stream, int* result_in_b) {
+    *result_in_b = 0;
+    if (n == 0) return SYN3R_OK;
+    size_t nblocks = (n + kSortChunk - 1) / kSortChunk;
+    if (nblocks > (1u << 22)) { set_error("sort: too many pairs (%zu)", n); return SYN3R_E_INVALID; }
+    unsigned* hist = (unsigned*)scratch;
+    size_t hist_bytes = ((256 * nblocks * 4 + 255) / 256) * 256;
+    void* scan_scratch = (char*)scratch + hist_bytes;
+    int passes = (nbits + 7) / 8;
+    unsigned long long* kin = keys_a; unsigned* vin = vals_a;
+    unsigned long long* kout = keys_b; unsigned* vout = vals_b;
+    for (int p = 0; p < passes; ++p) {
+        int shift = 8 * p;
+        hipLaunchKernelGGL(k_hist, dim3((unsigned)nblocks), dim3(kSortThreads), 0, stream, kin, n, shift, hist,
+                           (unsigned)nblocks);
+        int rc = exclusive_scan_u32(hist, hist, 256 * nblocks, nullptr, scan_scratch, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_scatter, dim3((unsigned)nblocks), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n,
+                           shift, hist, (unsigned)nblocks);
+        unsigned long long* tk = kin; kin = kout; kout = tk;
+        unsigned* tv = vin; vin = vout; vout = tv;
+    }
+    *result_in_b = (passes & 1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return check_hip(e, "radix sort launch");
+    return SYN3R_OK;
+}
+
+}  // namespace syn3r
+
+// ---------------------------------------------------------------- C-ABI (exposed for tests and for callers that bin their own keys)
+extern "C" size_t syn3r_sort_pairs_workspace_bytes(long long n) {
+    if (n < 0) return 0;
+    return sort_scratch_bytes((size_t)n) + 256;
+}
+
+extern "C" int syn3r_sort_pairs(unsigned long long* keys, unsigned* vals, unsigned long long* keys_tmp,
+                                unsigned* vals_tmp, long long n, int nbits, void* workspace, size_t workspace_bytes,
+                                int* result_in_tmp, void* stream) {
+    SYN3R_REQUIRE(n >= 0 && nbits >= 1 && nbits <= 64, "sort_pairs: bad n=%lld nbits=%d", n, nbits);
+    SYN3R_REQUIRE(result_in_tmp, "sort_pairs: result_in_tmp required");
+    if (n == 0) { *result_in_tmp = 0; return SYN3R_OK; }
+    SYN3R_REQUIRE(keys && vals && keys_tmp && vals_tmp, "sort_pairs: null buffer");
+    if (!workspace || workspace_bytes < syn3r_sort_pairs_workspace_bytes(n)) {
+        set_error("sort_pairs: workspace %zu < %zu", workspace_bytes, syn3r_sort_pairs_workspace_bytes(n));
+        return SYN3R_E_WORKSPACE;
+    }
+    return radix_sort_pairs(keys, vals, keys_tmp, vals_tmp, (size_t)n, nbits, workspace, (hipStream_t)stream,
+                            result_in_tmp);
+}

@@ -1,0 +1,157 @@
+"""Gaussian rasteriser on the HIP path, behind the Python interface FSGS's trainer binds
+(`diff_gaussian_rasterization`-style `GaussianRasterizationSettings` / `GaussianRasterizer`,
+returning colour, radii, depth and alpha, with a per-Gaussian `confidence`).
+
+The reference reaches it through `gsTrainer.render_view(cam)` (model/diffusionGS.py:154,166)
+and the trainer's loss.backward() (:139,1640).  Kernels: syn3r_raster_* in include/syn3r_hip.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+
+from .. import _lib as L
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor      # world_view_transform (transposed w2c, as FSGS cameras store it)
+    projmatrix: torch.Tensor      # full_proj_transform
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool = False
+    debug: bool = False
+
+
+def _host16(m: torch.Tensor):
+    return L.host_f32(m.detach().to("cpu", torch.float32).reshape(-1).tolist())
+
+
+class _Rasterize(torch.autograd.Function):
+    debug_state = None
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, confidence, settings):
+        s: GaussianRasterizationSettings = settings
+        dev = L.require_gpu(means3D, shs, opacities, scales, rotations)
+        lib = L.load()
+        N = means3D.shape[0]
+        H, W = int(s.image_height), int(s.image_width)
+        if N == 0:
+            raise ValueError("rasteriser needs at least one Gaussian")
+        M = shs.shape[1]
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        m3, sh, op, sc, ro = f32(means3D), f32(shs), f32(opacities).reshape(-1), f32(scales), f32(rotations)
+        cf = f32(confidence).reshape(-1) if confidence is not None else None
+        if m3.shape != (N, 3) or sc.shape != (N, 3) or ro.shape != (N, 4) or op.shape != (N,) or sh.shape != (N, M, 3):
+            raise ValueError("rasteriser: inconsistent Gaussian tensor shapes")
+        view, proj = _host16(s.viewmatrix), _host16(s.projmatrix)
+        campos = L.host_f32(s.campos.detach().cpu().reshape(-1).tolist())
+        bg = L.host_f32(s.bg.detach().cpu().reshape(-1).tolist())
+        stream = L.stream_ptr(dev)
+
+        geom = torch.empty(lib.syn3r_raster_geom_bytes(N), dtype=torch.uint8, device=dev)
+        image = torch.empty(lib.syn3r_raster_image_bytes(H, W), dtype=torch.uint8, device=dev)
+        radii = torch.empty(N, dtype=torch.int32, device=dev)
+        P = C.c_longlong(0)
+        rc = lib.syn3r_raster_preprocess(N, int(s.sh_degree), M, L.ptr(m3), L.ptr(sc), L.ptr(ro), L.ptr(op), L.ptr(sh),
+                                         L.ptr(cf), float(s.scale_modifier), view, proj, campos, float(s.tanfovx),
+                                         float(s.tanfovy), H, W, L.ptr(radii), L.ptr(geom), geom.numel(), C.byref(P),
+                                         stream)
+        L.check(rc, "syn3r_raster_preprocess")
+        P = int(P.value)
+        binning = torch.empty(lib.syn3r_raster_binning_bytes(P), dtype=torch.uint8, device=dev)
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        plist = C.c_void_p(0)
+        rc = lib.syn3r_raster_render(N, H, W, bg, L.ptr(radii), L.ptr(geom), geom.numel(), L.ptr(binning),
+                                     binning.numel(), L.ptr(image), image.numel(), P, L.ptr(color), L.ptr(depth),
+                                     L.ptr(alpha), C.byref(plist), stream)
+        L.check(rc, "syn3r_raster_render")
+        if s.debug:   # expose the binning / image state (tile ranges, sorted list) to the parity tests
+            tiles = ((W + 15) // 16) * ((H + 15) // 16)
+            a256 = lambda x: (x + 255) & ~255
+            off = plist.value - binning.data_ptr() if P > 0 else 0
+            _Rasterize.debug_state = dict(
+                num_rendered=P,
+                point_list=binning[off:off + 4 * P].view(torch.int32).clone(),
+                ranges=image[:tiles * 8].view(torch.int32).reshape(tiles, 2).clone(),
+                n_contrib=image[a256(tiles * 8):a256(tiles * 8) + 4 * H * W].view(torch.int32).reshape(H, W).clone(),
+                depths=geom[256:256 + 4 * N].view(torch.float32).clone(),
+            )
+        ctx.settings = s
+        ctx.host = (view, proj, campos, bg)
+        ctx.P, ctx.M = P, M
+        ctx.plist = plist.value
+        ctx.has_conf = cf is not None
+        ctx.save_for_backward(m3, sc, ro, op, sh, cf if cf is not None else torch.empty(0, device=dev), radii, geom,
+                              binning, image)
+        ctx.mark_non_differentiable(radii)
+        ctx.opacity_shape = opacities.shape
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_depth, g_alpha):
+        m3, sc, ro, op, sh, cf, radii, geom, binning, image = ctx.saved_tensors
+        s = ctx.settings
+        lib = L.load()
+        dev = m3.device
+        N, M = m3.shape[0], ctx.M
+        H, W = int(s.image_height), int(s.image_width)
+        view, proj, campos, bg = ctx.host
+        gc = g_color.detach().to(torch.float32).contiguous() if g_color is not None else torch.zeros(
+            (3, H, W), device=dev)
+        gd = g_depth.detach().to(torch.float32).contiguous() if g_depth is not None else None
+        ga = g_alpha.detach().to(torch.float32).contiguous() if g_alpha is not None else None
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        d_m3, d_sc, d_ro, d_op, d_sh, d_m2 = new(N, 3), new(N, 3), new(N, 4), new(N), new(N, M, 3), new(N, 3)
+        d_cf = new(N) if ctx.has_conf else None
+        ws = L.workspace(dev, lib.syn3r_raster_backward_workspace_bytes(N), "raster_bwd")
+        rc = lib.syn3r_raster_backward(
+            N, int(s.sh_degree), M, ctx.P, L.ptr(m3), L.ptr(sc), L.ptr(ro), L.ptr(op), L.ptr(sh),
+            L.ptr(cf) if ctx.has_conf else None, float(s.scale_modifier), view, proj, campos, float(s.tanfovx),
+            float(s.tanfovy), H, W, bg, L.ptr(radii), L.ptr(geom), geom.numel(), ctx.plist, L.ptr(image), image.numel(),
+            L.ptr(gc), L.ptr(gd), L.ptr(ga), L.ptr(d_m3), L.ptr(d_sc), L.ptr(d_ro), L.ptr(d_op), L.ptr(d_sh),
+            L.ptr(d_m2), L.ptr(d_cf), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+        L.check(rc, "syn3r_raster_backward")
+        return d_m3, d_m2, d_sh, d_op.reshape(ctx.opacity_shape), d_sc, d_ro, d_cf, None
+
+
+class GaussianRasterizer(torch.nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, confidence: Optional[torch.Tensor] = None):
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if colors_precomp is not None or cov3D_precomp is not None:
+            raise NotImplementedError("precomputed colours / covariances are not used by the SYN3R hot path")
+        if scales is None or rotations is None:
+            raise Exception("Please provide scales and rotations")
+        return _Rasterize.apply(means3D, means2D, shs, opacities, scales, rotations, confidence, self.raster_settings)
+
+
+def sort_pairs(keys: torch.Tensor, vals: torch.Tensor, nbits: int = 64):
+    """Stable radix sort of (int64/uint64-bit-pattern key, int32 value) pairs on the GPU."""
+    dev = L.require_gpu(keys, vals)
+    lib = L.load()
+    n = keys.numel()
+    k = keys.contiguous().clone()
+    v = vals.contiguous().clone()
+    kt, vt = torch.empty_like(k), torch.empty_like(v)
+    ws = L.workspace(dev, lib.syn3r_sort_pairs_workspace_bytes(n), "sort")
+    flag = C.c_int(0)
+    rc = lib.syn3r_sort_pairs(L.ptr(k), L.ptr(v), L.ptr(kt), L.ptr(vt), n, nbits, L.ptr(ws), ws.numel(), C.byref(flag),
+                              L.stream_ptr(dev))
+    L.check(rc, "syn3r_sort_pairs")
+    return (kt, vt) if flag.value else (k, v)

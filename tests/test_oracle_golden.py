@@ -90,3 +90,23 @@ def test_scheduler_oracle_matches_reference(name, golden_dir):
     assert bad.mean() < 1e-4
     np.testing.assert_allclose(o["prev_sample"][..., ::s, ::s].astype(np.float32), g["replace_prev"].astype(np.float32),
                                **tol)
+
+
+def test_scheduler_mirror_schedule_matches_golden(golden_dir):
+    """Host-side schedule of the product scheduler (no GPU needed).  sigmas are exact; timesteps go
+    through the host libm's log (0.25*ln sigma), which differs by 1 ulp between CPU models."""
+    from syn3r_amd.schedulers.scheduling_euler_discrete import SVD_XT_SCHEDULER_CONFIG, EulerDiscreteScheduler
+    s = EulerDiscreteScheduler(**SVD_XT_SCHEDULER_CONFIG)
+    s.set_timesteps(100)
+    g = np.load(golden_dir / "sched_sigmas.npz")
+    np.testing.assert_array_equal(s.sigmas.numpy(), g["sigmas"])
+    np.testing.assert_allclose(s.timesteps.numpy(), g["timesteps"], rtol=3e-7, atol=0)
+    assert np.float32(s.init_noise_sigma) == g["init_noise_sigma"]
+    x = __import__("torch").ones(2, 3)
+    np.testing.assert_allclose(s.scale_model_input(x, s.timesteps[4], step_i=4).numpy(),
+                               (x / ((s.sigmas[4] ** 2 + 1) ** 0.5)).numpy())
+    assert s.step_index == 4
+    s.set_timesteps(25)
+    g = np.load(golden_dir / "sched_sigmas25.npz")
+    np.testing.assert_array_equal(s.sigmas.numpy(), g["sigmas"])
+    np.testing.assert_allclose(s.timesteps.numpy(), g["timesteps"], rtol=3e-7, atol=0)

@@ -16,18 +16,6 @@ def make_scheduler():
     return s
 
 
-def test_schedule_matches_golden(golden_dir):
-    s = make_scheduler()
-    g = np.load(golden_dir / "sched_sigmas.npz")
-    np.testing.assert_array_equal(s.sigmas.numpy(), g["sigmas"])
-    np.testing.assert_array_equal(s.timesteps.numpy(), g["timesteps"])
-    assert np.float32(s.init_noise_sigma) == g["init_noise_sigma"]
-    s.set_timesteps(25)
-    g = np.load(golden_dir / "sched_sigmas25.npz")
-    np.testing.assert_array_equal(s.sigmas.numpy(), g["sigmas"])
-    np.testing.assert_array_equal(s.timesteps.numpy(), g["timesteps"])
-
-
 def run_hip(c, dev, sch, compute_grad=None, replace=False):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     v, x, cond, mask, lam = t(c["model_output"]), t(c["sample"]), t(c["temp_cond"]), t(c["mask"]), t(c["lambda_ts"])
