@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py — SYN3R hot loop on MI355X: LLFF 3-view train-loop iterations per second.
+
+One bench STEP is one block of the fern-like schedule:
+  HOT LOOP A  `--raster-iters` Gaussian-raster forward+backward iterations (L1 loss) at
+              N = 200 000 Gaussians, 1920x1080, SH degree 3, and
+  HOT LOOP B  one SVD (denoise-step, pass) unit: CFG UNet forward on [2,F,8,72,128] fp16 latents
+              + the fused modified-Euler step (F = 14, BASELINE.json configs[1]).
+The schedule 10k + 2 x (3 svd_render + 10k) has 30 000 raster iterations per 600 one-pass
+(step, pass) units = 50 : 1, which is the default ratio.  value = raster iterations / s over the
+whole job (all ranks), the SVD units being amortised inside the same wall-clock.
+
+Launch: `python bench.py` (1 GPU) or
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (one scene per rank,
+weak scaling, a single RCCL all-gather of the per-rank metric record at the end).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gaussians", type=int, default=200_000)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--raster-iters", type=int, default=50, help="raster fwd+bwd iterations per step")
+    ap.add_argument("--frames", type=int, default=14, help="SVD frames (14 = BASELINE configs[1], 25 = reference)")
+    ap.add_argument("--svd", choices=["on", "off"], default="on")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234)
+    return ap.parse_args()
+
+
+class RasterLoop:
+    """HOT LOOP A: render, L1 loss against a fixed target, backward (no optimiser state changes so
+    that every iteration does identical work)."""
+
+    def __init__(self, args, dev):
+        from syn3r_amd import synthetic as RO
+        from syn3r_amd.raster import GaussianRasterizationSettings, GaussianRasterizer
+        m, s, q, o, sh = RO.synthetic_gaussians(args.gaussians, seed=args.seed)
+        view, proj, campos, tfx, tfy = RO.look_at_camera(args.height, args.width)
+        f = lambda t: t.to(dev).requires_grad_(True)
+        self.p = dict(m=f(m), s=f(s), q=f(q), o=f(o), sh=f(sh))
+        self.m2 = torch.zeros(args.gaussians, 3, device=dev, requires_grad=True)
+        st = GaussianRasterizationSettings(args.height, args.width, tfx, tfy, torch.zeros(3, device=dev), 1.0,
+                                           view.to(dev), proj.to(dev), 3, campos.to(dev), False, False)
+        self.rast = GaussianRasterizer(st)
+        g = torch.Generator().manual_seed(args.seed)
+        self.target = torch.rand(3, args.height, args.width, generator=g).to(dev)
+        self.N, self.H, self.W = args.gaussians, args.height, args.width
+        self.P = 0
+
+    def iteration(self):
+        from syn3r_amd.raster import _Rasterize
+        p = self.p
+        color, radii, depth, alpha = self.rast(p["m"], self.m2, p["o"], shs=p["sh"], scales=p["s"], rotations=p["q"])
+        loss = (color - self.target).abs().mean()
+        loss.backward()
+        for t in list(p.values()) + [self.m2]:
+            t.grad = None
+        return loss
+
+    def pairs(self):
+        """number of (Gaussian, tile) pairs of this scene/camera (for the roofline byte count)"""
+        import ctypes as C
+        from syn3r_amd import _lib as L
+        lib = L.load()
+        p = self.p
+        dev = p["m"].device
+        geom = torch.empty(lib.syn3r_raster_geom_bytes(self.N), dtype=torch.uint8, device=dev)
+        radii = torch.empty(self.N, dtype=torch.int32, device=dev)
+        s = self.rast.raster_settings
+        P = C.c_longlong(0)
+        h16 = lambda m: L.host_f32(m.detach().cpu().reshape(-1).tolist())
+        rc = lib.syn3r_raster_preprocess(self.N, 3, 16, L.ptr(p["m"].detach()), L.ptr(p["s"].detach()),
+                                         L.ptr(p["q"].detach()), L.ptr(p["o"].detach()), L.ptr(p["sh"].detach()), None,
+                                         1.0, h16(s.viewmatrix), h16(s.projmatrix), h16(s.campos), s.tanfovx, s.tanfovy,
+                                         self.H, self.W, L.ptr(radii), L.ptr(geom), geom.numel(), C.byref(P),
+                                         L.stream_ptr(dev))
+        L.check(rc, "preprocess")
+        return int(P.value)
+
+
+def raster_algorithmic_bytes(N, P, H, W):
+    """SURVEY.md §8d raster roofline, per kernel (bytes one launch must move at minimum)."""
+    hw = H * W
+    return {
+        "k_preprocess": N * 236 + N * (48 + 4 + 8 + 24 + 16 + 12 + 4 + 4),
+        "k_render": P * (4 + 36) + hw * 20 + hw * 8,
+        "k_render_bwd": P * (4 + 36) + hw * (20 + 8) + P * 40,
+        "k_preprocess_bwd": N * 236 * 2 + N * 64,
+        "k_scatter": P * 12 * 2,
+        "k_hist": P * 8,
+        "k_dup_keys": N * 20 + P * 12,
+    }
+
+
+def cpu_baseline_raster(args):
+    """Oracle (CPU restatement, kind='port') on a bounded sample: same 200k-Gaussian scene rendered
+    fwd+bwd at 1/4 resolution per axis; pixel work is scaled by 16 to the full frame."""
+    from oracle import raster_oracle as RO
+    torch.set_num_threads(os.cpu_count() or 1)
+    N = args.gaussians
+    H, W = args.height // 4, args.width // 4
+    m, s, q, o, sh = RO.synthetic_gaussians(N, seed=args.seed)
+    # keep the footprint in pixels comparable: scales shrink with the image
+    view, proj, campos, tfx, tfy = RO.look_at_camera(H, W)
+    ps = [t.clone().requires_grad_(True) for t in (m, s, q, o, sh)]
+    t0 = time.time()
+    color, radii, depth, alpha, aux = RO.rasterize(ps[0], ps[1], ps[2], ps[3], ps[4], None, view, proj, campos, tfx, tfy,
+                                                   H, W, torch.zeros(3), 3)
+    color.abs().mean().backward()
+    dt = time.time() - t0
+    full = dt * 16.0
+    return dict(value=1.0 / full, unit="iters/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/raster_oracle.py fwd+bwd, {N} Gaussians at {W}x{H} (1/16 of the pixels) took "
+                       f"{dt:.1f} s; scaled x16 to 1920x1080; raster iterations only (no CPU UNet: see DESIGN.md)")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the SYN3R hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from syn3r_amd import _lib as L
+    L.load()
+
+    # one independent scene per rank (scene-parallel): different seed per rank
+    args.seed = args.seed + rank
+    loop_a = RasterLoop(args, dev)
+    loop_b = None
+    if args.svd == "on":
+        try:
+            from syn3r_amd.pipeline.svd_step import SvdStepBench
+            loop_b = SvdStepBench(args.frames, dev, seed=args.seed)
+        except ImportError:
+            loop_b = None
+
+    def step():
+        for _ in range(args.raster_iters):
+            loop_a.iteration()
+        if loop_b is not None:
+            loop_b.step_pass()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    with L.kernel_trace() as tr:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max = float(tmax.item())
+
+    # one collective at the end: fixed-size per-rank record (scene id, iters/s, svd units/s, wall)
+    rec = torch.tensor([rank, args.raster_iters * args.steps / dt, (args.steps / dt) if loop_b else 0.0, dt],
+                       device=dev, dtype=torch.float32)
+    if dist is not None:
+        allrec = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(allrec, rec)
+    else:
+        allrec = [rec]
+
+    if rank == 0:
+        iters = args.raster_iters * args.steps * world
+        value = iters / dt_max
+        P = loop_a.pairs()
+        alg = raster_algorithmic_bytes(args.gaussians, P, args.height, args.width)
+        kern = {k: v for k, v in tr.result.items()}
+        roof = None
+        if loop_b is not None:
+            roof = loop_b.roofline(kern)
+        if roof is None and kern:
+            name = max(kern, key=lambda k: kern[k][1])
+            calls, ms = kern[name]
+            avg_s = ms / calls / 1e3
+            if name in alg:
+                ach = alg[name] / avg_s / 1e9
+                roof = dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, avg_ms=round(ms / calls, 4), calls=calls,
+                            algorithmic_bytes=alg[name])
+            else:
+                roof = dict(bound="hbm", kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None,
+                            traffic=None, avg_ms=round(ms / calls, 4), calls=calls)
+        out = {
+            "metric": "llff_3view_train_loop_iters_per_sec",
+            "value": round(value, 3),
+            "unit": "iters/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt_max / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 raster / f16 UNet (f32 accumulate)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"LLFF fern-like 3-view block: {args.raster_iters} raster fwd+bwd iters "
+                            f"({args.gaussians} Gaussians, {args.width}x{args.height}, SH3, P={P} pairs) + "
+                            + (f"1 SVD (step,pass): CFG UNet fwd [2,{args.frames},8,72,128] f16 + fused Euler step"
+                               if loop_b is not None else "SVD pass NOT included (UNet not built yet)"),
+                "raster_iters_per_step": args.raster_iters,
+                "svd_units_per_step": 1 if loop_b is not None else 0,
+                "frames": args.frames,
+                "parallelism": f"scene-parallel x{world}",
+            },
+            "roofline": roof,
+            "kernels_ms": {k: [v[0], round(v[1], 3)] for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])[:12]},
+            "per_rank": [[round(float(x), 3) for x in r.tolist()] for r in allrec],
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_raster(args)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

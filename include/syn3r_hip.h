@@ -46,6 +46,15 @@ int syn3r_version(void);
 /* name of the GPU architecture the code objects were built for ("gfx950") */
 const char* syn3r_arch(void);
 
+/*
+ * Per-kernel timing for bench.py's roofline line: while enabled, every kernel
+ * launch is bracketed by HIP events recorded on the launch stream.
+ * syn3r_trace_report synchronises them, writes one "kernel calls total_ms"
+ * line per kernel into buf and clears the trace.
+ */
+int syn3r_trace_enable(int on);
+int syn3r_trace_report(char* buf, size_t cap);
+
 /* ------------------------------------------------------------------------
  * Geometry (solver_utils/)
  * ------------------------------------------------------------------------ */

@@ -26,6 +26,8 @@ SIGNATURES = {
     "syn3r_last_error": (C.c_char_p, []),
     "syn3r_version": (c_i, []),
     "syn3r_arch": (C.c_char_p, []),
+    "syn3r_trace_enable": (c_i, [c_i]),
+    "syn3r_trace_report": (c_i, [C.c_char_p, c_sz]),
     "syn3r_inverse_warp_workspace_bytes": (c_sz, [c_i]),
     "syn3r_inverse_warp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i,
                                  c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
@@ -143,3 +145,23 @@ def workspace(dev: torch.device, nbytes: int, tag: str = "") -> torch.Tensor:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
         _ws_cache[key] = buf
     return buf
+
+
+class kernel_trace:
+    """Context manager: per-kernel HIP-event timing of everything launched inside.
+    `.result` maps kernel name -> (calls, total_ms)."""
+
+    def __enter__(self):
+        load().syn3r_trace_enable(1)
+        self.result = {}
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        lib.syn3r_trace_enable(0)
+        buf = C.create_string_buffer(1 << 16)
+        lib.syn3r_trace_report(buf, len(buf))
+        for line in buf.value.decode().splitlines():
+            name, calls, ms = line.rsplit(" ", 2)
+            self.result[name] = (int(calls), float(ms))
+        return False

@@ -15,3 +15,69 @@ void set_error(const char* fmt, ...) {
 extern "C" const char* syn3r_last_error(void) { return syn3r::g_err; }
 extern "C" int syn3r_version(void) { return 100; }
 extern "C" const char* syn3r_arch(void) { return "gfx950"; }
+
+// ---------------------------------------------------------------- kernel tracer
+#include <map>
+#include <string>
+#include <vector>
+#include <mutex>
+
+namespace syn3r {
+namespace {
+struct Span { std::string name; hipEvent_t a, b; };
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Span> g_spans;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+bool trace_on() { return g_on; }
+void trace_begin(const char* name, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Span s{name, get_event(), get_event()};
+    hipEventRecord(s.a, stream);
+    g_spans.push_back(s);
+}
+void trace_end(hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_spans.empty()) hipEventRecord(g_spans.back().b, stream);
+}
+}  // namespace syn3r
+
+extern "C" int syn3r_trace_enable(int on) {
+    std::lock_guard<std::mutex> lk(syn3r::g_mu);
+    syn3r::g_on = on != 0;
+    return SYN3R_OK;
+}
+
+// Synchronises the recorded events, aggregates per kernel name and writes
+// "name calls total_ms\n" lines into buf (truncated to cap); clears the trace.
+extern "C" int syn3r_trace_report(char* buf, size_t cap) {
+    std::lock_guard<std::mutex> lk(syn3r::g_mu);
+    std::map<std::string, std::pair<long long, double>> agg;
+    for (auto& s : syn3r::g_spans) {
+        float ms = 0.f;
+        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            auto& e = agg[s.name];
+            e.first += 1;
+            e.second += ms;
+        }
+        syn3r::g_pool.push_back(s.a);
+        syn3r::g_pool.push_back(s.b);
+    }
+    syn3r::g_spans.clear();
+    size_t off = 0;
+    if (buf && cap) buf[0] = 0;
+    for (auto& kv : agg) {
+        char line[256];
+        int n = snprintf(line, sizeof(line), "%s %lld %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        if (buf && off + n + 1 < cap) { memcpy(buf + off, line, n + 1); off += n; }
+    }
+    return SYN3R_OK;
+}

@@ -22,6 +22,11 @@ inline int check_hip(hipError_t e, const char* what) {
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Optional per-kernel timing with HIP events on the launch stream (syn3r_trace_* in the ABI).
+bool trace_on();
+void trace_begin(const char* name, hipStream_t stream);
+void trace_end(hipStream_t stream);
+
 // 4x4 / 3x3 matrices travel to kernels by value.
 struct Mat4f { float m[16]; };
 struct Mat3f { float m[9]; };
@@ -36,6 +41,14 @@ struct Mat3d { double m[9]; };
             syn3r::set_error(__VA_ARGS__);       \
             return SYN3R_E_INVALID;              \
         }                                        \
+    } while (0)
+
+// Kernel launch that the tracer can bracket with events on the same stream.
+#define SYN3R_LAUNCH(kernel, grid, block, shmem, stream, ...)                        \
+    do {                                                                             \
+        if (syn3r::trace_on()) syn3r::trace_begin(#kernel, stream);                  \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);         \
+        if (syn3r::trace_on()) syn3r::trace_end(stream);                             \
     } while (0)
 
 #define SYN3R_LAUNCH_CHECK(name)                                        \

@@ -393,10 +393,10 @@ extern "C" int syn3r_raster_backward(int N, int sh_degree, int sh_coeffs, long l
     if (rc) return rc;
     const unsigned tiles = (unsigned)(cam.grid_x * cam.grid_y);
     if (P > 0)
-        hipLaunchKernelGGL(k_render_bwd, dim3(tiles), dim3(kTilePix), 0, stream, H, W, cam.grid_x, cam.grid_y, im.ranges,
+        SYN3R_LAUNCH(k_render_bwd, dim3(tiles), dim3(kTilePix), 0, stream, H, W, cam.grid_x, cam.grid_y, im.ranges,
                            point_list, g.splats, bg[0], bg[1], bg[2], im.n_contrib, im.final_T, dL_dcolor, dL_ddepth,
                            dL_dalpha, grad_rec);
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
+    SYN3R_LAUNCH(k_preprocess_bwd, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
                        scales, rotations, opacities, shs, confidence, scale_modifier, cam, radii, g, grad_rec,
                        dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacities, dL_dshs, dL_dmeans2D, dL_dconfidence);
     SYN3R_LAUNCH_CHECK("raster_backward launch");

@@ -399,7 +399,7 @@ extern "C" int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, cons
     GeomState g = carve_geom(geom, N);
     Camera cam;
     fill_camera(cam, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W);
-    hipLaunchKernelGGL(k_preprocess, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
+    SYN3R_LAUNCH(k_preprocess, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
                        scales, rotations, opacities, shs, confidence, scale_modifier, cam, radii, g);
     int rc = exclusive_scan_u32(g.tiles_touched, g.point_offsets, (size_t)N, g.header, g.scan_scratch, stream);
     if (rc) return rc;
@@ -438,7 +438,7 @@ extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const i
     if (rc) return rc;
     unsigned* point_list = bn.vals_a;
     if (P > 0) {
-        hipLaunchKernelGGL(k_dup_keys, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, g.means2D, g.depths,
+        SYN3R_LAUNCH(k_dup_keys, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, g.means2D, g.depths,
                            g.point_offsets, radii, gx, gy, bn.keys_a, bn.vals_a);
         int in_b = 0;
         rc = radix_sort_pairs(bn.keys_a, bn.vals_a, bn.keys_b, bn.vals_b, (size_t)P, 32 + bits_for((unsigned)tiles),
@@ -446,9 +446,9 @@ extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const i
         if (rc) return rc;
         const unsigned long long* keys = in_b ? bn.keys_b : bn.keys_a;
         point_list = in_b ? bn.vals_b : bn.vals_a;
-        hipLaunchKernelGGL(k_tile_ranges, dim3(ceil_div(P, 256)), dim3(256), 0, stream, P, keys, im.ranges);
+        SYN3R_LAUNCH(k_tile_ranges, dim3(ceil_div(P, 256)), dim3(256), 0, stream, P, keys, im.ranges);
     }
-    hipLaunchKernelGGL(k_render, dim3((unsigned)tiles), dim3(kTilePix), 0, stream, H, W, gx, gy, im.ranges, point_list,
+    SYN3R_LAUNCH(k_render, dim3((unsigned)tiles), dim3(kTilePix), 0, stream, H, W, gx, gy, im.ranges, point_list,
                        g.splats, bg[0], bg[1], bg[2], im.n_contrib, im.final_T, out_color, out_depth, out_alpha);
     SYN3R_LAUNCH_CHECK("raster_render launch");
     if (point_list_out) *point_list_out = point_list;

@@ -284,21 +284,21 @@ int run_step(bool replace, const void* v, const void* x, const float* cond, cons
     if (need_select && p.F > 2) {
         LambdaRow lam;
         for (int f = 0; f < p.F; ++f) lam.v[f] = lambda_row[f];
-        hipLaunchKernelGGL((k_select<VDT, SDT>), dim3(p.F - 2), dim3(kSel), 0, stream, p, v, x, cond, mask, lam,
+        SYN3R_LAUNCH((k_select<VDT, SDT>), dim3(p.F - 2), dim3(kSel), 0, stream, p, v, x, cond, mask, lam,
                            ws.dbits, ws.cutoff);
     }
     if (replace) {
-        hipLaunchKernelGGL((k_replace_tail<VDT, SDT>), dim3(ew_grid(total)), dim3(kEw), 0, stream, p, v, x, cond, mask,
+        SYN3R_LAUNCH((k_replace_tail<VDT, SDT>), dim3(ew_grid(total)), dim3(kEw), 0, stream, p, v, x, cond, mask,
                            ws.cutoff, prev, x0);
     } else {
         if (compute_grad) {
             int rc = check_hip(hipMemsetAsync(ws.sums, 0, 16, stream), "memset");
             if (rc) return rc;
         }
-        hipLaunchKernelGGL((k_interp_tail<VDT, SDT>), dim3(ew_grid(total)), dim3(kEw), 0, stream, p, v, x, cond, mask,
+        SYN3R_LAUNCH((k_interp_tail<VDT, SDT>), dim3(ew_grid(total)), dim3(kEw), 0, stream, p, v, x, cond, mask,
                            ws.cutoff, compute_grad, prev, x0, grad, ws.sums);
         if (compute_grad)
-            hipLaunchKernelGGL(k_grad_scale, dim3(ew_grid(total)), dim3(kEw), 0, stream, p, grad, ws.sums);
+            SYN3R_LAUNCH(k_grad_scale, dim3(ew_grid(total)), dim3(kEw), 0, stream, p, grad, ws.sums);
     }
     SYN3R_LAUNCH_CHECK("scheduler step launch");
     return SYN3R_OK;

@@ -119,9 +119,9 @@ int exclusive_scan_u32(const unsigned* in, unsigned* out, size_t n, unsigned* to
     size_t chunks = (n + kScanChunk - 1) / kScanChunk;
     if (chunks > (1u << 30)) { set_error("scan: too many elements"); return SYN3R_E_INVALID; }
     unsigned* sums = (unsigned*)scratch;
-    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)chunks), dim3(kScanThreads), 0, stream, in, n, sums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanThreads), 0, stream, sums, (int)chunks, total_out);
-    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)chunks), dim3(kScanThreads), 0, stream, in, n, sums, out);
+    SYN3R_LAUNCH(k_scan_sums, dim3((unsigned)chunks), dim3(kScanThreads), 0, stream, in, n, sums);
+    SYN3R_LAUNCH(k_scan_top, dim3(1), dim3(kScanThreads), 0, stream, sums, (int)chunks, total_out);
+    SYN3R_LAUNCH(k_scan_final, dim3((unsigned)chunks), dim3(kScanThreads), 0, stream, in, n, sums, out);
     return SYN3R_OK;
 }
 
@@ -236,11 +236,11 @@ int radix_sort_pairs(unsigned long long* keys_a, unsigned* vals_a, unsigned long
     unsigned long long* kout = keys_b; unsigned* vout = vals_b;
     for (int p = 0; p < passes; ++p) {
         int shift = 8 * p;
-        hipLaunchKernelGGL(k_hist, dim3((unsigned)nblocks), dim3(kSortThreads), 0, stream, kin, n, shift, hist,
+        SYN3R_LAUNCH(k_hist, dim3((unsigned)nblocks), dim3(kSortThreads), 0, stream, kin, n, shift, hist,
                            (unsigned)nblocks);
         int rc = exclusive_scan_u32(hist, hist, 256 * nblocks, nullptr, scan_scratch, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_scatter, dim3((unsigned)nblocks), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n,
+        SYN3R_LAUNCH(k_scatter, dim3((unsigned)nblocks), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n,
                            shift, hist, (unsigned)nblocks);
         unsigned long long* tk = kin; kin = kout; kout = tk;
         unsigned* tv = vin; vin = vout; vout = tv;

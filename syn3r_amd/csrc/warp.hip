@@ -412,8 +412,8 @@ extern "C" int syn3r_inverse_warp(const float* img, const float* depth, const fl
         p.bandwidth = bandwidth; p.H = H; p.W = W;
         const float* dp = depth_pseudo + b * n;
         int g = grid_for((int)n);
-        hipLaunchKernelGGL(k_iw_minmax, dim3(g), dim3(kBlock), 0, stream, p, depth, dp, mm + 4 * b);
-        hipLaunchKernelGGL(k_iw_main, dim3(g), dim3(kBlock), 0, stream, p, img, depth, dp, mm + 4 * b,
+        SYN3R_LAUNCH(k_iw_minmax, dim3(g), dim3(kBlock), 0, stream, p, depth, dp, mm + 4 * b);
+        SYN3R_LAUNCH(k_iw_main, dim3(g), dim3(kBlock), 0, stream, p, img, depth, dp, mm + 4 * b,
                            warped_img + 3 * b * n, warped_depth + b * n, mask_warp + b * n, mask_depth + b * n,
                            mask + b * n, warped_masked_img + 3 * b * n, mask_inv + b * n,
                            mask_depth_strict + b * n, mask_reproj + b * n, soft_mask_reproj + b * n,
@@ -432,7 +432,7 @@ extern "C" int syn3r_reproj_error(const float* depth1, const float* depth2, cons
     load4(p.T12, T12); load4(p.T21, T21);
     load3(p.K1, K1); load3(p.K1inv, K1inv); load3(p.K2, K2);
     p.H = H; p.W = W;
-    hipLaunchKernelGGL(k_reproj, dim3(grid_for(H * W)), dim3(kBlock), 0, (hipStream_t)stream_, p, depth1, depth2,
+    SYN3R_LAUNCH(k_reproj, dim3(grid_for(H * W)), dim3(kBlock), 0, (hipStream_t)stream_, p, depth1, depth2,
                        err);
     SYN3R_LAUNCH_CHECK("reproj_error launch");
     return SYN3R_OK;
@@ -465,9 +465,9 @@ extern "C" int syn3r_forward_warp(const double* frame1, const uint8_t* mask1, co
     int rc = check_hip(hipMemsetAsync(workspace, 0, need, stream), "memset");
     if (rc) return rc;
     int g = grid_for(H * W);
-    hipLaunchKernelGGL(k_fw_maxdepth, dim3(g), dim3(kBlock), 0, stream, p, depth1, maxbits);
-    hipLaunchKernelGGL(k_fw_splat, dim3(g), dim3(kBlock), 0, stream, p, frame1, mask1, depth1, maxbits, acc, flow12);
-    hipLaunchKernelGGL(k_fw_finish, dim3(g), dim3(kBlock), 0, stream, H, W, acc, warped, mask2);
+    SYN3R_LAUNCH(k_fw_maxdepth, dim3(g), dim3(kBlock), 0, stream, p, depth1, maxbits);
+    SYN3R_LAUNCH(k_fw_splat, dim3(g), dim3(kBlock), 0, stream, p, frame1, mask1, depth1, maxbits, acc, flow12);
+    SYN3R_LAUNCH(k_fw_finish, dim3(g), dim3(kBlock), 0, stream, H, W, acc, warped, mask2);
     SYN3R_LAUNCH_CHECK("forward_warp launch");
     return SYN3R_OK;
 }

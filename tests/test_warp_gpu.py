@@ -73,7 +73,9 @@ def test_inverse_warp_batch_matches_single(gpu):
                               bandwidth=10)
         for k, v in single.items():
             if v is not None:
-                assert torch.equal(out[k][b], v), (b, k)
+                a = out[k][b]
+                same = (a == v) | ((a != a) & (v != v))  # zero-depth holes give NaN errors in both
+                assert bool(same.all()), (b, k)
 
 
 def test_inverse_warp_identity_and_out_of_bounds(gpu):
