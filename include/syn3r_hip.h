@@ -230,6 +230,87 @@ int syn3r_sort_pairs(unsigned long long* keys, unsigned* vals, unsigned long lon
                      long long n, int nbits, void* workspace, size_t workspace_bytes, int* result_in_tmp,
                      void* stream);
 
+/* ------------------------------------------------------------------------
+ * SVD spatio-temporal UNet operators (fp16 storage, fp32 accumulation)
+ *
+ * Activations are channels-last token matrices: a tensor the reference holds as
+ * [B*F, C, h, w] (or [B, C, F, h, w]) is the row-major fp16 matrix
+ * [B*F*h*w, C] with row = ((b*F + f)*h + y)*w + x.  With that layout every
+ * permute/reshape of the reference's forward
+ * (diffusers/models/unets/unet_spatio_temporal_condition.py:356-489,
+ * resnet.py:691-721, transformers/transformer_temporal.py:277-379,
+ * attention.py:478-533) is an index calculation inside a kernel.
+ * ------------------------------------------------------------------------ */
+
+/*
+ * out[M,N] = s_acc*(A[M,K] . W[N,K]^T + bias[n] + rowvec[m / rows_per_vec, n])
+ *            + s_res*residual[m,n] + s_aux*aux[m,n]
+ * nn.Linear / 1x1 convolutions (attention_processor.py:187-202, resnet.py:316,
+ * transformer_temporal.py:236,273) with the adds that follow them fused.
+ * W is the nn.Linear weight as stored ([out_features, in_features]).
+ * K % 64 == 0; strides in elements, multiples of 8; pointers 16-byte aligned;
+ * bias / rowvec / residual / aux may be NULL.
+ */
+int syn3r_gemm_f16(const void* A, long long lda, const void* W, void* out, long long ldc, const void* bias,
+                   const void* rowvec, long long ldrv, int rows_per_vec, const void* residual, long long ldr,
+                   const void* aux, long long ldaux, float s_acc, float s_res, float s_aux, int M, int N, int K,
+                   void* stream);
+
+/*
+ * 3x3 Conv2d, padding 1, on NHWC fp16 (resnet.py:274,290; downsampling.py:116-148 with stride 2;
+ * upsampling.py:172-183 with upsample != 0: nearest-2x of the input fused into the gather).
+ * X [NB,Hi,Wi,Cin], W [Cout, 3, 3, Cin] (= the Conv2d weight permuted to OHWI), Cin % 64 == 0.
+ * out [NB*Ho*Wo, Cout] with the gemm epilogue (aux excluded).
+ */
+int syn3r_conv2d3x3_f16(const void* X, const void* W, void* out, long long ldc, const void* bias,
+                        const void* rowvec, long long ldrv, int rows_per_vec, const void* residual, long long ldr,
+                        float s_acc, float s_res, int NB, int Hi, int Wi, int Cin, int Cout, int stride, int upsample,
+                        void* stream);
+
+/*
+ * (3,1,1) Conv3d over frames, padding (1,0,0) (resnet.py:571-597) on [B,F,HW,Cin] fp16.
+ * W [Cout, 3, Cin] (= the Conv3d weight [Cout,Cin,3,1,1] permuted), Cin % 64 == 0.
+ */
+int syn3r_tconv3_f16(const void* X, const void* W, void* out, long long ldc, const void* bias, const void* rowvec,
+                     long long ldrv, int rows_per_vec, const void* residual, long long ldr, float s_acc, float s_res,
+                     int B, int F, int HW, int Cin, int Cout, void* stream);
+
+/*
+ * Self-attention over the S tokens of each of nseq sequences, head dim 64, scale 1/8
+ * (F.scaled_dot_product_attention at attention_processor.py:1279).  q/k/v point at column 0 of
+ * head 0 inside row-major matrices with row stride ld (e.g. the three thirds of a fused QKV
+ * projection); out [nseq*S, ldo], head hd at columns [64 hd, 64 hd + 64).
+ */
+int syn3r_attention_f16(const void* q, const void* k, const void* v, long long ld, void* out, long long ldo,
+                        int nseq, int S, int heads, void* stream);
+
+/*
+ * Temporal self-attention (attention.py:491-508): for every (b, pixel) the F <= 32 tokens at rows
+ * (b*F + f)*HW + pixel attend to each other.  Same operand convention as syn3r_attention_f16.
+ */
+int syn3r_attention_temporal_f16(const void* q, const void* k, const void* v, long long ld, void* out,
+                                 long long ldo, int B, int F, int HW, int heads, void* stream);
+
+/*
+ * GroupNorm(32 groups) [+ SiLU] on [samples, rows, C] fp16 (statistics per sample and group over
+ * rows x C/32).  2D norms: samples = B*F, rows = h*w; the 3D norms of TemporalResnetBlock
+ * (resnet.py:574,588): samples = B, rows = F*h*w.
+ */
+size_t syn3r_groupnorm_workspace_bytes(int samples);
+int syn3r_groupnorm_f16(const void* x, void* y, int samples, int rows, int C, const void* gamma, const void* beta,
+                        float eps, int silu, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * LayerNorm over C of [M, C] fp16.  If addvec != NULL, addvec[m / rows_per_vec, :] is added first
+ * (fp16 add: `hidden_states + emb`, transformer_temporal.py:355) and, if xsum != NULL, the sum is
+ * also written there (it is the temporal block's residual, attention.py:490).
+ */
+int syn3r_layernorm_f16(const void* x, void* y, void* xsum, const void* addvec, int rows_per_vec, long long M,
+                        int C, const void* gamma, const void* beta, float eps, void* stream);
+
+/* GEGLU gate (activations.py GEGLU.forward): y[M,D] = x[:, :D] * gelu_erf(x[:, D:]) for x [M, 2D]. */
+int syn3r_geglu_f16(const void* x, void* y, long long M, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

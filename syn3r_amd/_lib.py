@@ -52,6 +52,18 @@ SIGNATURES = {
                                     c_p, c_p, c_p, c_p, c_sz, c_p]),
     "syn3r_sort_pairs_workspace_bytes": (c_sz, [c_ll]),
     "syn3r_sort_pairs": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_i, c_p, c_sz, C.POINTER(c_i), c_p]),
+    "syn3r_gemm_f16": (c_i, [c_p, c_ll, c_p, c_p, c_ll, c_p, c_p, c_ll, c_i, c_p, c_ll, c_p, c_ll, c_f, c_f, c_f,
+                             c_i, c_i, c_i, c_p]),
+    "syn3r_conv2d3x3_f16": (c_i, [c_p, c_p, c_p, c_ll, c_p, c_p, c_ll, c_i, c_p, c_ll, c_f, c_f,
+                                  c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "syn3r_tconv3_f16": (c_i, [c_p, c_p, c_p, c_ll, c_p, c_p, c_ll, c_i, c_p, c_ll, c_f, c_f,
+                               c_i, c_i, c_i, c_i, c_i, c_p]),
+    "syn3r_attention_f16": (c_i, [c_p, c_p, c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, c_p]),
+    "syn3r_attention_temporal_f16": (c_i, [c_p, c_p, c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, c_i, c_p]),
+    "syn3r_groupnorm_workspace_bytes": (c_sz, [c_i]),
+    "syn3r_groupnorm_f16": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_p, c_sz, c_p]),
+    "syn3r_layernorm_f16": (c_i, [c_p, c_p, c_p, c_p, c_i, c_ll, c_i, c_p, c_p, c_f, c_p]),
+    "syn3r_geglu_f16": (c_i, [c_p, c_p, c_ll, c_i, c_p]),
 }
 
 

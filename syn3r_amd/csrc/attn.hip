@@ -1,0 +1,340 @@
+// Fused attention (QK^T / softmax / .V) for the SVD spatio-temporal UNet, head dim 64, fp16 in,
+// fp32 softmax and accumulation.
+//
+// Replaces F.scaled_dot_product_attention as called from AttnProcessor2_0
+// (thirdparty/diffusers/src/diffusers/models/attention_processor.py:1222-1299; scale 1/8, no mask):
+//   k_attn_spatial   self-attention over the S = h*w tokens of one frame (attention.py:329),
+//                    S up to 9216, flash-style online softmax, never materialises S x S.
+//   k_attn_temporal  self-attention over the F <= 32 frames of one pixel (attention.py:491-508),
+//                    one wavefront per (batch, pixel, head); tokens are addressed with the frame
+//                    stride, so the reference's permutes (attention.py:487-489,527-529) never happen.
+//
+// CDNA4 mapping (both): scores are computed transposed, S^T = K.Q^T with v_mfma_f32_32x32x16_f16,
+// so a lane owns ONE query column and its keys sit in the accumulator registers: the row max /
+// sum is a register reduction plus one lane^32 exchange (no 32-lane shuffles).  The probability
+// tile is then used directly from the accumulator as the B operand of O^T += V^T.P (the k order
+// of an accumulator-sourced fragment is permuted; V^T is written to LDS in that same order, XOR-
+// swizzled so the 16-byte fragment reads are conflict-free).
+#include "common.h"
+
+using namespace syn3r;
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr float kNegBig = -1.0e30f;
+
+// position of key kk (0..31) inside a 32-key group so that an accumulator-sourced B fragment
+// (k-step s, lane half h, element j  <->  key 16 s + 8 (j>>2) + 4 h + (j&3)) reads 8 contiguous halfs
+__device__ __forceinline__ int key_pos(int kk) {
+    int s = kk >> 4, rem = kk & 15;
+    int h = (rem >> 2) & 1;
+    int j = ((rem >> 3) << 2) | (rem & 3);
+    return s * 16 + h * 8 + j;
+}
+
+__device__ __forceinline__ half8 pack8(const float16v& p, int s) {
+    half8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (_Float16)p[8 * s + j];
+    return r;
+}
+
+struct AttnParams {
+    const __half* q; const __half* k; const __half* v;   // column offsets already applied; head hd at +64*hd
+    long long ld;                                         // row stride (halfs) of q/k/v
+    __half* o; long long ldo;
+    int S;        // tokens per sequence
+    int nseq;     // sequences (spatial: B*F ; temporal: B*HW handled through strides)
+    int heads;
+    // temporal addressing: token (b, f, pix) lives at row (b*F + f)*HW + pix
+    int F, HW;
+};
+
+constexpr int BQ = 128, BKV = 64, ATHREADS = 256;
+
+__global__ void __launch_bounds__(ATHREADS) k_attn_spatial(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) __half Ks[2][BKV * 64];
+    __shared__ __attribute__((aligned(16))) __half Vt[2][64 * BKV];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lq = lane & 31, h = lane >> 5;
+    const int qblocks = (p.S + BQ - 1) / BQ;
+    int bid = blockIdx.x;
+    const int qb = bid % qblocks; bid /= qblocks;
+    const int hd = bid % p.heads;
+    const int seq = bid / p.heads;
+    const long long row0 = (long long)seq * p.S;
+    const int q0 = qb * BQ + wv * 32;
+    const __half* qp = p.q + hd * 64;
+    const __half* kp = p.k + hd * 64;
+    const __half* vp = p.v + hd * 64;
+
+    // Q fragments (B operand), prescaled by 1/8 (exact in fp16)
+    half8 qf[4];
+    {
+        int qi = q0 + lq;
+        if (qi > p.S - 1) qi = p.S - 1;
+        const __half* src = qp + (row0 + qi) * p.ld;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 t = *(const half8*)(src + ks * 16 + 8 * h);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = t[j] * (_Float16)0.125f;
+            qf[ks] = t;
+        }
+    }
+
+    // staging assignment: 64 keys x 8 chunks = 512 chunks, 2 per thread
+    const int s_chunk = tid & 7;
+    const int s_key0 = tid >> 3;   // keys s_key0 and s_key0 + 32
+    uint4 rk[2], rv[2];
+    auto load_kv = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int key = kv0 + s_key0 + 32 * i;
+            if (key < p.S) {
+                rk[i] = *(const uint4*)(kp + (row0 + key) * p.ld + s_chunk * 8);
+                rv[i] = *(const uint4*)(vp + (row0 + key) * p.ld + s_chunk * 8);
+            } else {
+                rk[i] = make_uint4(0, 0, 0, 0);
+                rv[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_kv = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int key = s_key0 + 32 * i;
+            *(uint4*)(&Ks[buf][key * 64 + ((s_chunk ^ (key & 7)) << 3)]) = rk[i];
+            int pos = (key & 32) + key_pos(key & 31);
+            const __half* ve = (const __half*)&rv[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int d = s_chunk * 8 + e;
+                Vt[buf][d * BKV + ((((pos >> 3) ^ (d & 7)) << 3) | (pos & 7))] = ve[e];
+            }
+        }
+    };
+
+    float16v ot[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; }
+    float m_run = kNegBig, l_run = 0.f;
+
+    const int ntiles = (p.S + BKV - 1) / BKV;
+    load_kv(0);
+    store_kv(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) load_kv((t + 1) * BKV);
+        // S^T = K . Q^T : two 32-key groups
+        float16v st[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[g][r] = 0.f;
+            int key = g * 32 + lq;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                half8 kf = *(const half8*)(&Ks[cur][key * 64 + (((ks * 2 + h) ^ (key & 7)) << 3)]);
+                st[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st[g], 0, 0, 0);
+            }
+        }
+        const int kv0 = t * BKV;
+        if (kv0 + BKV > p.S) {   // wave-uniform: mask keys beyond the sequence
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int key = kv0 + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= p.S) st[g][r] = kNegBig;
+                }
+        }
+        float mx = st[0][0];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[g][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float ls = 0.f;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float e = __expf(st[g][r] - m_new);
+                st[g][r] = e;
+                ls += e;
+            }
+        l_run = l_run * alpha + ls;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
+        // O^T += V^T . P
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                half8 pf = pack8(st[g], s);
+                int chunk = (g * 32 + s * 16 + h * 8) >> 3;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    int d = dt * 32 + lq;
+                    half8 vf = *(const half8*)(&Vt[cur][d * BKV + ((chunk ^ (d & 7)) << 3)]);
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[dt], 0, 0, 0);
+                }
+            }
+        if (t + 1 < ntiles) store_kv(cur ^ 1);
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + lq;
+    if (qi < p.S) {
+        __half* dst = p.o + (row0 + qi) * p.ldo + hd * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = (_Float16)(ot[dt][4 * g + e] * inv);
+                *(half4*)(dst + dt * 32 + 8 * g + 4 * h) = o4;
+            }
+    }
+}
+
+// One wavefront per (batch, pixel, head); 4 wavefronts per block.
+__global__ void __launch_bounds__(ATHREADS) k_attn_temporal(AttnParams p, long long nitems) {
+    __shared__ __attribute__((aligned(16))) __half Vt[4][64 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lq = lane & 31, h = lane >> 5;
+    long long item = (long long)blockIdx.x * 4 + wv;
+    const bool live = item < nitems;
+    if (!live) item = nitems - 1;   // keep the wavefront in lock-step for the barrier
+    const int hd = (int)(item % p.heads);
+    long long bp = item / p.heads;
+    const int pix = (int)(bp % p.HW);
+    const int b = (int)(bp / p.HW);
+    const int F = p.F;
+    auto row_of = [&](int f) { return ((long long)b * F + f) * p.HW + pix; };
+
+    const int fq = lq < F ? lq : F - 1;
+    const __half* qsrc = p.q + row_of(fq) * p.ld + hd * 64;
+    const __half* ksrc = p.k + row_of(fq) * p.ld + hd * 64;
+    half8 qf[4], kf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        half8 t = *(const half8*)(qsrc + ks * 16 + 8 * h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = t[j] * (_Float16)0.125f;
+        qf[ks] = t;
+        kf[ks] = *(const half8*)(ksrc + ks * 16 + 8 * h);
+    }
+    // V^T into LDS in accumulator-fragment key order: 32 keys x 8 chunks = 256 chunks, 4 per lane
+    __half* vt = Vt[wv];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int q = lane + 64 * i;
+        int key = q >> 3, ch = q & 7;
+        uint4 rv = make_uint4(0, 0, 0, 0);
+        if (key < F) rv = *(const uint4*)(p.v + row_of(key) * p.ld + hd * 64 + ch * 8);
+        int pos = key_pos(key);
+        const __half* ve = (const __half*)&rv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int d = ch * 8 + e;
+            vt[d * 32 + ((((pos >> 3) ^ (d & 3)) << 3) | (pos & 7))] = ve[e];
+        }
+    }
+    float16v st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], st, 0, 0, 0);
+    float mx = kNegBig;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int key = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (key >= F) st[r] = kNegBig;
+        mx = fmaxf(mx, st[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float e = __expf(st[r] - mx);
+        st[r] = e;
+        ls += e;
+    }
+    ls += __shfl_xor(ls, 32, 64);
+    __syncthreads();   // V^T visible
+    float16v ot[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        half8 pf = pack8(st, s);
+        int chunk = (s * 16 + h * 8) >> 3;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            int d = dt * 32 + lq;
+            half8 vf = *(const half8*)(vt + d * 32 + ((chunk ^ (d & 3)) << 3));
+            ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[dt], 0, 0, 0);
+        }
+    }
+    if (live && lq < F) {
+        const float inv = 1.0f / ls;
+        __half* dst = p.o + row_of(lq) * p.ldo + hd * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = (_Float16)(ot[dt][4 * g + e] * inv);
+                *(half4*)(dst + dt * 32 + 8 * g + 4 * h) = o4;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int syn3r_attention_f16(const void* q, const void* k, const void* v, long long ld, void* out, long long ldo,
+                                   int nseq, int S, int heads, void* stream) {
+    SYN3R_REQUIRE(q && k && v && out, "attention: null tensor");
+    SYN3R_REQUIRE(nseq > 0 && S > 0 && heads > 0, "attention: bad sizes nseq=%d S=%d heads=%d", nseq, S, heads);
+    SYN3R_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && ld >= 64 * heads && ldo >= 64 * heads, "attention: bad strides");
+    SYN3R_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0, "attention: misaligned tensor");
+    AttnParams p{};
+    p.q = (const __half*)q; p.k = (const __half*)k; p.v = (const __half*)v; p.ld = ld;
+    p.o = (__half*)out; p.ldo = ldo; p.S = S; p.nseq = nseq; p.heads = heads;
+    long long blocks = (long long)nseq * heads * ((S + BQ - 1) / BQ);
+    SYN3R_REQUIRE(blocks < (1ll << 31), "attention: grid too large");
+    SYN3R_LAUNCH(k_attn_spatial, dim3((unsigned)blocks), dim3(ATHREADS), 0, (hipStream_t)stream, p);
+    SYN3R_LAUNCH_CHECK("attention launch");
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_attention_temporal_f16(const void* q, const void* k, const void* v, long long ld, void* out,
+                                            long long ldo, int B, int F, int HW, int heads, void* stream) {
+    SYN3R_REQUIRE(q && k && v && out, "attention_temporal: null tensor");
+    SYN3R_REQUIRE(B > 0 && HW > 0 && heads > 0 && F >= 1 && F <= 32, "attention_temporal: bad sizes B=%d F=%d HW=%d heads=%d (F <= 32)",
+                  B, F, HW, heads);
+    SYN3R_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && ld >= 64 * heads && ldo >= 64 * heads, "attention_temporal: bad strides");
+    SYN3R_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0, "attention_temporal: misaligned tensor");
+    AttnParams p{};
+    p.q = (const __half*)q; p.k = (const __half*)k; p.v = (const __half*)v; p.ld = ld;
+    p.o = (__half*)out; p.ldo = ldo; p.S = F; p.heads = heads; p.F = F; p.HW = HW;
+    long long nitems = (long long)B * HW * heads;
+    long long blocks = (nitems + 3) / 4;
+    SYN3R_REQUIRE(blocks < (1ll << 31), "attention_temporal: grid too large");
+    SYN3R_LAUNCH(k_attn_temporal, dim3((unsigned)blocks), dim3(ATHREADS), 0, (hipStream_t)stream, p, nitems);
+    SYN3R_LAUNCH_CHECK("attention_temporal launch");
+    return SYN3R_OK;
+}

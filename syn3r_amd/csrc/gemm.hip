@@ -1,0 +1,358 @@
+// fp16 MFMA GEMM / implicit-GEMM convolution for the SVD spatio-temporal UNet.
+//
+// One kernel serves every dense contraction of the UNet forward
+// (thirdparty/diffusers/src/diffusers/models/unets/unet_spatio_temporal_condition.py:356-489):
+//   MODE_DENSE   out[M,N] = A[M,K] . W[N,K]^T            nn.Linear, 1x1 Conv2d/Conv3d shortcuts
+//   MODE_CONV2D  3x3 Conv2d on NHWC activations (stride 1/2, optional fused nearest-2x
+//                upsample of the input)                   resnet.py:274,290, downsampling.py:116-148, upsampling.py:172-183
+//   MODE_TCONV   (3,1,1) Conv3d over the frame axis       resnet.py:571-597
+// with a fused epilogue
+//   out = s_acc * (acc + bias[n] + rowvec[m / rows_per_vec, n]) + s_res * residual[m,n] + s_aux * aux[m,n]
+// which covers bias, the time-embedding add (resnet.py:352), residual adds, the Sk=1
+// cross-attention broadcast and the AlphaBlender mix (resnet.py:789-802).
+//
+// CDNA4 mapping: 256x160x64 block tile, 512 threads = 8 wavefronts (4 along M x 2 along N),
+// each wavefront 64x80 = 4x5 tiles of v_mfma_f32_16x16x32_f16 (f32 accumulate).  Operands are
+// staged global -> registers -> LDS (XOR-swizzled 16-byte chunks, conflict-free ds_read_b128
+// fragment reads), double-buffered: the loads of k-tile t+1 are issued before the MFMAs of tile t
+// and written to the other LDS buffer after them.  Every UNet channel count (320k) is a multiple
+// of BN = 160.  Output tiles go through LDS so that stores are 16 bytes per lane, row-contiguous.
+// Blocks are dealt to XCDs in contiguous chunks (neighbouring M-tiles share the weight panel,
+// the N-tiles of one M-tile share the activation panel in L2).
+#include "common.h"
+
+using namespace syn3r;
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // 16-byte staging register (native vector: stays in VGPRs)
+
+constexpr int BM = 256, BN = 160, BK = 64;
+constexpr int NTHREADS = 512;
+constexpr int WM = 64, WN = 80;            // per-wavefront output tile
+constexpr int TM = WM / 16, TN = WN / 16;  // 4 x 5 MFMA tiles
+constexpr int A_TILE = BM * BK;            // halfs
+constexpr int B_TILE = BN * BK;
+constexpr int EPI_LD = 88;                 // padded row stride (halfs) of the epilogue staging tile
+
+enum { MODE_DENSE = 0, MODE_CONV2D = 1, MODE_TCONV = 2 };
+
+struct GemmParams {
+    const __half* A; long long lda;       // dense: row stride; conv: unused (NHWC dense)
+    const __half* W;                      // [N][K], K contiguous
+    __half* out; long long ldc;
+    const __half* bias;                   // [N] or null
+    const __half* rowvec; long long ldrv; int rows_per_vec;   // [M/rows_per_vec][ldrv] or null
+    const __half* residual; long long ldr;
+    const __half* aux; long long ldaux;
+    float s_acc, s_res, s_aux;
+    int M, N, K;
+    // conv geometry (NHWC): output Ho x Wo, input Hi x Wi, Cin channels (K = taps * Cin)
+    int Ho, Wo, Hi, Wi, Cin, stride, ups;
+    // temporal conv: F frames of HW rows each (row = (b*F + f)*HW + p)
+    int F, HW;
+};
+
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8, k = bid / 8;
+    unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
+
+template <int MODE>
+__global__ void __launch_bounds__(NTHREADS, 2) k_gemm(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __half* As = (__half*)smem_raw;                 // [2][BM][BK]
+    __half* Bs = As + 2 * A_TILE;                   // [2][BN][BK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const unsigned bid = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;   // N-tiles of one M-tile adjacent
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-thread staging assignment
+    const int a_chunk = tid & 7;
+    const int a_row0 = tid >> 3;                    // rows a_row0 + 64*i, i = 0..3
+    long long a_off[4];                             // dense: element offset of the row; conv: pixel index pieces
+    int a_n[4], a_y[4], a_x[4];                     // conv: sample / output y / output x ; tconv: frame index in a_y
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + a_row0 + 64 * i;
+        a_ok[i] = m < p.M;
+        int mc = a_ok[i] ? m : p.M - 1;
+        if constexpr (MODE == MODE_DENSE) {
+            a_off[i] = (long long)mc * p.lda;
+            a_n[i] = a_y[i] = a_x[i] = 0;
+        } else if constexpr (MODE == MODE_CONV2D) {
+            int hw = p.Ho * p.Wo;
+            a_n[i] = mc / hw;
+            int r = mc - a_n[i] * hw;
+            a_y[i] = r / p.Wo;
+            a_x[i] = r - a_y[i] * p.Wo;
+            a_off[i] = 0;
+        } else {
+            int fi = (mc / p.HW) % p.F;
+            a_y[i] = fi;
+            a_n[i] = a_x[i] = 0;
+            a_off[i] = (long long)mc * p.Cin;
+        }
+    }
+    const int b_chunk = tid & 7;
+    long long b_off[3];
+    bool b_ok[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int q = tid + NTHREADS * i;
+        int row = q >> 3;
+        b_ok[i] = (q < BN * 8);
+        int n = n0 + row;
+        bool in = b_ok[i] && n < p.N;
+        b_off[i] = (long long)(in ? n : (p.N - 1)) * p.K;
+        if (!in && b_ok[i]) b_off[i] = -1;          // zero-fill rows beyond N
+    }
+
+    const int nkt = p.K / BK;
+    const int cpb = (MODE == MODE_DENSE) ? 1 : p.Cin / BK;   // k-tiles per tap
+
+    u32x4 ra[4], rb[3];
+    auto load_tile = [&](int kt) {
+        const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
+        if constexpr (MODE == MODE_DENSE) {
+            const int k0 = kt * BK + a_chunk * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = *(const u32x4*)(p.A + a_off[i] + k0);
+        } else if constexpr (MODE == MODE_CONV2D) {
+            const int tap = kt / cpb, c0 = (kt - tap * cpb) * BK + a_chunk * 8;
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int yy = a_y[i] * p.stride + dy, xx = a_x[i] * p.stride + dx;
+                // bounds on the (possibly upsampled) input grid
+                int Hg = p.ups ? p.Hi * 2 : p.Hi, Wg = p.ups ? p.Wi * 2 : p.Wi;
+                bool ok = yy >= 0 && yy < Hg && xx >= 0 && xx < Wg;
+                if (p.ups) { yy >>= 1; xx >>= 1; }
+                long long off = (((long long)a_n[i] * p.Hi + yy) * p.Wi + xx) * p.Cin + c0;
+                ra[i] = ok ? *(const u32x4*)(p.A + off) : z;
+            }
+        } else {
+            const int tap = kt / cpb, c0 = (kt - tap * cpb) * BK + a_chunk * 8;
+            const int df = tap - 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int ff = a_y[i] + df;
+                bool ok = ff >= 0 && ff < p.F;
+                long long off = a_off[i] + (long long)df * p.HW * p.Cin + c0;
+                ra[i] = ok ? *(const u32x4*)(p.A + off) : z;
+            }
+        }
+        const int kb = kt * BK + b_chunk * 8;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (b_ok[i]) rb[i] = (b_off[i] >= 0) ? *(const u32x4*)(p.W + b_off[i] + kb) : z;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        __half* as = As + buf * A_TILE;
+        __half* bs = Bs + buf * B_TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(u32x4*)(as + swz(a_row0 + 64 * i, a_chunk)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            int q = tid + NTHREADS * i;
+            if (b_ok[i]) *(u32x4*)(bs + swz(q >> 3, b_chunk)) = rb[i];
+        }
+    };
+
+    float4v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const __half* as = As + cur * A_TILE + (wm * WM) * BK;
+        const __half* bs = Bs + cur * B_TILE + (wn * WN) * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int row = i * 16 + fr;
+                af[i] = *(const half8*)(as + row * BK + (((ks * 4 + fq) ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int row = j * 16 + fr;
+                bf[j] = *(const half8*)(bs + row * BK + (((ks * 4 + fq) ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc (+bias +rowvec) -> fp16 through LDS -> row-contiguous 16-byte stores
+    __half* st = (__half*)smem_raw + wv * (WM * EPI_LD);
+    const int gm0 = m0 + wm * WM, gn0 = n0 + wn * WN;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int col = j * 16 + fr;
+        int n = gn0 + col;
+        float bv = (p.bias && n < p.N) ? __half2float(p.bias[n]) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = i * 16 + fq * 4 + r;
+                float v = acc[i][j][r] + bv;
+                if (p.rowvec) {
+                    int m = gm0 + row;
+                    if (m < p.M && n < p.N) v += __half2float(p.rowvec[(long long)(m / p.rows_per_vec) * p.ldrv + n]);
+                }
+                st[row * EPI_LD + col] = __float2half_rn(v * p.s_acc);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    // 64 rows x 10 chunks of 8 halfs per wavefront
+#pragma unroll 2
+    for (int q = lane; q < WM * (WN / 8); q += 64) {
+        int row = q / (WN / 8), ch = q - row * (WN / 8);
+        int m = gm0 + row, n = gn0 + ch * 8;
+        if (m >= p.M || n >= p.N) continue;
+        half8 v = *(const half8*)(st + row * EPI_LD + ch * 8);
+        if (p.residual || p.aux) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+            if (p.residual) {
+                half8 rv = *(const half8*)(p.residual + (long long)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += p.s_res * (float)rv[e];
+            }
+            if (p.aux) {
+                half8 av = *(const half8*)(p.aux + (long long)m * p.ldaux + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += p.s_aux * (float)av[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (_Float16)f[e];
+        }
+        if (n + 8 <= p.N) {
+            *(half8*)(p.out + (long long)m * p.ldc + n) = v;
+        } else {
+            for (int e = 0; e < 8 && n + e < p.N; ++e) ((_Float16*)p.out)[(long long)m * p.ldc + n + e] = v[e];
+        }
+    }
+}
+
+constexpr size_t kGemmLds = (size_t)2 * (A_TILE + B_TILE) * sizeof(__half);   // 106,496 B
+static_assert(8 * WM * EPI_LD * sizeof(__half) <= kGemmLds, "epilogue staging must fit in the tile buffers");
+
+template <int MODE>
+int launch(const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kGemmLds);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm)");
+        attr_set = true;
+    }
+    int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    SYN3R_LAUNCH(k_gemm<MODE>, dim3(tiles), dim3(NTHREADS), kGemmLds, stream, p);
+    SYN3R_LAUNCH_CHECK("gemm launch");
+    return SYN3R_OK;
+}
+
+int check_common(const GemmParams& p, const char* who) {
+    SYN3R_REQUIRE(p.A && p.W && p.out, "%s: null operand", who);
+    SYN3R_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "%s: bad sizes M=%d N=%d K=%d", who, p.M, p.N, p.K);
+    SYN3R_REQUIRE(p.K % BK == 0, "%s: K=%d must be a multiple of %d", who, p.K, BK);
+    SYN3R_REQUIRE(p.ldc % 8 == 0 && p.ldc >= p.N, "%s: ldc=%lld must be >= N and a multiple of 8", who, p.ldc);
+    SYN3R_REQUIRE(!p.residual || (p.ldr % 8 == 0 && p.ldr >= p.N), "%s: bad residual stride", who);
+    SYN3R_REQUIRE(!p.aux || (p.ldaux % 8 == 0 && p.ldaux >= p.N), "%s: bad aux stride", who);
+    SYN3R_REQUIRE(!p.rowvec || (p.rows_per_vec > 0 && p.ldrv >= p.N), "%s: bad rowvec arguments", who);
+    SYN3R_REQUIRE(((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out | (uintptr_t)p.residual | (uintptr_t)p.aux) % 16 == 0,
+                  "%s: operands must be 16-byte aligned", who);
+    return SYN3R_OK;
+}
+
+}  // namespace
+
+extern "C" int syn3r_gemm_f16(const void* A, long long lda, const void* W, void* out, long long ldc, const void* bias,
+                              const void* rowvec, long long ldrv, int rows_per_vec, const void* residual,
+                              long long ldr, const void* aux, long long ldaux, float s_acc, float s_res, float s_aux,
+                              int M, int N, int K, void* stream) {
+    GemmParams p{};
+    p.A = (const __half*)A; p.lda = lda; p.W = (const __half*)W; p.out = (__half*)out; p.ldc = ldc;
+    p.bias = (const __half*)bias; p.rowvec = (const __half*)rowvec; p.ldrv = ldrv; p.rows_per_vec = rows_per_vec;
+    p.residual = (const __half*)residual; p.ldr = ldr; p.aux = (const __half*)aux; p.ldaux = ldaux;
+    p.s_acc = s_acc; p.s_res = s_res; p.s_aux = s_aux; p.M = M; p.N = N; p.K = K;
+    int rc = check_common(p, "gemm_f16");
+    if (rc) return rc;
+    SYN3R_REQUIRE(lda % 8 == 0 && lda >= K, "gemm_f16: lda=%lld must be >= K and a multiple of 8", lda);
+    return launch<MODE_DENSE>(p, (hipStream_t)stream);
+}
+
+extern "C" int syn3r_conv2d3x3_f16(const void* X, const void* W, void* out, long long ldc, const void* bias,
+                                   const void* rowvec, long long ldrv, int rows_per_vec, const void* residual,
+                                   long long ldr, float s_acc, float s_res, int NB, int Hi, int Wi, int Cin, int Cout,
+                                   int stride, int upsample, void* stream) {
+    SYN3R_REQUIRE(NB > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv2d3x3: bad sizes");
+    SYN3R_REQUIRE(stride == 1 || stride == 2, "conv2d3x3: stride must be 1 or 2");
+    SYN3R_REQUIRE(!(upsample && stride != 1), "conv2d3x3: upsample requires stride 1");
+    SYN3R_REQUIRE(Cin % BK == 0, "conv2d3x3: Cin=%d must be a multiple of %d (pad the input channels)", Cin, BK);
+    GemmParams p{};
+    p.A = (const __half*)X; p.W = (const __half*)W; p.out = (__half*)out; p.ldc = ldc; p.bias = (const __half*)bias;
+    p.rowvec = (const __half*)rowvec; p.ldrv = ldrv; p.rows_per_vec = rows_per_vec;
+    p.residual = (const __half*)residual; p.ldr = ldr; p.s_acc = s_acc; p.s_res = s_res; p.s_aux = 0.f;
+    p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.stride = stride; p.ups = upsample ? 1 : 0;
+    int Hg = upsample ? 2 * Hi : Hi, Wg = upsample ? 2 * Wi : Wi;
+    p.Ho = (Hg + 2 - 3) / stride + 1;
+    p.Wo = (Wg + 2 - 3) / stride + 1;
+    long long M = (long long)NB * p.Ho * p.Wo;
+    SYN3R_REQUIRE(M < (1ll << 31), "conv2d3x3: too many output pixels");
+    p.M = (int)M; p.N = Cout; p.K = 9 * Cin;
+    int rc = check_common(p, "conv2d3x3");
+    if (rc) return rc;
+    return launch<MODE_CONV2D>(p, (hipStream_t)stream);
+}
+
+extern "C" int syn3r_tconv3_f16(const void* X, const void* W, void* out, long long ldc, const void* bias,
+                                const void* rowvec, long long ldrv, int rows_per_vec, const void* residual,
+                                long long ldr, float s_acc, float s_res, int B, int F, int HW, int Cin, int Cout,
+                                void* stream) {
+    SYN3R_REQUIRE(B > 0 && F > 0 && HW > 0 && Cin > 0 && Cout > 0, "tconv3: bad sizes");
+    SYN3R_REQUIRE(Cin % BK == 0, "tconv3: Cin=%d must be a multiple of %d", Cin, BK);
+    GemmParams p{};
+    p.A = (const __half*)X; p.W = (const __half*)W; p.out = (__half*)out; p.ldc = ldc; p.bias = (const __half*)bias;
+    p.rowvec = (const __half*)rowvec; p.ldrv = ldrv; p.rows_per_vec = rows_per_vec;
+    p.residual = (const __half*)residual; p.ldr = ldr; p.s_acc = s_acc; p.s_res = s_res; p.s_aux = 0.f;
+    p.F = F; p.HW = HW; p.Cin = Cin;
+    long long M = (long long)B * F * HW;
+    SYN3R_REQUIRE(M < (1ll << 31), "tconv3: too many rows");
+    p.M = (int)M; p.N = Cout; p.K = 3 * Cin;
+    int rc = check_common(p, "tconv3");
+    if (rc) return rc;
+    return launch<MODE_TCONV>(p, (hipStream_t)stream);
+}

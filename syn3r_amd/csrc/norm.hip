@@ -1,0 +1,246 @@
+// HBM-bound normalisation / activation kernels of the SVD UNet on channels-last fp16 tensors
+// (statistics and arithmetic in fp32, 16-byte vector accesses).
+//
+//   GroupNorm(32) [+ SiLU]   resnet.py:272,286,574,588 ; transformer_temporal.py:235 ; unet_...:243-244
+//                            2D form: one sample = one frame (R = h*w rows)
+//                            3D form: one sample = one batch item (R = F*h*w rows, contiguous)
+//   LayerNorm                attention.py:195,225,253,430,440,453,465 — optionally fused with the
+//                            broadcast add of the frame-position embedding (transformer_temporal.py:355)
+//   GEGLU                    activations.py GEGLU.forward: hidden * gelu(gate), exact erf GELU
+#include "common.h"
+
+using namespace syn3r;
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// ---------------------------------------------------------------- GroupNorm
+// thread t owns channel vector cv = t % cvec (8 channels) of rows (t / cvec) + k * rpb
+__global__ void k_gn_stats(const __half* __restrict__ x, int R, int C, int rows_per_block, float* __restrict__ stats) {
+    extern __shared__ float red[];   // [threads][16]
+    const int cvec = C >> 3;
+    const int rpb = blockDim.x / cvec;
+    const int cv = threadIdx.x % cvec, rl = threadIdx.x / cvec;
+    const int sample = blockIdx.y;
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int r_end = min(R, r_begin + rows_per_block);
+    const __half* base = x + (size_t)sample * R * C + (size_t)cv * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    for (int r = r_begin + rl; r < r_end; r += rpb) {
+        half8 v = *(const half8*)(base + (size_t)r * C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = (float)v[e];
+            s[e] += f;
+            q[e] += f * f;
+        }
+    }
+    float* my = red + threadIdx.x * 16;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { my[e] = s[e]; my[8 + e] = q[e]; }
+    __syncthreads();
+    // threads 0..31: one group each; sum its channels over the rpb row-lanes
+    if (threadIdx.x < 32) {
+        const int g = threadIdx.x, cpg = C / 32;
+        float gs = 0.f, gq = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            int v = c >> 3, e = c & 7;
+            for (int k = 0; k < rpb; ++k) {
+                const float* o = red + (k * cvec + v) * 16;
+                gs += o[e];
+                gq += o[8 + e];
+            }
+        }
+        float* dst = stats + ((size_t)sample * 32 + g) * 2;
+        unsafeAtomicAdd(dst, gs);
+        unsafeAtomicAdd(dst + 1, gq);
+    }
+}
+
+template <bool SILU>
+__global__ void k_gn_apply(const __half* __restrict__ x, __half* __restrict__ y, int R, int C, int rows_per_block,
+                           const float* __restrict__ stats, const __half* __restrict__ gamma,
+                           const __half* __restrict__ beta, float eps) {
+    const int cvec = C >> 3;
+    const int rpb = blockDim.x / cvec;
+    const int cv = threadIdx.x % cvec, rl = threadIdx.x / cvec;
+    const int sample = blockIdx.y;
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int r_end = min(R, r_begin + rows_per_block);
+    const int cpg = C / 32;
+    const float inv_n = 1.0f / ((float)R * (float)cpg);
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int c = cv * 8 + e;
+        int g = c / cpg;
+        const float* st = stats + ((size_t)sample * 32 + g) * 2;
+        float mean = st[0] * inv_n;
+        float var = fmaxf(st[1] * inv_n - mean * mean, 0.0f);
+        float rstd = rsqrtf(var + eps);
+        float ga = (float)((const _Float16*)gamma)[c], be = (float)((const _Float16*)beta)[c];
+        a[e] = rstd * ga;
+        b[e] = be - mean * rstd * ga;
+    }
+    const size_t off = (size_t)sample * R * C + (size_t)cv * 8;
+    for (int r = r_begin + rl; r < r_end; r += rpb) {
+        half8 v = *(const half8*)(x + off + (size_t)r * C);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = (float)v[e] * a[e] + b[e];
+            if (SILU) f = f / (1.0f + __expf(-f));
+            o[e] = (_Float16)f;
+        }
+        *(half8*)(y + off + (size_t)r * C) = o;
+    }
+}
+
+// ---------------------------------------------------------------- LayerNorm (one wavefront per row)
+constexpr int LN_MAXV = 8;   // up to 8 vectors of 8 channels per lane: C <= 4096
+
+__global__ void __launch_bounds__(256) k_layernorm(const __half* __restrict__ x, __half* __restrict__ y,
+                                                   __half* __restrict__ xsum, const __half* __restrict__ addvec,
+                                                   int rows_per_vec, long long M, int C,
+                                                   const __half* __restrict__ gamma, const __half* __restrict__ beta,
+                                                   float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int cvec = C >> 3;
+    const __half* src = x + row * C;
+    const __half* add = addvec ? addvec + (row / rows_per_vec) * C : nullptr;
+    float v[LN_MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        int cv = lane + 64 * k;
+        if (cv < cvec) {
+            half8 h = *(const half8*)(src + cv * 8);
+            if (add) {
+                half8 a = *(const half8*)(add + cv * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = h[e] + a[e];   // fp16 add, as the reference's tensor add
+                if (xsum) *(half8*)(xsum + row * C + cv * 8) = h;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[k][e] = (float)h[e]; s += v[k][e]; }
+        }
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        int cv = lane + 64 * k;
+        if (cv < cvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { float d = v[k][e] - mean; q += d * d; }
+        }
+    }
+    q = wave_sum(q);
+    const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        int cv = lane + 64 * k;
+        if (cv < cvec) {
+            half8 g = *(const half8*)(gamma + cv * 8), b = *(const half8*)(beta + cv * 8), o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)((v[k][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+            *(half8*)(y + row * C + cv * 8) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- GEGLU
+__global__ void __launch_bounds__(256) k_geglu(const __half* __restrict__ x, __half* __restrict__ y, long long M, int D) {
+    const int dvec = D >> 3;
+    const long long total = M * dvec;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long row = i / dvec;
+        int cv = (int)(i - row * dvec);
+        const __half* src = x + row * 2 * D + cv * 8;
+        half8 hv = *(const half8*)src, gv = *(const half8*)(src + D), o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float g = (float)gv[e];
+            float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752f));
+            o[e] = (_Float16)((float)hv[e] * ge);
+        }
+        *(half8*)(y + row * D + cv * 8) = o;
+    }
+}
+
+int gn_threads(int C) {
+    int cvec = C / 8;
+    if (cvec > 1024) return -1;
+    int rpb = 256 / cvec;
+    if (rpb < 1) rpb = 1;
+    return rpb * cvec;
+}
+
+}  // namespace
+
+extern "C" size_t syn3r_groupnorm_workspace_bytes(int samples) { return samples > 0 ? (size_t)samples * 32 * 2 * 4 : 0; }
+
+extern "C" int syn3r_groupnorm_f16(const void* x, void* y, int samples, int rows, int C, const void* gamma,
+                                   const void* beta, float eps, int silu, void* workspace, size_t workspace_bytes,
+                                   void* stream_) {
+    SYN3R_REQUIRE(x && y && gamma && beta, "groupnorm: null tensor");
+    SYN3R_REQUIRE(samples > 0 && rows > 0 && C > 0 && C % 32 == 0 && C % 8 == 0, "groupnorm: bad sizes samples=%d rows=%d C=%d",
+                  samples, rows, C);
+    int threads = gn_threads(C);
+    SYN3R_REQUIRE(threads > 0, "groupnorm: C=%d too large", C);
+    size_t need = syn3r_groupnorm_workspace_bytes(samples);
+    if (!workspace || workspace_bytes < need) {
+        set_error("groupnorm: workspace %zu < %zu", workspace_bytes, need);
+        return SYN3R_E_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_hip(hipMemsetAsync(workspace, 0, need, stream), "memset");
+    if (rc) return rc;
+    // enough blocks to fill the chip: ~2048 in total
+    int chunks = (2048 + samples - 1) / samples;
+    int rows_per_block = (rows + chunks - 1) / chunks;
+    if (rows_per_block < 8) rows_per_block = 8;
+    chunks = (rows + rows_per_block - 1) / rows_per_block;
+    dim3 grid(chunks, samples);
+    size_t lds = (size_t)threads * 16 * sizeof(float);
+    SYN3R_LAUNCH(k_gn_stats, grid, dim3(threads), lds, stream, (const __half*)x, rows, C, rows_per_block,
+                 (float*)workspace);
+    if (silu)
+        SYN3R_LAUNCH(k_gn_apply<true>, grid, dim3(threads), 0, stream, (const __half*)x, (__half*)y, rows, C,
+                     rows_per_block, (const float*)workspace, (const __half*)gamma, (const __half*)beta, eps);
+    else
+        SYN3R_LAUNCH(k_gn_apply<false>, grid, dim3(threads), 0, stream, (const __half*)x, (__half*)y, rows, C,
+                     rows_per_block, (const float*)workspace, (const __half*)gamma, (const __half*)beta, eps);
+    SYN3R_LAUNCH_CHECK("groupnorm launch");
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_layernorm_f16(const void* x, void* y, void* xsum, const void* addvec, int rows_per_vec,
+                                   long long M, int C, const void* gamma, const void* beta, float eps, void* stream_) {
+    SYN3R_REQUIRE(x && y && gamma && beta, "layernorm: null tensor");
+    SYN3R_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "layernorm: bad sizes M=%lld C=%d", M, C);
+    SYN3R_REQUIRE(!addvec || rows_per_vec > 0, "layernorm: rows_per_vec required with addvec");
+    long long blocks = (M + 3) / 4;
+    SYN3R_REQUIRE(blocks < (1ll << 31), "layernorm: too many rows");
+    SYN3R_LAUNCH(k_layernorm, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const __half*)x, (__half*)y,
+                 (__half*)xsum, (const __half*)addvec, rows_per_vec, M, C, (const __half*)gamma, (const __half*)beta, eps);
+    SYN3R_LAUNCH_CHECK("layernorm launch");
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_geglu_f16(const void* x, void* y, long long M, int D, void* stream_) {
+    SYN3R_REQUIRE(x && y, "geglu: null tensor");
+    SYN3R_REQUIRE(M > 0 && D > 0 && D % 8 == 0, "geglu: bad sizes M=%lld D=%d", M, D);
+    long long total = M * (D / 8);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    SYN3R_LAUNCH(k_geglu, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const __half*)x, (__half*)y, M, D);
+    SYN3R_LAUNCH_CHECK("geglu launch");
+    return SYN3R_OK;
+}

@@ -1,0 +1,154 @@
+"""Thin torch-tensor wrappers over the UNet operators of include/syn3r_hip.h.
+
+Every function takes contiguous fp16 HIP tensors in the channels-last token-matrix layout
+(rows = ((b*F + f)*h + y)*w + x, columns = channels) and launches on torch's current stream.
+No CPU fallback: CPU tensors raise `Syn3rError`.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import _lib as L
+
+H = torch.float16
+
+
+def _chk(*ts):
+    dev = L.require_gpu(*[t for t in ts if t is not None])
+    for t in ts:
+        if t is not None and (t.dtype != H or not t.is_contiguous()):
+            raise L.Syn3rError(f"UNet operators need contiguous fp16 tensors, got {t.dtype} contiguous={t.is_contiguous()}")
+    return dev
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+           rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0, residual: Optional[torch.Tensor] = None,
+           aux: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0, s_aux: float = 1.0,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [M,K] @ weight[N,K]^T with the fused epilogue of syn3r_gemm_f16.  x may be a column
+    slice of a wider matrix (stride(0) >= K)."""
+    dev = L.require_gpu(x, weight)
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K or x.stride(1) != 1:
+        raise ValueError(f"linear: x {tuple(x.shape)} / weight {tuple(weight.shape)} mismatch")
+    _chk(weight, bias, rowvec, residual, aux)
+    if out is None:
+        out = torch.empty((M, N), dtype=H, device=dev)
+    lib = L.load()
+    rc = lib.syn3r_gemm_f16(x.data_ptr(), x.stride(0), L.ptr(weight), out.data_ptr(), out.stride(0), L.ptr(bias),
+                            L.ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0, int(rows_per_vec),
+                            residual.data_ptr() if residual is not None else None,
+                            residual.stride(0) if residual is not None else 0,
+                            aux.data_ptr() if aux is not None else None, aux.stride(0) if aux is not None else 0,
+                            float(s_acc), float(s_res), float(s_aux), M, N, K, L.stream_ptr(dev))
+    L.check(rc, "syn3r_gemm_f16")
+    return out
+
+
+def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride: int = 1,
+            upsample: bool = False, rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0,
+            residual: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0) -> torch.Tensor:
+    """x [NB,Hi,Wi,Cin] NHWC, weight [Cout,3,3,Cin] -> [NB,Ho,Wo,Cout]."""
+    dev = _chk(x, weight, bias, rowvec, residual)
+    NB, Hi, Wi, Cin = x.shape
+    Cout = weight.shape[0]
+    if tuple(weight.shape[1:]) != (3, 3, Cin):
+        raise ValueError(f"conv3x3: weight {tuple(weight.shape)} does not match Cin={Cin}")
+    Hg, Wg = (2 * Hi, 2 * Wi) if upsample else (Hi, Wi)
+    Ho, Wo = (Hg - 1) // stride + 1, (Wg - 1) // stride + 1
+    out = torch.empty((NB, Ho, Wo, Cout), dtype=H, device=dev)
+    lib = L.load()
+    rc = lib.syn3r_conv2d3x3_f16(L.ptr(x), L.ptr(weight), L.ptr(out), Cout, L.ptr(bias), L.ptr(rowvec),
+                                 rowvec.stride(0) if rowvec is not None else 0, int(rows_per_vec),
+                                 L.ptr(residual), Cout if residual is not None else 0, float(s_acc), float(s_res),
+                                 NB, Hi, Wi, Cin, Cout, int(stride), 1 if upsample else 0, L.stream_ptr(dev))
+    L.check(rc, "syn3r_conv2d3x3_f16")
+    return out
+
+
+def tconv3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], B: int, F: int, HW: int, *,
+           rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0, residual: Optional[torch.Tensor] = None,
+           s_acc: float = 1.0, s_res: float = 1.0) -> torch.Tensor:
+    """x [B*F*HW, Cin], weight [Cout,3,Cin] -> [B*F*HW, Cout] (3-tap convolution over frames)."""
+    dev = _chk(x, weight, bias, rowvec, residual)
+    M, Cin = x.shape
+    Cout = weight.shape[0]
+    if M != B * F * HW or tuple(weight.shape[1:]) != (3, Cin):
+        raise ValueError("tconv3: shape mismatch")
+    out = torch.empty((M, Cout), dtype=H, device=dev)
+    lib = L.load()
+    rc = lib.syn3r_tconv3_f16(L.ptr(x), L.ptr(weight), L.ptr(out), Cout, L.ptr(bias), L.ptr(rowvec),
+                              rowvec.stride(0) if rowvec is not None else 0, int(rows_per_vec), L.ptr(residual),
+                              Cout if residual is not None else 0, float(s_acc), float(s_res), B, F, HW, Cin, Cout,
+                              L.stream_ptr(dev))
+    L.check(rc, "syn3r_tconv3_f16")
+    return out
+
+
+def attention(qkv: torch.Tensor, nseq: int, S: int, heads: int) -> torch.Tensor:
+    """qkv [nseq*S, 3*heads*64] (q | k | v thirds) -> [nseq*S, heads*64]."""
+    dev = _chk(qkv)
+    C = heads * 64
+    if qkv.shape != (nseq * S, 3 * C):
+        raise ValueError(f"attention: qkv {tuple(qkv.shape)} != {(nseq * S, 3 * C)}")
+    out = torch.empty((nseq * S, C), dtype=H, device=dev)
+    base = qkv.data_ptr()
+    lib = L.load()
+    rc = lib.syn3r_attention_f16(base, base + 2 * C, base + 4 * C, 3 * C, L.ptr(out), C, nseq, S, heads,
+                                 L.stream_ptr(dev))
+    L.check(rc, "syn3r_attention_f16")
+    return out
+
+
+def attention_temporal(qkv: torch.Tensor, B: int, F: int, HW: int, heads: int) -> torch.Tensor:
+    dev = _chk(qkv)
+    C = heads * 64
+    if qkv.shape != (B * F * HW, 3 * C):
+        raise ValueError(f"attention_temporal: qkv {tuple(qkv.shape)} != {(B * F * HW, 3 * C)}")
+    out = torch.empty((B * F * HW, C), dtype=H, device=dev)
+    base = qkv.data_ptr()
+    lib = L.load()
+    rc = lib.syn3r_attention_temporal_f16(base, base + 2 * C, base + 4 * C, 3 * C, L.ptr(out), C, B, F, HW, heads,
+                                          L.stream_ptr(dev))
+    L.check(rc, "syn3r_attention_temporal_f16")
+    return out
+
+
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, samples: int, eps: float, silu: bool) -> torch.Tensor:
+    """x [samples*rows, C] -> same shape; 32 groups, statistics per (sample, group)."""
+    dev = _chk(x, gamma, beta)
+    M, C = x.shape
+    if M % samples:
+        raise ValueError("groupnorm: rows not divisible by samples")
+    y = torch.empty_like(x)
+    lib = L.load()
+    ws = L.workspace(dev, lib.syn3r_groupnorm_workspace_bytes(samples), "gn")
+    rc = lib.syn3r_groupnorm_f16(L.ptr(x), L.ptr(y), samples, M // samples, C, L.ptr(gamma), L.ptr(beta), float(eps),
+                                 1 if silu else 0, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+    L.check(rc, "syn3r_groupnorm_f16")
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, *,
+              addvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0, want_sum: bool = False):
+    dev = _chk(x, gamma, beta, addvec)
+    M, C = x.shape
+    y = torch.empty_like(x)
+    xsum = torch.empty_like(x) if (want_sum and addvec is not None) else None
+    lib = L.load()
+    rc = lib.syn3r_layernorm_f16(L.ptr(x), L.ptr(y), L.ptr(xsum), L.ptr(addvec), int(rows_per_vec), M, C,
+                                 L.ptr(gamma), L.ptr(beta), float(eps), L.stream_ptr(dev))
+    L.check(rc, "syn3r_layernorm_f16")
+    return (y, xsum) if want_sum else y
+
+
+def geglu(x: torch.Tensor) -> torch.Tensor:
+    dev = _chk(x)
+    M, D2 = x.shape
+    y = torch.empty((M, D2 // 2), dtype=H, device=dev)
+    rc = L.load().syn3r_geglu_f16(L.ptr(x), L.ptr(y), M, D2 // 2, L.stream_ptr(dev))
+    L.check(rc, "syn3r_geglu_f16")
+    return y

@@ -1,0 +1,188 @@
+"""Each hand-written UNet operator vs a plain PyTorch fp32 reference of the same op (inputs are the
+same fp16-rounded values; fp32 accumulation on both sides; tolerance = fp16 output rounding)."""
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+pytestmark = pytest.mark.gpu
+
+H = torch.float16
+
+
+def rnd(gen, *shape, scale=1.0, dev=None):
+    return (torch.randn(*shape, generator=gen) * scale).to(H).to(dev)
+
+
+def close(a, b, tol=2e-3):
+    a, b = a.float(), b.float()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-6
+    assert err <= tol * ref + 1e-3, (err, ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 160, 64), (300, 320, 128), (1000, 2560, 320), (37, 48, 192), (513, 960, 640)])
+def test_gemm_plain(M, N, K, gpu):
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(M + N)
+    x, w, b = rnd(g, M, K, dev=gpu), rnd(g, N, K, scale=K ** -0.5, dev=gpu), rnd(g, N, dev=gpu)
+    close(ops.linear(x, w, b), x.float() @ w.float().T + b.float())
+    close(ops.linear(x, w), x.float() @ w.float().T)
+
+
+def test_gemm_asymmetric_identity(gpu):
+    """A = I with an asymmetric B catches a transposed accumulator map."""
+    from syn3r_amd.unet import ops
+    K = 128
+    x = torch.eye(K, dtype=H, device=gpu)
+    w = (torch.arange(160 * K, device=gpu).reshape(160, K) % 61).to(H)
+    assert torch.equal(ops.linear(x, w), w.T.contiguous())
+
+
+def test_gemm_epilogue(gpu):
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(5)
+    M, N, K, rpv = 600, 320, 320, 100
+    x, w, b = rnd(g, M, K, dev=gpu), rnd(g, N, K, scale=K ** -0.5, dev=gpu), rnd(g, N, dev=gpu)
+    rv, res, aux = rnd(g, M // rpv, N, dev=gpu), rnd(g, M, N, dev=gpu), rnd(g, M, N, dev=gpu)
+    out = ops.linear(x, w, b, rowvec=rv, rows_per_vec=rpv, residual=res, aux=aux, s_acc=0.3, s_res=1.0, s_aux=0.7)
+    ref = 0.3 * (x.float() @ w.float().T + b.float() + rv.float().repeat_interleave(rpv, 0)) + res.float() + 0.7 * aux.float()
+    close(out, ref)
+    # strided A (column slice of a wider matrix) and strided output
+    wide = rnd(g, M, 3 * K, dev=gpu)
+    close(ops.linear(wide[:, K:2 * K], w), wide[:, K:2 * K].float() @ w.float().T)
+
+
+@pytest.mark.parametrize("NB,Hi,Wi,Cin,Cout,stride,ups", [(2, 9, 16, 64, 160, 1, False), (3, 18, 32, 128, 64, 2, False),
+                                                          (2, 5, 7, 64, 320, 1, True), (1, 40, 72, 320, 320, 1, False),
+                                                          (2, 9, 7, 64, 64, 2, False)])
+def test_conv3x3(NB, Hi, Wi, Cin, Cout, stride, ups, gpu):
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(NB * Hi + Cout)
+    x = rnd(g, NB, Hi, Wi, Cin, dev=gpu)
+    w = rnd(g, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, dev=gpu)
+    b = rnd(g, Cout, dev=gpu)
+    xin = x.permute(0, 3, 1, 2).float()
+    if ups:
+        xin = Fn.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = Fn.conv2d(xin, w.float(), b.float(), stride=stride, padding=1).permute(0, 2, 3, 1)
+    out = ops.conv3x3(x, w.permute(0, 2, 3, 1).contiguous(), b, stride=stride, upsample=ups)
+    assert out.shape == ref.shape
+    close(out, ref)
+
+
+def test_conv3x3_epilogue(gpu):
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(11)
+    NB, Hh, Ww, C = 4, 8, 12, 64
+    x, w, b = rnd(g, NB, Hh, Ww, C, dev=gpu), rnd(g, 128, C, 3, 3, scale=0.05, dev=gpu), rnd(g, 128, dev=gpu)
+    temb, res = rnd(g, NB, 128, dev=gpu), rnd(g, NB, Hh, Ww, 128, dev=gpu)
+    out = ops.conv3x3(x, w.permute(0, 2, 3, 1).contiguous(), b, rowvec=temb, rows_per_vec=Hh * Ww,
+                      residual=res.reshape(-1, 128), s_acc=1.0, s_res=1.0)
+    ref = Fn.conv2d(x.permute(0, 3, 1, 2).float(), w.float(), b.float(), padding=1).permute(0, 2, 3, 1)
+    ref = ref + temb.float()[:, None, None, :] + res.float()
+    close(out, ref)
+
+
+@pytest.mark.parametrize("B,F,HW,Cin,Cout", [(2, 14, 24, 64, 64), (1, 25, 30, 128, 320), (2, 5, 7, 64, 160)])
+def test_tconv3(B, F, HW, Cin, Cout, gpu):
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(F + HW)
+    x = rnd(g, B * F * HW, Cin, dev=gpu)
+    w = rnd(g, Cout, Cin, 3, scale=(3 * Cin) ** -0.5, dev=gpu)   # Conv3d weight [Cout,Cin,3,1,1] squeezed
+    b = rnd(g, Cout, dev=gpu)
+    res = rnd(g, B * F * HW, Cout, dev=gpu)
+    x5 = x.float().reshape(B, F, HW, Cin).permute(0, 3, 1, 2)[..., None]    # [B,C,F,HW,1]
+    ref = Fn.conv3d(x5, w.float()[..., None, None], b.float(), padding=(1, 0, 0))
+    ref = ref[..., 0].permute(0, 2, 3, 1).reshape(B * F * HW, Cout)
+    out = ops.tconv3(x, w.permute(0, 2, 1).contiguous(), b, B, F, HW, residual=res, s_acc=0.6, s_res=1.0)
+    close(out, 0.6 * ref + res.float())
+
+
+@pytest.mark.parametrize("nseq,S,heads", [(2, 128, 1), (3, 576, 2), (1, 2304, 5), (2, 45, 2), (2, 216, 1), (1, 130, 3)])
+def test_attention_spatial(nseq, S, heads, gpu):
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(S)
+    C = heads * 64
+    qkv = rnd(g, nseq * S, 3 * C, dev=gpu)
+    out = ops.attention(qkv, nseq, S, heads)
+    q, k, v = [t.float().reshape(nseq, S, heads, 64).transpose(1, 2) for t in qkv.split(C, dim=1)]
+    ref = Fn.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(nseq * S, C)
+    close(out, ref, tol=3e-3)
+
+
+def test_attention_spatial_peaked_softmax(gpu):
+    """Force the online-softmax rescale: one key row dominates late in the sequence."""
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(3)
+    S, C = 512, 64
+    qkv = rnd(g, S, 3 * C, dev=gpu)
+    qkv[400, C:2 * C] = qkv[7, :C] * 6.0      # key 400 aligned with query 7, far larger logit
+    out = ops.attention(qkv, 1, S, 1)
+    q, k, v = [t.float().reshape(1, S, 1, 64).transpose(1, 2) for t in qkv.split(C, dim=1)]
+    ref = Fn.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(S, C)
+    close(out, ref, tol=3e-3)
+
+
+@pytest.mark.parametrize("B,F,HW,heads", [(2, 14, 50, 2), (1, 25, 33, 5), (2, 3, 7, 1), (1, 32, 9, 1)])
+def test_attention_temporal(B, F, HW, heads, gpu):
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(F * HW)
+    C = heads * 64
+    qkv = rnd(g, B * F * HW, 3 * C, dev=gpu)
+    out = ops.attention_temporal(qkv, B, F, HW, heads)
+    def seqs(t):   # [B,F,HW,heads,64] -> [B*HW, heads, F, 64]
+        return t.float().reshape(B, F, HW, heads, 64).permute(0, 2, 3, 1, 4).reshape(B * HW, heads, F, 64)
+    q, k, v = [seqs(t) for t in qkv.split(C, dim=1)]
+    ref = Fn.scaled_dot_product_attention(q, k, v)            # [B*HW, heads, F, 64]
+    ref = ref.reshape(B, HW, heads, F, 64).permute(0, 3, 1, 2, 4).reshape(B * F * HW, C)
+    close(out, ref, tol=3e-3)
+
+
+@pytest.mark.parametrize("samples,rows,C,silu", [(4, 200, 320, True), (2, 1000, 64, False), (3, 77, 2560, True),
+                                                 (2, 512, 960, True), (28, 144, 1280, False)])
+def test_groupnorm(samples, rows, C, silu, gpu):
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(rows + C)
+    x = (rnd(g, samples * rows, C, dev=gpu).float() * 2 + 0.5).to(H)
+    ga, be = rnd(g, C, dev=gpu), rnd(g, C, dev=gpu)
+    out = ops.groupnorm(x, ga, be, samples, 1e-5, silu)
+    xr = x.float().reshape(samples, rows, C).permute(0, 2, 1)
+    ref = Fn.group_norm(xr, 32, ga.float(), be.float(), 1e-5)
+    if silu:
+        ref = Fn.silu(ref)
+    close(out, ref.permute(0, 2, 1).reshape(samples * rows, C), tol=3e-3)
+
+
+@pytest.mark.parametrize("M,C", [(1000, 320), (37, 1280), (513, 64), (64, 640)])
+def test_layernorm(M, C, gpu):
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(M)
+    x, ga, be = rnd(g, M, C, dev=gpu), rnd(g, C, dev=gpu), rnd(g, C, dev=gpu)
+    close(ops.layernorm(x, ga, be), Fn.layer_norm(x.float(), (C,), ga.float(), be.float(), 1e-5), tol=3e-3)
+    rpv = 8 if M % 8 == 0 else 1
+    add = rnd(g, M // rpv, C, dev=gpu)
+    y, s = ops.layernorm(x, ga, be, addvec=add, rows_per_vec=rpv, want_sum=True)
+    xs = x + add.repeat_interleave(rpv, 0)            # fp16 add, as the reference
+    assert torch.equal(s, xs)
+    close(y, Fn.layer_norm(xs.float(), (C,), ga.float(), be.float(), 1e-5), tol=3e-3)
+
+
+def test_geglu(gpu):
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(2)
+    x = rnd(g, 333, 2 * 640, scale=2.0, dev=gpu)
+    hid, gate = x.float().chunk(2, dim=-1)
+    close(ops.geglu(x), hid * Fn.gelu(gate))
+
+
+def test_ops_reject_bad_input(gpu):
+    from syn3r_amd import _lib
+    from syn3r_amd.unet import ops
+    x = torch.zeros(8, 100, dtype=H, device=gpu)     # K not a multiple of 64
+    w = torch.zeros(16, 100, dtype=H, device=gpu)
+    with pytest.raises(_lib.Syn3rError):
+        ops.linear(x, w)
+    with pytest.raises(_lib.Syn3rError):
+        ops.linear(torch.zeros(8, 64, dtype=H), torch.zeros(16, 64, dtype=H))   # CPU tensors
+    with pytest.raises(_lib.Syn3rError):
+        ops.attention_temporal(torch.zeros(40 * 2, 192, dtype=H, device=gpu), 1, 40, 2, 1)   # F > 32
