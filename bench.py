@@ -177,6 +177,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if loop_b is not None:
+        loop_b.count_flops()
     barrier()
     with L.kernel_trace() as tr:
         t0 = time.perf_counter()
@@ -206,7 +208,7 @@ def main():
         kern = {k: v for k, v in tr.result.items()}
         roof = None
         if loop_b is not None:
-            roof = loop_b.roofline(kern)
+            roof = loop_b.roofline(kern, args.steps)
         if roof is None and kern:
             name = max(kern, key=lambda k: kern[k][1])
             calls, ms = kern[name]

@@ -130,10 +130,31 @@ def gen_sched(EulerDiscreteScheduler):
         print("sched", name, {k: getattr(v_, "shape", ()) for k, v_ in out.items()})
 
 
+def gen_unet():
+    """Reference UNetSpatioTemporalConditionModel (small config, CPU fp32) on seeded weights/inputs."""
+    from diffusers.models import UNetSpatioTemporalConditionModel
+    from oracle import unet_weights as UW
+    torch.manual_seed(0)
+    model = UNetSpatioTemporalConditionModel(**UW.SMALL_CONFIG)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(UW.make_state_dict(shapes))
+    model.eval()
+    out = {"names": np.array(sorted(shapes)), "shapes": np.array([str(shapes[k]) for k in sorted(shapes)])}
+    for tag, (B, F, h, w) in {"b2f5": (2, 5, 16, 24), "b1f14": (1, 14, 8, 16)}.items():
+        sample, t, ehs, added = UW.make_inputs(B, F, h, w, seed=F)
+        with torch.no_grad():
+            y = model(sample, t, ehs, added, return_dict=False)[0]
+        out[f"{tag}_out"] = y.numpy()
+        print("unet", tag, y.shape, float(y.abs().mean()), float(y.std()))
+    np.savez_compressed(GOLD / "unet_small.npz", **out)
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     Sch, consistency, forward_warp, inverse_warp = _import_reference()
-    which = sys.argv[1:] or ["warp", "sched"]
+    which = sys.argv[1:] or ["warp", "sched", "unet"]
+    if "unet" in which:
+        gen_unet()
     if "warp" in which:
         gen_warp(consistency, forward_warp, inverse_warp)
     if "sched" in which:

@@ -1,0 +1,89 @@
+"""One SVD (denoise-step, pass) unit on synthetic inputs — HOT LOOP B of bench.py.
+
+Follows the body of the reference's denoising loop for one pass of the "Replace" variant
+(model/SVD_2pass_prob_uncertain.py:661-742): duplicate the latents for classifier-free guidance,
+`scale_model_input`, concatenate the conditioning-image latents on the channel axis, UNet forward,
+per-frame guidance combine, `step_interp_prob_uncertain`.  Synthetic data as SURVEY.md §8d
+(no checkpoint is reachable offline: seeded N(0, 0.02) weights of the SVD-XT architecture).
+"""
+from __future__ import annotations
+
+import torch
+
+from ..schedulers.scheduling_euler_discrete import SVD_XT_SCHEDULER_CONFIG, EulerDiscreteScheduler
+from ..unet import ops
+from ..unet.model import UNetSpatioTemporalConditionModel
+
+MFMA_F16_PEAK_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def cfg_combine(noise_pred: torch.Tensor, guidance_scale: torch.Tensor) -> torch.Tensor:
+    """`uncond + gs * (cond - uncond)` in the model dtype, as SVD_2pass_prob_uncertain.py:709-711."""
+    uncond, cond = noise_pred.chunk(2)
+    return uncond + guidance_scale * (cond - uncond)
+
+
+class SvdStepBench:
+    def __init__(self, frames: int, dev: torch.device, seed: int = 1234, h: int = 72, w: int = 128):
+        self.F, self.h, self.w, self.dev = frames, h, w, dev
+        self.unet = UNetSpatioTemporalConditionModel().init_random(dev, seed=seed)
+        self.sch = EulerDiscreteScheduler(**SVD_XT_SCHEDULER_CONFIG)
+        self.sch.set_timesteps(100)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        rn = lambda *s: torch.randn(*s, generator=g, device=dev)
+        F = frames
+        self.latents = (rn(1, F, 4, h, w) * float(self.sch.init_noise_sigma)).half()
+        self.image_latents = rn(1, F, 4, h, w).half().repeat(2, 1, 1, 1, 1)
+        self.image_latents[0].zero_()                                   # CFG: unconditional half is zeros
+        cond = rn(1, F, 4, h, w) / 5.6
+        self.temp_cond = torch.cat([torch.zeros_like(cond), cond], 0)  # index 1 = conditioning latents
+        self.ehs = torch.cat([torch.zeros(1, 1, 1024, device=dev), rn(1, 1, 1024)], 0).half()
+        self.added = torch.tensor([[6.0, 127.0, 0.02]] * 2, device=dev).half()
+        m = torch.rand(1, F - 2, 1, h, w, generator=g, device=dev)
+        self.mask = m.expand(1, F - 2, 4, h, w).contiguous()
+        self.lambda_ts = (torch.rand(100, F, generator=g, device=dev) > 0.5).double()
+        self.guidance = torch.linspace(1.0, 3.0, F, device=dev).half()[None, :, None, None, None]
+        self.i = 0
+        self.flops_per_unit = None
+
+    def step_pass(self) -> torch.Tensor:
+        i = self.i % 100
+        self.i += 1
+        t = self.sch.timesteps[i]
+        x = torch.cat([self.latents] * 2)
+        x = self.sch.scale_model_input(x, t, step_i=i).half()
+        x = torch.cat([x, self.image_latents], dim=2)
+        noise_pred = self.unet(x, t, self.ehs, self.added)[0]
+        noise_pred = cfg_combine(noise_pred, self.guidance)
+        out = self.sch.step_interp_prob_uncertain(noise_pred, t, self.latents, self.temp_cond, self.mask,
+                                                  self.lambda_ts, step_i=i)
+        return out.prev_sample
+
+    def count_flops(self) -> dict:
+        """Algorithmic FLOPs of one unit, counted from the launched contractions (2*M*N*K)."""
+        ops.FLOPS.update(enabled=True, gemm=0.0, attn=0.0)
+        self.step_pass()
+        torch.cuda.synchronize(self.dev)
+        ops.FLOPS["enabled"] = False
+        self.flops_per_unit = dict(gemm=ops.FLOPS["gemm"], attn=ops.FLOPS["attn"])
+        return self.flops_per_unit
+
+    def roofline(self, kernels: dict, units: int):
+        """MFMA roofline of the dominant UNet kernel from bench.py's HIP-event kernel trace."""
+        if self.flops_per_unit is None:
+            self.count_flops()
+        cand = {"k_gemm<MODE>": "gemm", "k_attn_spatial": "attn"}
+        best = None
+        for name, kind in cand.items():
+            if name in kernels and (best is None or kernels[name][1] > kernels[best][1]):
+                best = name
+        if best is None:
+            return None
+        calls, ms = kernels[best]
+        flops = self.flops_per_unit[cand[best]] * units
+        if best == "k_attn_spatial" and "k_attn_temporal" in kernels:
+            pass
+        ach = flops / (ms / 1e3) / 1e12
+        return dict(bound="mfma", kernel=best, achieved=round(ach, 1), peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / MFMA_F16_PEAK_TFLOPS, 4), traffic=None, avg_ms=round(ms / calls, 4), calls=calls,
+                    algorithmic_flops_per_unit=self.flops_per_unit)

@@ -1,0 +1,452 @@
+"""UNetSpatioTemporalConditionModel on the HIP path.
+
+Mirror of the reference's vendored
+`thirdparty/diffusers/src/diffusers/models/unets/unet_spatio_temporal_condition.py` (same
+constructor arguments, same `forward(sample, timestep, encoder_hidden_states, added_time_ids)`
+signature and output shape, same parameter names so a diffusers `state_dict` / safetensors
+checkpoint loads unchanged).  The host code only orders kernel launches and owns the buffers;
+all tensor work runs in the operators of `ops.py` on channels-last fp16 token matrices.
+
+Restructurings relative to the reference graph (each keeps the reference's result):
+  * no permutes / reshapes: the layout [((b*F + f)*h + y)*w + x, C] serves the spatial blocks,
+    the temporal blocks and the 3-D resnets alike (unet_3d_blocks.py, resnet.py:703-720,
+    attention.py:487-489,527-529);
+  * cross-attention has ONE key (encoder_hidden_states is [B*F, 1, 1024],
+    unet_spatio_temporal_condition.py:425), so softmax == 1 and attn2 == to_out(to_v(ctx)): a
+    per-batch vector added in the epilogue of the preceding projection; its LayerNorm is dead work;
+  * time-embedding adds, residual adds and both AlphaBlender mixes are GEMM epilogues;
+  * nearest-2x upsampling is folded into the following 3x3 convolution's gather.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn.functional as Fn
+
+from .. import _lib as L
+from . import ops
+
+H = torch.float16
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """embeddings.py `Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)` -> fp32 [len(t), dim]."""
+    half = dim // 2
+    exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32, device=t.device) / half
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+
+
+class _Params:
+    """Name -> tensor store with diffusers names; tracks what a module declared."""
+
+    def __init__(self):
+        self.shapes: Dict[str, Tuple[int, ...]] = {}
+        self.t: Dict[str, torch.Tensor] = {}
+
+    def declare(self, name: str, *shape: int):
+        self.shapes[name] = tuple(shape)
+        return name
+
+    def linear(self, prefix: str, cin: int, cout: int, bias: bool = True):
+        self.declare(prefix + ".weight", cout, cin)
+        if bias:
+            self.declare(prefix + ".bias", cout)
+
+    def norm(self, prefix: str, c: int):
+        self.declare(prefix + ".weight", c)
+        self.declare(prefix + ".bias", c)
+
+    def __getitem__(self, name):
+        return self.t[name]
+
+
+class UNetSpatioTemporalConditionModel:
+    def __init__(self, sample_size: Optional[int] = None, in_channels: int = 8, out_channels: int = 4,
+                 down_block_types: Tuple[str, ...] = ("CrossAttnDownBlockSpatioTemporal",) * 3 + ("DownBlockSpatioTemporal",),
+                 up_block_types: Tuple[str, ...] = ("UpBlockSpatioTemporal",) + ("CrossAttnUpBlockSpatioTemporal",) * 3,
+                 block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280), addition_time_embed_dim: int = 256,
+                 projection_class_embeddings_input_dim: int = 768, layers_per_block: Union[int, Tuple[int, ...]] = 2,
+                 cross_attention_dim: Union[int, Tuple[int, ...]] = 1024,
+                 transformer_layers_per_block: Union[int, Tuple[int, ...]] = 1,
+                 num_attention_heads: Union[int, Tuple[int, ...]] = (5, 10, 20, 20), num_frames: int = 25):
+        n = len(block_out_channels)
+        if len(down_block_types) != len(up_block_types):
+            raise ValueError("Must provide the same number of `down_block_types` as `up_block_types`.")
+        if len(block_out_channels) != len(down_block_types):
+            raise ValueError("Must provide the same number of `block_out_channels` as `down_block_types`.")
+        tup = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
+        self.config = dict(sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
+                           down_block_types=tuple(down_block_types), up_block_types=tuple(up_block_types),
+                           block_out_channels=tuple(block_out_channels),
+                           addition_time_embed_dim=addition_time_embed_dim,
+                           projection_class_embeddings_input_dim=projection_class_embeddings_input_dim,
+                           layers_per_block=tup(layers_per_block), cross_attention_dim=tup(cross_attention_dim),
+                           transformer_layers_per_block=tup(transformer_layers_per_block),
+                           num_attention_heads=tup(num_attention_heads), num_frames=num_frames)
+        c = self.config
+        if any(v != 1 for v in c["transformer_layers_per_block"]):
+            raise NotImplementedError("transformer_layers_per_block != 1 is not used by SVD")
+        for ch, hd in zip(block_out_channels, c["num_attention_heads"]):
+            if ch != 64 * hd:
+                raise NotImplementedError("attention head dim must be 64 (block_out_channels == 64 * num_attention_heads)")
+            if ch % 64:
+                raise NotImplementedError("channel counts must be multiples of 64")
+        self.p = _Params()
+        self._declare()
+        self.packed: Dict[str, torch.Tensor] = {}
+        self.device: Optional[torch.device] = None
+
+    # ------------------------------------------------------------------ parameter declaration (diffusers names)
+    def _declare_resblock(self, pre: str, cin: int, cout: int, temb: int):
+        p = self.p
+        s = pre + ".spatial_res_block"
+        p.norm(s + ".norm1", cin)
+        p.declare(s + ".conv1.weight", cout, cin, 3, 3); p.declare(s + ".conv1.bias", cout)
+        p.linear(s + ".time_emb_proj", temb, cout)
+        p.norm(s + ".norm2", cout)
+        p.declare(s + ".conv2.weight", cout, cout, 3, 3); p.declare(s + ".conv2.bias", cout)
+        if cin != cout:
+            p.declare(s + ".conv_shortcut.weight", cout, cin, 1, 1); p.declare(s + ".conv_shortcut.bias", cout)
+        t = pre + ".temporal_res_block"
+        p.norm(t + ".norm1", cout)
+        p.declare(t + ".conv1.weight", cout, cout, 3, 1, 1); p.declare(t + ".conv1.bias", cout)
+        p.linear(t + ".time_emb_proj", temb, cout)
+        p.norm(t + ".norm2", cout)
+        p.declare(t + ".conv2.weight", cout, cout, 3, 1, 1); p.declare(t + ".conv2.bias", cout)
+        p.declare(pre + ".time_mixer.mix_factor", 1)
+
+    def _declare_attn(self, pre: str, dim: int, cross: Optional[int]):
+        p = self.p
+        kdim = cross if cross is not None else dim
+        p.linear(pre + ".to_q", dim, dim, bias=False)
+        p.linear(pre + ".to_k", kdim, dim, bias=False)
+        p.linear(pre + ".to_v", kdim, dim, bias=False)
+        p.linear(pre + ".to_out.0", dim, dim)
+
+    def _declare_ff(self, pre: str, dim: int):
+        self.p.linear(pre + ".net.0.proj", dim, 8 * dim)
+        self.p.linear(pre + ".net.2", 4 * dim, dim)
+
+    def _declare_transformer(self, pre: str, ch: int, cross: int):
+        p = self.p
+        p.norm(pre + ".norm", ch)
+        p.linear(pre + ".proj_in", ch, ch)
+        b = pre + ".transformer_blocks.0"
+        p.norm(b + ".norm1", ch); self._declare_attn(b + ".attn1", ch, None)
+        p.norm(b + ".norm2", ch); self._declare_attn(b + ".attn2", ch, cross)
+        p.norm(b + ".norm3", ch); self._declare_ff(b + ".ff", ch)
+        t = pre + ".temporal_transformer_blocks.0"
+        p.norm(t + ".norm_in", ch); self._declare_ff(t + ".ff_in", ch)
+        p.norm(t + ".norm1", ch); self._declare_attn(t + ".attn1", ch, None)
+        p.norm(t + ".norm2", ch); self._declare_attn(t + ".attn2", ch, cross)
+        p.norm(t + ".norm3", ch); self._declare_ff(t + ".ff", ch)
+        p.linear(pre + ".time_pos_embed.linear_1", ch, 4 * ch)
+        p.linear(pre + ".time_pos_embed.linear_2", 4 * ch, ch)
+        p.declare(pre + ".time_mixer.mix_factor", 1)
+        p.linear(pre + ".proj_out", ch, ch)
+
+    def _declare(self):
+        c, p = self.config, self.p
+        boc = c["block_out_channels"]
+        temb = boc[0] * 4
+        p.declare("conv_in.weight", boc[0], c["in_channels"], 3, 3); p.declare("conv_in.bias", boc[0])
+        p.linear("time_embedding.linear_1", boc[0], temb); p.linear("time_embedding.linear_2", temb, temb)
+        p.linear("add_embedding.linear_1", c["projection_class_embeddings_input_dim"], temb)
+        p.linear("add_embedding.linear_2", temb, temb)
+        self.down_plan, self.up_plan = [], []
+        out_ch = boc[0]
+        for i, typ in enumerate(c["down_block_types"]):
+            in_ch, out_ch = out_ch, boc[i]
+            has_attn = typ == "CrossAttnDownBlockSpatioTemporal"
+            if not has_attn and typ != "DownBlockSpatioTemporal":
+                raise ValueError(f"{typ} does not exist.")
+            layers = []
+            for j in range(c["layers_per_block"][i]):
+                pre = f"down_blocks.{i}"
+                self._declare_resblock(f"{pre}.resnets.{j}", in_ch if j == 0 else out_ch, out_ch, temb)
+                if has_attn:
+                    self._declare_transformer(f"{pre}.attentions.{j}", out_ch, c["cross_attention_dim"][i])
+                layers.append((in_ch if j == 0 else out_ch, out_ch))
+            down = i != len(boc) - 1
+            if down:
+                p.declare(f"down_blocks.{i}.downsamplers.0.conv.weight", out_ch, out_ch, 3, 3)
+                p.declare(f"down_blocks.{i}.downsamplers.0.conv.bias", out_ch)
+            self.down_plan.append(dict(idx=i, attn=has_attn, layers=layers, down=down, ch=out_ch,
+                                       heads=c["num_attention_heads"][i]))
+        mid = boc[-1]
+        self._declare_resblock("mid_block.resnets.0", mid, mid, temb)
+        self._declare_transformer("mid_block.attentions.0", mid, c["cross_attention_dim"][-1])
+        self._declare_resblock("mid_block.resnets.1", mid, mid, temb)
+        rev = list(reversed(boc))
+        rev_heads = list(reversed(c["num_attention_heads"]))
+        rev_layers = list(reversed(c["layers_per_block"]))
+        rev_cross = list(reversed(c["cross_attention_dim"]))
+        out_ch = rev[0]
+        for i, typ in enumerate(c["up_block_types"]):
+            has_attn = typ == "CrossAttnUpBlockSpatioTemporal"
+            if not has_attn and typ != "UpBlockSpatioTemporal":
+                raise ValueError(f"{typ} does not exist.")
+            prev_out, out_ch = out_ch, rev[i]
+            in_ch = rev[min(i + 1, len(boc) - 1)]
+            nl = rev_layers[i] + 1
+            layers = []
+            for j in range(nl):
+                res_skip = in_ch if j == nl - 1 else out_ch
+                res_in = prev_out if j == 0 else out_ch
+                self._declare_resblock(f"up_blocks.{i}.resnets.{j}", res_in + res_skip, out_ch, temb)
+                if has_attn:
+                    self._declare_transformer(f"up_blocks.{i}.attentions.{j}", out_ch, rev_cross[i])
+                layers.append((res_in + res_skip, out_ch))
+            up = i != len(boc) - 1
+            if up:
+                p.declare(f"up_blocks.{i}.upsamplers.0.conv.weight", out_ch, out_ch, 3, 3)
+                p.declare(f"up_blocks.{i}.upsamplers.0.conv.bias", out_ch)
+            self.up_plan.append(dict(idx=i, attn=has_attn, layers=layers, up=up, ch=out_ch, heads=rev_heads[i]))
+        p.norm("conv_norm_out", boc[0])
+        p.declare("conv_out.weight", c["out_channels"], boc[0], 3, 3); p.declare("conv_out.bias", c["out_channels"])
+
+    # ------------------------------------------------------------------ weights
+    def parameter_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        return dict(self.p.shapes)
+
+    def num_parameters(self) -> int:
+        return sum(math.prod(s) for s in self.p.shapes.values())
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], device) -> "UNetSpatioTemporalConditionModel":
+        missing = [k for k in self.p.shapes if k not in sd]
+        extra = [k for k in sd if k not in self.p.shapes]
+        if missing or extra:
+            raise KeyError(f"state_dict mismatch: missing {missing[:5]} (+{max(0, len(missing) - 5)}), "
+                           f"unexpected {extra[:5]} (+{max(0, len(extra) - 5)})")
+        dev = torch.device(device)
+        for k, shape in self.p.shapes.items():
+            t = sd[k]
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{k}: shape {tuple(t.shape)} != {shape}")
+            self.p.t[k] = t.detach().to(device=dev, dtype=H)
+        self.device = dev
+        self._pack()
+        return self
+
+    def init_random(self, device, seed: int = 0, std: float = 0.02) -> "UNetSpatioTemporalConditionModel":
+        """Seeded N(0, std) weights (bench / smoke: no checkpoint is reachable offline)."""
+        dev = torch.device(device)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        sd = {}
+        for k, shape in self.p.shapes.items():
+            if k.endswith("mix_factor"):
+                sd[k] = torch.full(shape, 0.5, device=dev)
+            elif ".norm" in k and k.endswith(".weight") or k == "conv_norm_out.weight":
+                sd[k] = torch.ones(shape, device=dev)
+            elif k.endswith(".bias"):
+                sd[k] = torch.zeros(shape, device=dev)
+            else:
+                fan_in = math.prod(shape[1:])
+                sd[k] = torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * min(std, fan_in ** -0.5)
+        return self.load_state_dict(sd, dev)
+
+    @classmethod
+    def from_pretrained(cls, directory: str, device, **kw):
+        """Load `<directory>/config.json` + `diffusion_pytorch_model[.fp16].safetensors` (local files only;
+        the reference fetches by model name at model/diffusionGS.py:1089)."""
+        import json
+        from pathlib import Path
+        from safetensors.torch import load_file
+        d = Path(directory)
+        cfg = json.loads((d / "config.json").read_text())
+        keys = ("sample_size in_channels out_channels down_block_types up_block_types block_out_channels "
+                "addition_time_embed_dim projection_class_embeddings_input_dim layers_per_block cross_attention_dim "
+                "transformer_layers_per_block num_attention_heads num_frames").split()
+        model = cls(**{k: cfg[k] for k in keys if k in cfg})
+        for name in ("diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors"):
+            if (d / name).exists():
+                return model.load_state_dict(load_file(str(d / name)), device)
+        raise FileNotFoundError(f"no safetensors weights under {d}")
+
+    def _pack(self):
+        """Kernel-side layouts: OHWI conv weights, fused QKV, (3,1,1) convs as [Cout,3,Cin]."""
+        p, pk = self.p, {}
+        for k, t in p.t.items():
+            if k.endswith(".weight") and t.dim() == 4 and t.shape[-1] == 3:          # Conv2d 3x3
+                w = t
+                if w.shape[1] % 64:                                                    # conv_in: pad Cin to 64
+                    w = Fn.pad(w, (0, 0, 0, 0, 0, 64 - w.shape[1] % 64))
+                if w.shape[0] % 8:                                                     # conv_out: pad Cout to 8
+                    w = Fn.pad(w, (0, 0, 0, 0, 0, 0, 0, 8 - w.shape[0] % 8))
+                pk[k] = w.permute(0, 2, 3, 1).contiguous()
+            elif k.endswith(".weight") and t.dim() == 5:                               # Conv3d (3,1,1)
+                pk[k] = t[..., 0, 0].permute(0, 2, 1).contiguous()
+            elif k.endswith("conv_shortcut.weight"):
+                pk[k] = t.reshape(t.shape[0], t.shape[1]).contiguous()
+        if p.t["conv_out.bias"].shape[0] % 8:
+            pk["conv_out.bias"] = Fn.pad(p.t["conv_out.bias"], (0, 8 - p.t["conv_out.bias"].shape[0] % 8))
+        for k in list(p.t):
+            if k.endswith("attn1.to_q.weight"):
+                pre = k[: -len("to_q.weight")]
+                pk[pre + "qkv"] = torch.cat([p.t[pre + "to_q.weight"], p.t[pre + "to_k.weight"],
+                                             p.t[pre + "to_v.weight"]], 0).contiguous()
+        self.packed = pk
+        self.alpha = {k: torch.sigmoid(t.float()).to(H) for k, t in p.t.items() if k.endswith("mix_factor")}
+
+    def w(self, name: str) -> torch.Tensor:
+        return self.packed.get(name, self.p.t.get(name))
+
+    # ------------------------------------------------------------------ blocks
+    def _blend_scales(self, name: str):
+        a = self.alpha[name]                       # fp16, as `alpha.to(x_spatial.dtype)` (resnet.py:797)
+        one_minus = (1.0 - a).to(H)                # fp16 arithmetic, as the reference
+        return float(a), float(one_minus)
+
+    def _resblock(self, pre: str, x: torch.Tensor, st: dict, cin: int, cout: int) -> torch.Tensor:
+        B, F, h, w_ = st["B"], st["F"], st["h"], st["w"]
+        HW = h * w_
+        s, t = pre + ".spatial_res_block", pre + ".temporal_res_block"
+        W = self.w
+        # spatial ResnetBlock2D (resnet.py:325-378)
+        tp_s = ops.linear(st["temb_act"], W(s + ".time_emb_proj.weight"), W(s + ".time_emb_proj.bias"))    # [B, cout]
+        hcur = ops.groupnorm(x, W(s + ".norm1.weight"), W(s + ".norm1.bias"), B * F, 1e-5, True)
+        hcur = ops.conv3x3(hcur.view(B * F, h, w_, cin), W(s + ".conv1.weight"), W(s + ".conv1.bias"),
+                           rowvec=tp_s, rows_per_vec=F * HW).view(-1, cout)
+        hcur = ops.groupnorm(hcur, W(s + ".norm2.weight"), W(s + ".norm2.bias"), B * F, 1e-5, True)
+        skip = x
+        if cin != cout:
+            skip = ops.linear(x, W(s + ".conv_shortcut.weight"), W(s + ".conv_shortcut.bias"))
+        xs = ops.conv3x3(hcur.view(B * F, h, w_, cout), W(s + ".conv2.weight"), W(s + ".conv2.bias"),
+                         residual=skip).view(-1, cout)
+        # TemporalResnetBlock (resnet.py:613-636) + AlphaBlender (:789-802)
+        tp_t = ops.linear(st["temb_act"], W(t + ".time_emb_proj.weight"), W(t + ".time_emb_proj.bias"))
+        hcur = ops.groupnorm(xs, W(t + ".norm1.weight"), W(t + ".norm1.bias"), B, 1e-5, True)
+        hcur = ops.tconv3(hcur, W(t + ".conv1.weight"), W(t + ".conv1.bias"), B, F, HW, rowvec=tp_t, rows_per_vec=F * HW)
+        hcur = ops.groupnorm(hcur, W(t + ".norm2.weight"), W(t + ".norm2.bias"), B, 1e-5, True)
+        a, om = self._blend_scales(pre + ".time_mixer.mix_factor")
+        # alpha*xs + (1-alpha)*(xs + conv2)  ==  (alpha + (1-alpha))*xs + (1-alpha)*conv2
+        return ops.tconv3(hcur, W(t + ".conv2.weight"), W(t + ".conv2.bias"), B, F, HW, residual=xs, s_acc=om,
+                          s_res=a + om)
+
+    def _cross_vec(self, pre: str, ehs: torch.Tensor) -> torch.Tensor:
+        """attn2 with a single key: to_out(to_v(ctx)) per batch item -> [B, C]."""
+        v = ops.linear(ehs, self.w(pre + ".to_v.weight"))
+        return ops.linear(v, self.w(pre + ".to_out.0.weight"), self.w(pre + ".to_out.0.bias"))
+
+    def _ff(self, pre: str, x: torch.Tensor, **epilogue) -> torch.Tensor:
+        g = ops.linear(x, self.w(pre + ".net.0.proj.weight"), self.w(pre + ".net.0.proj.bias"))
+        return ops.linear(ops.geglu(g), self.w(pre + ".net.2.weight"), self.w(pre + ".net.2.bias"), **epilogue)
+
+    def _transformer(self, pre: str, x: torch.Tensor, st: dict, ch: int, heads: int) -> torch.Tensor:
+        B, F, h, w_ = st["B"], st["F"], st["h"], st["w"]
+        HW = h * w_
+        W = self.w
+        ehs = st["ehs"]
+        hs = ops.groupnorm(x, W(pre + ".norm.weight"), W(pre + ".norm.bias"), B * F, 1e-6, False)
+        hs = ops.linear(hs, W(pre + ".proj_in.weight"), W(pre + ".proj_in.bias"))
+        # frame-position embedding (transformer_temporal.py:326-337), one row per (b, f)
+        key = ("pos", ch, F)
+        if key not in st:
+            st[key] = timestep_embedding(torch.arange(F, device=x.device), ch).to(H)
+        e = ops.linear(st[key], W(pre + ".time_pos_embed.linear_1.weight"), W(pre + ".time_pos_embed.linear_1.bias"))
+        e = ops.linear(Fn.silu(e), W(pre + ".time_pos_embed.linear_2.weight"), W(pre + ".time_pos_embed.linear_2.bias"))
+        emb = e.repeat(B, 1).contiguous()                                  # [B*F, C]
+        # BasicTransformerBlock (attention.py:283-403)
+        b = pre + ".transformer_blocks.0"
+        n1 = ops.layernorm(hs, W(b + ".norm1.weight"), W(b + ".norm1.bias"))
+        a1 = ops.attention(ops.linear(n1, W(b + ".attn1.qkv")), B * F, HW, heads)
+        hs = ops.linear(a1, W(b + ".attn1.to_out.0.weight"), W(b + ".attn1.to_out.0.bias"), residual=hs,
+                        rowvec=self._cross_vec(b + ".attn2", ehs), rows_per_vec=F * HW)
+        n3 = ops.layernorm(hs, W(b + ".norm3.weight"), W(b + ".norm3.bias"))
+        hs = self._ff(b + ".ff", n3, residual=hs)
+        # TemporalBasicTransformerBlock (attention.py:478-533) on hs + emb
+        t = pre + ".temporal_transformer_blocks.0"
+        nin, hmix = ops.layernorm(hs, W(t + ".norm_in.weight"), W(t + ".norm_in.bias"), addvec=emb, rows_per_vec=HW,
+                                  want_sum=True)
+        tt = self._ff(t + ".ff_in", nin, residual=hmix)
+        n1 = ops.layernorm(tt, W(t + ".norm1.weight"), W(t + ".norm1.bias"))
+        a1 = ops.attention_temporal(ops.linear(n1, W(t + ".attn1.qkv")), B, F, HW, heads)
+        tt = ops.linear(a1, W(t + ".attn1.to_out.0.weight"), W(t + ".attn1.to_out.0.bias"), residual=tt,
+                        rowvec=self._cross_vec(t + ".attn2", ehs), rows_per_vec=F * HW)
+        n3 = ops.layernorm(tt, W(t + ".norm3.weight"), W(t + ".norm3.bias"))
+        a, om = self._blend_scales(pre + ".time_mixer.mix_factor")
+        # alpha*hs + (1-alpha)*(ff + tt)
+        mix = self._ff(t + ".ff", n3, residual=tt, aux=hs, s_acc=om, s_res=om, s_aux=a)
+        return ops.linear(mix, W(pre + ".proj_out.weight"), W(pre + ".proj_out.bias"), residual=x)
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor,
+                added_time_ids: torch.Tensor, return_dict: bool = False):
+        """Reference: unet_spatio_temporal_condition.py:356-489.  sample [B,F,Cin,h,w] fp16 -> [B,F,Cout,h,w]."""
+        if self.device is None:
+            raise L.Syn3rError("UNet weights are not loaded (load_state_dict / from_pretrained / init_random)")
+        dev = L.require_gpu(sample, encoder_hidden_states, added_time_ids)
+        c = self.config
+        B, F, Cin, h, w_ = sample.shape
+        if Cin != c["in_channels"]:
+            raise ValueError(f"sample has {Cin} channels, the model expects {c['in_channels']}")
+        if F > 32:
+            raise NotImplementedError("temporal attention kernel supports up to 32 frames")
+        W = self.w
+        boc = c["block_out_channels"]
+        # 1. time (:385-418)
+        ts = timestep if torch.is_tensor(timestep) else torch.tensor([timestep], dtype=torch.float64)
+        ts = ts.reshape(-1).to(dev).expand(B)
+        t_emb = timestep_embedding(ts, boc[0]).to(H)
+        emb = ops.linear(t_emb, W("time_embedding.linear_1.weight"), W("time_embedding.linear_1.bias"))
+        emb = ops.linear(Fn.silu(emb), W("time_embedding.linear_2.weight"), W("time_embedding.linear_2.bias"))
+        te = timestep_embedding(added_time_ids.flatten().to(dev), c["addition_time_embed_dim"]).reshape(B, -1).to(H)
+        aug = ops.linear(te, W("add_embedding.linear_1.weight"), W("add_embedding.linear_1.bias"))
+        aug = ops.linear(Fn.silu(aug), W("add_embedding.linear_2.weight"), W("add_embedding.linear_2.bias"))
+        emb = emb + aug
+        st = dict(B=B, F=F, h=h, w=w_, temb_act=Fn.silu(emb).contiguous(),
+                  ehs=encoder_hidden_states.reshape(B, -1).to(H).contiguous())
+        # 2. conv_in on NHWC with channels padded to 64 (:428)
+        x = sample.to(H).flatten(0, 1).permute(0, 2, 3, 1)
+        x = Fn.pad(x, (0, 64 - Cin % 64 if Cin % 64 else 0)).contiguous()
+        x = ops.conv3x3(x, W("conv_in.weight"), W("conv_in.bias")).view(-1, boc[0])
+        skips = [(x, boc[0])]
+        # 3. down (:432-449)
+        for blk in self.down_plan:
+            i = blk["idx"]
+            for j, (cin, cout) in enumerate(blk["layers"]):
+                x = self._resblock(f"down_blocks.{i}.resnets.{j}", x, st, cin, cout)
+                if blk["attn"]:
+                    x = self._transformer(f"down_blocks.{i}.attentions.{j}", x, st, cout, blk["heads"])
+                skips.append((x, cout))
+            if blk["down"]:
+                ch = blk["ch"]
+                x = ops.conv3x3(x.view(B * F, st["h"], st["w"], ch), W(f"down_blocks.{i}.downsamplers.0.conv.weight"),
+                                W(f"down_blocks.{i}.downsamplers.0.conv.bias"), stride=2)
+                st["h"], st["w"] = x.shape[1], x.shape[2]
+                x = x.view(-1, ch)
+                skips.append((x, ch))
+        # 4. mid (:452-457)
+        mid = boc[-1]
+        x = self._resblock("mid_block.resnets.0", x, st, mid, mid)
+        x = self._transformer("mid_block.attentions.0", x, st, mid, c["num_attention_heads"][-1])
+        x = self._resblock("mid_block.resnets.1", x, st, mid, mid)
+        # 5. up (:460-478)
+        for blk in self.up_plan:
+            i = blk["idx"]
+            for j, (cin, cout) in enumerate(blk["layers"]):
+                sk, sk_ch = skips.pop()
+                x = torch.cat([x, sk], dim=1)
+                x = self._resblock(f"up_blocks.{i}.resnets.{j}", x, st, cin, cout)
+                if blk["attn"]:
+                    x = self._transformer(f"up_blocks.{i}.attentions.{j}", x, st, cout, blk["heads"])
+            if blk["up"]:
+                ch = blk["ch"]
+                x = ops.conv3x3(x.view(B * F, st["h"], st["w"], ch), W(f"up_blocks.{i}.upsamplers.0.conv.weight"),
+                                W(f"up_blocks.{i}.upsamplers.0.conv.bias"), upsample=True)
+                st["h"], st["w"] = x.shape[1], x.shape[2]
+                x = x.view(-1, ch)
+        # 6. out (:481-486)
+        x = ops.groupnorm(x, W("conv_norm_out.weight"), W("conv_norm_out.bias"), B * F, 1e-5, True)
+        y = ops.conv3x3(x.view(B * F, st["h"], st["w"], boc[0]), W("conv_out.weight"), W("conv_out.bias"))
+        y = y[..., : c["out_channels"]].permute(0, 3, 1, 2).reshape(B, F, c["out_channels"], st["h"], st["w"]).contiguous()
+        if return_dict:
+            from types import SimpleNamespace
+            return SimpleNamespace(sample=y)
+        return (y,)
+
+    __call__ = forward

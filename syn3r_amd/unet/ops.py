@@ -14,6 +14,14 @@ from .. import _lib as L
 
 H = torch.float16
 
+# algorithmic FLOP accounting for bench.py's roofline line (2*M*N*K per contraction)
+FLOPS = {"enabled": False, "gemm": 0.0, "attn": 0.0}
+
+
+def _count(kind: str, flops: float) -> None:
+    if FLOPS["enabled"]:
+        FLOPS[kind] += flops
+
 
 def _chk(*ts):
     dev = L.require_gpu(*[t for t in ts if t is not None])
@@ -45,6 +53,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
                             aux.data_ptr() if aux is not None else None, aux.stride(0) if aux is not None else 0,
                             float(s_acc), float(s_res), float(s_aux), M, N, K, L.stream_ptr(dev))
     L.check(rc, "syn3r_gemm_f16")
+    _count("gemm", 2.0 * M * N * K)
     return out
 
 
@@ -66,6 +75,7 @@ def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
                                  L.ptr(residual), Cout if residual is not None else 0, float(s_acc), float(s_res),
                                  NB, Hi, Wi, Cin, Cout, int(stride), 1 if upsample else 0, L.stream_ptr(dev))
     L.check(rc, "syn3r_conv2d3x3_f16")
+    _count("gemm", 2.0 * NB * Ho * Wo * Cout * 9 * Cin)
     return out
 
 
@@ -85,6 +95,7 @@ def tconv3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
                               Cout if residual is not None else 0, float(s_acc), float(s_res), B, F, HW, Cin, Cout,
                               L.stream_ptr(dev))
     L.check(rc, "syn3r_tconv3_f16")
+    _count("gemm", 2.0 * M * Cout * 3 * Cin)
     return out
 
 
@@ -100,6 +111,7 @@ def attention(qkv: torch.Tensor, nseq: int, S: int, heads: int) -> torch.Tensor:
     rc = lib.syn3r_attention_f16(base, base + 2 * C, base + 4 * C, 3 * C, L.ptr(out), C, nseq, S, heads,
                                  L.stream_ptr(dev))
     L.check(rc, "syn3r_attention_f16")
+    _count("attn", 4.0 * nseq * heads * S * S * 64)
     return out
 
 
@@ -114,6 +126,7 @@ def attention_temporal(qkv: torch.Tensor, B: int, F: int, HW: int, heads: int) -
     rc = lib.syn3r_attention_temporal_f16(base, base + 2 * C, base + 4 * C, 3 * C, L.ptr(out), C, B, F, HW, heads,
                                           L.stream_ptr(dev))
     L.check(rc, "syn3r_attention_temporal_f16")
+    _count("attn", 4.0 * B * HW * heads * F * F * 64)
     return out
 
 

@@ -1,0 +1,64 @@
+"""UNet host module: parameter table vs the reference (CPU) and forward vs the reference's golden output (GPU)."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_weights as UW
+
+
+def test_parameter_names_and_shapes_match_reference(golden_dir):
+    """The HIP UNet declares exactly the reference module's state_dict (names and shapes), so a diffusers
+    checkpoint loads unchanged."""
+    from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel
+    g = np.load(golden_dir / "unet_small.npz")
+    ref = {str(n): ast.literal_eval(str(s)) for n, s in zip(g["names"], g["shapes"])}
+    mine = UNetSpatioTemporalConditionModel(**UW.SMALL_CONFIG).parameter_shapes()
+    assert set(mine) == set(ref)
+    for k in ref:
+        assert tuple(mine[k]) == tuple(ref[k]), k
+
+
+def test_default_config_is_svd_xt_sized():
+    from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel
+    m = UNetSpatioTemporalConditionModel()
+    assert m.num_parameters() == 1_524_623_082      # SURVEY.md §2.2 / BASELINE.md §2
+    with pytest.raises(ValueError):
+        UNetSpatioTemporalConditionModel(down_block_types=("DownBlockSpatioTemporal",) * 3)
+    with pytest.raises(Exception):
+        m.forward(torch.zeros(1, 2, 8, 8, 8), 1.0, torch.zeros(1, 1, 1024), torch.zeros(1, 3))   # weights not loaded
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,B,F,h,w", [("b2f5", 2, 5, 16, 24), ("b1f14", 1, 14, 8, 16)])
+def test_forward_matches_reference_golden(tag, B, F, h, w, gpu, golden_dir):
+    """fp16 HIP forward vs the reference's fp32 CPU forward on identical (fp16-representable) weights.
+    Tolerance: fp16 activations through ~60 layers -> 2e-2 of the output scale."""
+    from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel
+    g = np.load(golden_dir / "unet_small.npz")
+    model = UNetSpatioTemporalConditionModel(**UW.SMALL_CONFIG)
+    model.load_state_dict(UW.make_state_dict(model.parameter_shapes()), gpu)
+    sample, t, ehs, added = UW.make_inputs(B, F, h, w, seed=F)
+    y = model(sample.half().to(gpu), t, ehs.half().to(gpu), added.to(gpu))[0]
+    assert y.shape == (B, F, 4, h, w) and y.dtype == torch.float16
+    ref = torch.from_numpy(g[f"{tag}_out"])
+    err = (y.float().cpu() - ref).abs()
+    scale = ref.abs().max().item()
+    assert err.max().item() < 3e-2 * scale, (err.max().item(), scale)
+    assert err.mean().item() < 3e-3 * scale, (err.mean().item(), scale)
+
+
+@pytest.mark.gpu
+def test_forward_is_deterministic_and_batch_independent(gpu):
+    """Size-independent properties: same input -> bit-identical output; CFG batch items do not interact."""
+    from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel
+    model = UNetSpatioTemporalConditionModel(**UW.SMALL_CONFIG)
+    model.load_state_dict(UW.make_state_dict(model.parameter_shapes()), gpu)
+    sample, t, ehs, added = UW.make_inputs(2, 5, 16, 24, seed=3)
+    s, e, a = sample.half().to(gpu), ehs.half().to(gpu), added.to(gpu)
+    y1 = model(s, t, e, a)[0]
+    y2 = model(s, t, e, a)[0]
+    assert torch.equal(y1, y2)
+    y_single = model(s[1:], t, e[1:], a[1:])[0]
+    assert torch.allclose(y_single.float(), y1[1:].float(), atol=2e-3, rtol=1e-2)
