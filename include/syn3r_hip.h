@@ -248,6 +248,8 @@ int syn3r_sort_pairs(unsigned long long* keys, unsigned* vals, unsigned long lon
  * nn.Linear / 1x1 convolutions (attention_processor.py:187-202, resnet.py:316,
  * transformer_temporal.py:236,273) with the adds that follow them fused.
  * W is the nn.Linear weight as stored ([out_features, in_features]).
+ * rows_per_vec < 0 selects rowvec[m mod |rows_per_vec|] instead (the batch-interleaved context of
+ * the temporal cross-attention, transformer_temporal.py:310-317).
  * K % 64 == 0; strides in elements, multiples of 8; pointers 16-byte aligned;
  * bias / rowvec / residual / aux may be NULL.
  */

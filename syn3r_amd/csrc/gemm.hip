@@ -226,7 +226,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_gemm(GemmParams p) {
                 float v = acc[i][j][r] + bv;
                 if (p.rowvec) {
                     int m = gm0 + row;
-                    if (m < p.M && n < p.N) v += __half2float(p.rowvec[(long long)(m / p.rows_per_vec) * p.ldrv + n]);
+                    // rows_per_vec > 0: one vector per block of rows; < 0: vector index = m mod |rows_per_vec|
+                    if (m < p.M && n < p.N) {
+                        int vi = p.rows_per_vec > 0 ? m / p.rows_per_vec : m % (-p.rows_per_vec);
+                        v += __half2float(p.rowvec[(long long)vi * p.ldrv + n]);
+                    }
                 }
                 st[row * EPI_LD + col] = __float2half_rn(v * p.s_acc);
             }
@@ -291,7 +295,7 @@ int check_common(const GemmParams& p, const char* who) {
     SYN3R_REQUIRE(p.ldc % 8 == 0 && p.ldc >= p.N, "%s: ldc=%lld must be >= N and a multiple of 8", who, p.ldc);
     SYN3R_REQUIRE(!p.residual || (p.ldr % 8 == 0 && p.ldr >= p.N), "%s: bad residual stride", who);
     SYN3R_REQUIRE(!p.aux || (p.ldaux % 8 == 0 && p.ldaux >= p.N), "%s: bad aux stride", who);
-    SYN3R_REQUIRE(!p.rowvec || (p.rows_per_vec > 0 && p.ldrv >= p.N), "%s: bad rowvec arguments", who);
+    SYN3R_REQUIRE(!p.rowvec || (p.rows_per_vec != 0 && p.ldrv >= p.N), "%s: bad rowvec arguments", who);
     SYN3R_REQUIRE(((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out | (uintptr_t)p.residual | (uintptr_t)p.aux) % 16 == 0,
                   "%s: operands must be 16-byte aligned", who);
     return SYN3R_OK;

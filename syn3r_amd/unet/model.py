@@ -364,8 +364,13 @@ class UNetSpatioTemporalConditionModel:
         tt = self._ff(t + ".ff_in", nin, residual=hmix)
         n1 = ops.layernorm(tt, W(t + ".norm1.weight"), W(t + ".norm1.bias"))
         a1 = ops.attention_temporal(ops.linear(n1, W(t + ".attn1.qkv")), B, F, HW, heads)
+        # The reference lays the first-frame context out pixel-major / batch-minor
+        # (transformer_temporal.py:310-317) while the temporal tokens are batch-major (attention.py:487-489):
+        # token (b, pixel) reads the context of batch item (b*HW + pixel) mod B.  Reproduced, not fixed.
+        if HW % B:
+            raise NotImplementedError("temporal cross-attention context interleave needs h*w divisible by the batch size")
         tt = ops.linear(a1, W(t + ".attn1.to_out.0.weight"), W(t + ".attn1.to_out.0.bias"), residual=tt,
-                        rowvec=self._cross_vec(t + ".attn2", ehs), rows_per_vec=F * HW)
+                        rowvec=self._cross_vec(t + ".attn2", ehs), rows_per_vec=-B)
         n3 = ops.layernorm(tt, W(t + ".norm3.weight"), W(t + ".norm3.bias"))
         a, om = self._blend_scales(pre + ".time_mixer.mix_factor")
         # alpha*hs + (1-alpha)*(ff + tt)
