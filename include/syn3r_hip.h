@@ -298,7 +298,7 @@ int syn3r_attention_temporal_f16(const void* q, const void* k, const void* v, lo
  * rows x C/32).  2D norms: samples = B*F, rows = h*w; the 3D norms of TemporalResnetBlock
  * (resnet.py:574,588): samples = B, rows = F*h*w.
  */
-size_t syn3r_groupnorm_workspace_bytes(int samples);
+size_t syn3r_groupnorm_workspace_bytes(int samples, int rows);
 int syn3r_groupnorm_f16(const void* x, void* y, int samples, int rows, int C, const void* gamma, const void* beta,
                         float eps, int silu, void* workspace, size_t workspace_bytes, void* stream);
 

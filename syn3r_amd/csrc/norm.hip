@@ -54,9 +54,10 @@ __global__ void k_gn_stats(const __half* __restrict__ x, int R, int C, int rows_
                 gq += o[8 + e];
             }
         }
-        float* dst = stats + ((size_t)sample * 32 + g) * 2;
-        unsafeAtomicAdd(dst, gs);
-        unsafeAtomicAdd(dst + 1, gq);
+        // per-chunk partial (summed in a fixed order by k_gn_apply: bitwise reproducible, no atomics)
+        float* dst = stats + (((size_t)sample * gridDim.x + blockIdx.x) * 32 + g) * 2;
+        dst[0] = gs;
+        dst[1] = gq;
     }
 }
 
@@ -77,9 +78,14 @@ __global__ void k_gn_apply(const __half* __restrict__ x, __half* __restrict__ y,
     for (int e = 0; e < 8; ++e) {
         int c = cv * 8 + e;
         int g = c / cpg;
-        const float* st = stats + ((size_t)sample * 32 + g) * 2;
-        float mean = st[0] * inv_n;
-        float var = fmaxf(st[1] * inv_n - mean * mean, 0.0f);
+        float s1 = 0.f, s2 = 0.f;
+        for (int ch = 0; ch < (int)gridDim.x; ++ch) {
+            const float* st = stats + (((size_t)sample * gridDim.x + ch) * 32 + g) * 2;
+            s1 += st[0];
+            s2 += st[1];
+        }
+        float mean = s1 * inv_n;
+        float var = fmaxf(s2 * inv_n - mean * mean, 0.0f);
         float rstd = rsqrtf(var + eps);
         float ga = (float)((const _Float16*)gamma)[c], be = (float)((const _Float16*)beta)[c];
         a[e] = rstd * ga;
@@ -184,7 +190,22 @@ int gn_threads(int C) {
 
 }  // namespace
 
-extern "C" size_t syn3r_groupnorm_workspace_bytes(int samples) { return samples > 0 ? (size_t)samples * 32 * 2 * 4 : 0; }
+namespace {
+// launch geometry shared by the workspace query and the launcher: ~2048 blocks in total
+void gn_geometry(int samples, int rows, int& chunks, int& rows_per_block) {
+    chunks = (2048 + samples - 1) / samples;
+    rows_per_block = (rows + chunks - 1) / chunks;
+    if (rows_per_block < 8) rows_per_block = 8;
+    chunks = (rows + rows_per_block - 1) / rows_per_block;
+}
+}  // namespace
+
+extern "C" size_t syn3r_groupnorm_workspace_bytes(int samples, int rows) {
+    if (samples <= 0 || rows <= 0) return 0;
+    int chunks, rpb;
+    gn_geometry(samples, rows, chunks, rpb);
+    return (size_t)samples * chunks * 32 * 2 * sizeof(float);
+}
 
 extern "C" int syn3r_groupnorm_f16(const void* x, void* y, int samples, int rows, int C, const void* gamma,
                                    const void* beta, float eps, int silu, void* workspace, size_t workspace_bytes,
@@ -194,19 +215,14 @@ extern "C" int syn3r_groupnorm_f16(const void* x, void* y, int samples, int rows
                   samples, rows, C);
     int threads = gn_threads(C);
     SYN3R_REQUIRE(threads > 0, "groupnorm: C=%d too large", C);
-    size_t need = syn3r_groupnorm_workspace_bytes(samples);
+    size_t need = syn3r_groupnorm_workspace_bytes(samples, rows);
     if (!workspace || workspace_bytes < need) {
         set_error("groupnorm: workspace %zu < %zu", workspace_bytes, need);
         return SYN3R_E_WORKSPACE;
     }
     hipStream_t stream = (hipStream_t)stream_;
-    int rc = check_hip(hipMemsetAsync(workspace, 0, need, stream), "memset");
-    if (rc) return rc;
-    // enough blocks to fill the chip: ~2048 in total
-    int chunks = (2048 + samples - 1) / samples;
-    int rows_per_block = (rows + chunks - 1) / chunks;
-    if (rows_per_block < 8) rows_per_block = 8;
-    chunks = (rows + rows_per_block - 1) / rows_per_block;
+    int chunks, rows_per_block;
+    gn_geometry(samples, rows, chunks, rows_per_block);
     dim3 grid(chunks, samples);
     size_t lds = (size_t)threads * 16 * sizeof(float);
     SYN3R_LAUNCH(k_gn_stats, grid, dim3(threads), lds, stream, (const __half*)x, rows, C, rows_per_block,

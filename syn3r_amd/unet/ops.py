@@ -138,7 +138,7 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, samples:
         raise ValueError("groupnorm: rows not divisible by samples")
     y = torch.empty_like(x)
     lib = L.load()
-    ws = L.workspace(dev, lib.syn3r_groupnorm_workspace_bytes(samples), "gn")
+    ws = L.workspace(dev, lib.syn3r_groupnorm_workspace_bytes(samples, M // samples), "gn")
     rc = lib.syn3r_groupnorm_f16(L.ptr(x), L.ptr(y), samples, M // samples, C, L.ptr(gamma), L.ptr(beta), float(eps),
                                  1 if silu else 0, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
     L.check(rc, "syn3r_groupnorm_f16")
