@@ -175,6 +175,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    log("setup done; warmup")
     for _ in range(args.warmup):
         step()
     if loop_b is not None:
@@ -186,6 +191,7 @@ def main():
             step()
         barrier()
         dt = time.perf_counter() - t0
+    log(f"timed region done: {dt:.3f} s")
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -249,6 +255,7 @@ def main():
             "per_rank": [[round(float(x), 3) for x in r.tolist()] for r in allrec],
         }
         if not args.no_cpu_baseline:
+            log("cpu baseline (oracle on the host cores, bounded sample) ...")
             out["cpu_baseline"] = cpu_baseline_raster(args)
         print(json.dumps(out))
     if dist is not None:

@@ -149,10 +149,93 @@ def gen_unet():
     np.savez_compressed(GOLD / "unet_small.npz", **out)
 
 
+def gen_pipeline():
+    """Run the REFERENCE pipeline classes' own __call__ (both variants) on the CPU with mock CLIP / VAE /
+    UNet (oracle/pipeline_mocks.py), 3 denoise steps, output_type='latent'."""
+    import diffusers.utils.torch_utils as tu_
+    from diffusers import EulerDiscreteScheduler
+    from diffusers.image_processor import VaeImageProcessor
+    from oracle import pipeline_mocks as PM
+    import model.SVD_2pass_prob_uncertain as P2
+    import model.SVD_2pass_prob_uncertain_post as P1
+
+    inp = PM.pipeline_inputs(seed=0)
+
+    def make(cls):
+        class Pipe(cls):
+            def __init__(self):           # skip DiffusionPipeline.register_modules: plain attributes suffice
+                self.vae, self.image_encoder, self.unet = PM.MockVAE(), PM.MockImageEncoder(), PM.MockUNet()
+                self.scheduler = EulerDiscreteScheduler(**GI.SCHED_CONFIG)
+                self.feature_extractor = None
+                self.vae_scale_factor = 8
+                self.image_processor = VaeImageProcessor(vae_scale_factor=8)
+
+            @property
+            def _execution_device(self):
+                return torch.device("cpu")
+
+            def check_inputs(self, *a, **k):
+                return None
+
+            def maybe_free_model_hooks(self):
+                return None
+        return Pipe()
+
+    out = {}
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self           # `mask = mask.cuda()` (…post.py:557)
+    for tag, mod in (("post", P1), ("replace", P2)):
+        # both pipelines draw ONE augmentation noise with randn_tensor (…post.py:583): inject the fixture's
+        orig = mod.randn_tensor
+        mod.randn_tensor = lambda shape, **k: inp["noise"].clone() if tuple(shape) == tuple(inp["noise"].shape) else orig(shape, **k)
+        try:
+            pipe = make(mod.StableVideoDiffusionPipeline)
+            with torch.no_grad():
+                res = pipe(inp["image"], temp_cond=inp["temp_cond"], mask=inp["mask"].clone(), lambda_ts=inp["lambda_ts"],
+                           num_frames=25, decode_chunk_size=8, num_inference_steps=3, latent_num=1,
+                           latents=inp["latents"].clone(), output_type="latent")
+        finally:
+            mod.randn_tensor = orig
+        lat = res.frames
+        out[tag] = lat.float().numpy()[..., ::3, ::3]
+        print("pipeline", tag, lat.shape, lat.dtype, float(lat.abs().mean()))
+    torch.Tensor.cuda = orig_cuda
+    np.savez_compressed(GOLD / "pipeline_mock.npz", **out)
+
+
+def gen_orchestrator():
+    """Pure-numpy methods of the reference's DiffusionGS (model/diffusionGS.py:1120-1296).  The module
+    imports packages that are absent here (FSGS submodule, cv2, open3d, trimesh); they are not touched by
+    these methods, so empty placeholder modules satisfy the import statements."""
+    import types
+    for name in ("cv2", "trimesh", "open3d", "FSGS", "FSGS.utils", "FSGS.utils.trainer", "FSGS.scene", "FSGS.scene.cameras"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["FSGS.utils.trainer"].init_GSTrainer = None
+    sys.modules["FSGS.utils.trainer"].GSTrainer = object
+    sys.modules["FSGS.scene.cameras"].Camera = object
+    from model.diffusionGS import DiffusionGS
+    out = {}
+    for k, (a, b) in enumerate(GI.orch_pose_pairs()):
+        poses = DiffusionGS.pose_interpolation(None, a, b)
+        out[f"poses{k}"] = poses
+        d, idx = DiffusionGS.compute_dists(None, poses)
+        out[f"dists{k}"] = d
+        out[f"idx{k}"] = np.int64(idx)
+    for k, m in enumerate(GI.orch_masks()):
+        out[f"lambda{k}"] = DiffusionGS.search_hypers_v2(None, torch.from_numpy(m), "/tmp").numpy()
+    np.savez_compressed(GOLD / "orchestrator.npz", **out)
+    print("orchestrator", {k: getattr(v, "shape", ()) for k, v in out.items()})
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     Sch, consistency, forward_warp, inverse_warp = _import_reference()
-    which = sys.argv[1:] or ["warp", "sched", "unet"]
+    which = sys.argv[1:] or ["warp", "sched", "unet", "pipeline", "orch"]
+    if "pipeline" in which:
+        gen_pipeline()
+    if "orch" in which:
+        gen_orchestrator()
     if "unet" in which:
         gen_unet()
     if "warp" in which:

@@ -108,3 +108,24 @@ def karras_sigmas(n, sigma_min=0.002, sigma_max=700.0, rho=7.0):
     lo, hi = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
     s = (hi + ramp * (lo - hi)) ** rho
     return np.concatenate([s.astype(f32), np.zeros(1, f32)])
+
+
+def orch_pose_pairs():
+    """Two (start, end) w2c pose pairs for pose_interpolation / compute_dists."""
+    out = []
+    for seed, (yaw, pitch, t) in enumerate([(12.0, -3.0, (0.4, 0.05, -0.1)), (-35.0, 8.0, (-0.7, 0.2, 0.3))]):
+        a = (_rot_x(2.0 * seed) @ np.eye(4))
+        a[:3, 3] = [0.1 * seed, -0.05, 0.02]
+        b = _rot_y(yaw) @ _rot_x(pitch) @ a
+        b[:3, 3] = np.array(t)
+        out.append((a.astype(np.float32), b.astype(np.float32)))
+    return out
+
+
+def orch_masks():
+    """Uncertainty masks [23,72,128] for search_hypers_v2: low, high and ramped uncertainty."""
+    rng = np.random.default_rng(21)
+    lo = (0.2 * rng.random((23, 72, 128))).astype(f32)
+    hi = (0.5 + 0.5 * rng.random((23, 72, 128))).astype(f32)
+    ramp = (rng.random((23, 72, 128)) * np.sin(np.linspace(0.1, np.pi - 0.1, 23))[:, None, None]).astype(f32)
+    return [lo, hi, ramp]

@@ -120,21 +120,23 @@ def build_tile_lists(pre):
     x0, y0, x1, y1 = [v.numpy() for v in pre["rect"]]
     valid = pre["valid"].numpy()
     dbits = pre["depth"].detach().to(torch.float32).numpy().view(np.uint32).astype(np.uint64)
-    keys, vals = [], []
-    for i in np.nonzero(valid)[0]:
-        for y in range(y0[i], y1[i]):
-            for x in range(x0[i], x1[i]):
-                keys.append((np.uint64(y * gx + x) << np.uint64(32)) | dbits[i])
-                vals.append(i)
-    keys = np.array(keys, dtype=np.uint64)
-    vals = np.array(vals, dtype=np.int64)
+    ids = np.nonzero(valid)[0]
+    wd = (x1 - x0)[ids].astype(np.int64)
+    area = wd * (y1 - y0)[ids].astype(np.int64)
+    total = int(area.sum())
+    rep = np.repeat(np.arange(len(ids)), area)                      # duplication order = Gaussian index order
+    start = np.repeat(np.cumsum(area) - area, area)
+    off = np.arange(total, dtype=np.int64) - start                  # row-major inside the tile rectangle
+    ty = y0[ids][rep] + off // wd[rep]
+    tx = x0[ids][rep] + off % wd[rep]
+    keys = ((ty * gx + tx).astype(np.uint64) << np.uint64(32)) | dbits[ids][rep]
+    vals = ids[rep].astype(np.int64)
     order = np.argsort(keys, kind="stable")
     keys, vals = keys[order], vals[order]
-    ranges = np.zeros((gx * gy, 2), dtype=np.int64)
     tiles = (keys >> np.uint64(32)).astype(np.int64)
-    for tid in np.unique(tiles):
-        idx = np.nonzero(tiles == tid)[0]
-        ranges[tid] = (idx[0], idx[-1] + 1)
+    tid = np.arange(gx * gy)
+    ranges = np.stack([np.searchsorted(tiles, tid, "left"), np.searchsorted(tiles, tid, "right")], 1).astype(np.int64)
+    ranges[ranges[:, 0] == ranges[:, 1]] = 0
     return keys, vals, ranges
 
 

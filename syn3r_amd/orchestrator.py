@@ -1,0 +1,151 @@
+"""Host-side numerics of the reference orchestrator `model/diffusionGS.py` that sit between the hot
+kernels: pose interpolation, warp-mask pooling, uncertainty
+fusion and the lambda schedule that feed `svd_render`.  Host code stays Python (north_star); the
+per-pixel warps underneath run on the HIP path (`syn3r_amd.solver_utils`).
+
+The reference class itself needs FSGS / cv2 / open3d / trimesh (absent); these functions keep its
+method names and argument meaning so that `DiffusionGS` can call them one for one.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+from scipy.interpolate import CubicSpline
+from scipy.optimize import minimize_scalar
+from scipy.spatial.transform import Rotation as R
+from scipy.spatial.transform import Slerp
+
+from .solver_utils.forward_warp import inverse_warp
+
+
+def pose_interpolation(pose_start: np.ndarray, pose_end: np.ndarray, num: int = 25) -> np.ndarray:
+    """diffusionGS.py:1208-1234 — SLERP rotations + natural cubic spline (2 knots => linear) translations,
+    `num` float32 w2c poses."""
+    times = np.array([0, num - 1])
+    interp_times = np.linspace(0, num - 1, num)
+    rotations = R.from_matrix([pose[:3, :3] for pose in [pose_start, pose_end]])
+    interpolated_rotations = Slerp(times, rotations)(interp_times)
+    translations = np.vstack([pose[:3, 3] for pose in [pose_start, pose_end]])
+    interpolated_translations = CubicSpline(times, translations, bc_type="natural")(interp_times)
+    return np.array([
+        np.vstack([np.hstack([interpolated_rotations[i].as_matrix(), interpolated_translations[i][:, np.newaxis]]),
+                   [0, 0, 0, 1]]) for i in range(len(interp_times))]).astype(np.float32)
+
+
+def compute_dists(interpolated_poses: np.ndarray, type: str = "double_end"):
+    """diffusionGS.py:1237-1296 — normalised distance of every pose to its nearer end pose."""
+    assert type in ["double_end", "single_end"]
+    points = np.array([pp[:3, 3].reshape(1, 3) for pp in interpolated_poses])
+
+    def total_distance(index):
+        index = int(index)
+        if index <= 0 or index >= len(points) - 1:
+            return float("inf")
+        left, right = points[:index], points[index:]
+        return np.sum(np.linalg.norm(left - left[0], axis=1)) + np.sum(np.linalg.norm(right - right[-1], axis=1))
+
+    result = minimize_scalar(total_distance, bounds=(1, len(points) - 2), method="bounded")
+    min_indice = int(result.x)
+    if type == "single_end":
+        min_indice = len(interpolated_poses) + 10000
+    pt1, pt2 = interpolated_poses[0], interpolated_poses[-1]
+    diff = np.array([pp[:3, 3] - (pt1 if ii < min_indice else pt2)[:3, 3] for ii, pp in enumerate(interpolated_poses)])
+    dists = np.linalg.norm(diff, axis=1)
+    return dists / np.max(dists), min_indice
+
+
+def block_mean_pool(x: np.ndarray, h: int = 72, w: int = 128) -> np.ndarray:
+    """The `(72,8,128,8)` reshape/mean idiom (diffusionGS.py:853-855,1481-1483): (h*8, w*8) -> (h, w)."""
+    fy, fx = x.shape[0] // h, x.shape[1] // w
+    return x.reshape(h, fy, w, fx).transpose(0, 2, 1, 3).reshape(h, w, fy * fx).mean(axis=2)
+
+
+def dilate5x5(mask: np.ndarray) -> np.ndarray:
+    """cv2.dilate(mask, ones((5,5)), iterations=1) (diffusionGS.py:1457-1458): 5x5 max filter, border
+    pixels see only the in-image part of the window (OpenCV's default border value for dilation)."""
+    t = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.float32))
+    squeeze = t.dim() == 2
+    t = t[None, None] if squeeze else t.permute(2, 0, 1)[None]
+    out = torch.nn.functional.max_pool2d(torch.nn.functional.pad(t, (2, 2, 2, 2), value=float("-inf")), 5, stride=1)
+    return (out[0, 0] if squeeze else out[0].permute(1, 2, 0)).numpy().astype(mask.dtype)
+
+
+def search_hypers_v2(masks: torch.Tensor, save_path=None, type: str = "double_end", diffusion_steps: int = 100) -> torch.Tensor:
+    """diffusionGS.py:1120-1205 — per-frame mean uncertainty -> lambda_ts [steps, F] float64 of {0,1}:
+    frame tau follows the warped view while `steps - t > (a u^2 + b u + c) * 100`."""
+    assert type in ["double_end", "single_end"]
+
+    def quad_tau_func(u, a=-0.22 / 1.4, b=2.4 * 0.22 / 1.4, c=0.2):
+        return (a * u ** 2 + b * u + c) * 100
+
+    m = torch.mean(masks, dim=(-1, -2))
+    m = torch.clamp(m / (torch.maximum(m.max(), torch.full_like(m.max(), 0.5))), 0, 1)
+    if type == "double_end":
+        m = torch.cat([torch.zeros_like(m[0:1]), m, torch.zeros_like(m[:1])], dim=0)
+        index_list = list(range(1, m.shape[0] - 1))
+    else:
+        m = torch.cat([torch.zeros_like(m[0:1]), m], dim=0)
+        index_list = list(range(1, m.shape[0]))
+    F = m.shape[0]
+    lam = np.ones((diffusion_steps, F), dtype=np.float64)
+    for t in range(diffusion_steps):
+        for tau in index_list:
+            lam[t, tau] = 1.0 if diffusion_steps - t > quad_tau_func(m[tau]) else 0.0
+    return torch.tensor(lam)
+
+
+def fuse_uncertainty(cond_images_ori: np.ndarray, gs_images: np.ndarray, soft_masks_reproj_ori: np.ndarray,
+                     h: int = 72, w: int = 128):
+    """diffusionGS.py:821-862 — intensity confidence exp(-(|warp - gs|_2 / 0.5)^3) * (warp != 0), combined
+    with the reprojection confidence; returns (masks [n,h,w] float32 tensor, cond_image [n,H,W,3], uncertainty)."""
+    unc_mask = 1 - (cond_images_ori.sum(axis=-1, keepdims=True) > 0)
+    intensity_conf = np.exp(-((np.linalg.norm(cond_images_ori - gs_images, axis=-1, keepdims=True)) / 0.5) ** 3) * (1 - unc_mask)
+    geo_inten_uncertainty = 1 - intensity_conf * (1 - soft_masks_reproj_ori[..., None])
+    masks = np.stack([block_mean_pool(np.mean(u, axis=-1), h, w) for u in geo_inten_uncertainty])
+    cond_image = np.where(geo_inten_uncertainty > 0.5, gs_images, cond_images_ori)
+    cond_image = [np.clip(im, 0, 1) for im in cond_image]
+    return torch.from_numpy(masks).float(), cond_image, geo_inten_uncertainty
+
+
+def warp_images_bw(intrinsics: np.ndarray, interpolated_poses: Sequence[np.ndarray], image_l: np.ndarray,
+                   image_r: np.ndarray, depth_l: np.ndarray, depth_r: np.ndarray,
+                   render_depth: Callable[[np.ndarray], np.ndarray], device="cuda:0", h: int = 72, w: int = 128):
+    """diffusionGS.py:1367-1510 without the PNG round trips: for every interior pose render the pseudo-view
+    depth (`render_depth(pose) -> (H,W)` = the reference's `render_GS`), inverse-warp the nearer end view into
+    it on the GPU (bandwidth 20) and derive the hard mask (5x5 dilate, 8x8 pool, threshold 0.2) and the soft
+    reprojection uncertainty.  Images are (H,W,3) in [0,255], already at the diffusion resolution."""
+    dev = torch.device(device)
+    n = len(interpolated_poses) - 1
+    interp_num = n - 1
+    K = torch.tensor(intrinsics, device=dev, dtype=torch.float32)
+    src = {side: (torch.tensor(img, device=dev, dtype=torch.float32).permute(2, 0, 1).contiguous(),
+                  torch.tensor(dep[None], device=dev, dtype=torch.float32))
+           for side, img, dep in (("l", image_l, depth_l), ("r", image_r, depth_r))}
+    masks, cond_image, masks_ero, soft_pool, soft_ori, cond_ori = [], [], [], [], [], []
+    for i in range(interp_num):
+        side = "l" if i < 12 else "r"                                   # :1411-1420
+        pose_s = interpolated_poses[0] if side == "l" else interpolated_poses[-1]
+        pose_t = interpolated_poses[i + 1]
+        depth_t = render_depth(pose_t)
+        wd = inverse_warp(src[side][0], src[side][1], torch.tensor(depth_t[None], device=dev, dtype=torch.float32),
+                          torch.tensor(pose_s, device=dev, dtype=torch.float32),
+                          torch.tensor(pose_t, device=dev, dtype=torch.float32), K)
+        mask2 = wd["mask_reproj"].cpu().numpy()
+        warped = wd["warped_img"].cpu().numpy().transpose([1, 2, 0])
+        mask = (1 - mask2 >= 0.5).astype(np.float64)
+        mask = np.repeat(mask[:, :, None] * 255.0, 3, axis=2)
+        ero = np.uint8(dilate5x5(mask)) / 255.0
+        ero = (ero >= 0.5).astype(np.float64)
+        masks_ero.append(ero)
+        cond_ori.append(warped / 255.0)
+        cond_image.append(np.asarray(np.uint8(warped * (1 - ero)), dtype=np.float32) / 255.0)   # uint8 round trip (:1469,1475)
+        pooled = block_mean_pool(np.mean(ero, axis=-1), h, w)
+        masks.append(torch.from_numpy((pooled >= 0.2).astype(np.float64)).unsqueeze(0))
+        soft = 1 - wd["soft_mask_reproj"].cpu().numpy()
+        soft_ori.append(soft)
+        soft_pool.append(torch.from_numpy(block_mean_pool(soft, h, w)).unsqueeze(0))
+    aux = dict(masks_ero=np.stack(masks_ero).astype(np.uint8), soft_masks_reproj=torch.cat(soft_pool).to(torch.float32),
+               soft_masks_reproj_ori=np.stack(soft_ori).astype(np.float32), cond_images_ori=cond_ori)
+    return image_l / 255.0, image_r / 255.0, torch.cat(masks), cond_image, aux

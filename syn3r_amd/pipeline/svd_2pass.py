@@ -1,0 +1,279 @@
+"""Two-pass Stable-Video-Diffusion completion pipelines on the HIP path.
+
+Mirrors of the reference's
+  model/SVD_2pass_prob_uncertain.py       ("Replace": soft replacement of x0, :661-742)
+  model/SVD_2pass_prob_uncertain_post.py  ("Post": tile-wise guidance gradient + plain Euler, :671-831)
+with the same class name, `__call__` signature and output object.  The denoising loop — the hot
+path — runs on the HIP UNet (`syn3r_amd.unet.model`) and the fused scheduler steps
+(`syn3r_amd.schedulers`).  The CLIP image encoder and the temporal VAE are OUT OF SCOPE rows
+(SURVEY.md §2, N1): the pipeline takes them as objects with the reference's interface
+(`image_encoder(x).image_embeds`, `vae.encode(x).latent_dist.mode()`, `vae.decode(z, num_frames=…)`)
+and calls them exactly where the reference does.
+
+Differences from the reference that do not change results:
+  * the "Post" gradient pass does not run autograd through the UNet: the UNet input is detached
+    (…post.py:732), so the gradient is the closed form implemented by `syn3r_step_interp`
+     — saves ≈96 TFLOP per (step, pass);
+  * `one_pass=True` runs the forward-in-time pass only (BASELINE.json configs[1] "SVD_1pass");
+  * `num_frames` is a parameter (the reference asserts 25, …post.py:531).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Union
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+
+@dataclass
+class StableVideoDiffusionPipelineOutput:
+    frames: object
+
+
+def _append_dims(x, target_dims):
+    return x[(...,) + (None,) * (target_dims - x.ndim)]
+
+
+def preprocess_images(images, height: int, width: int) -> torch.Tensor:
+    """VaeImageProcessor.preprocess for the inputs SYN3R passes (PIL / HWC uint8-or-float numpy /
+    CHW float tensors in [0,1]): resize if needed, scale to [-1, 1], NCHW float32."""
+    if not isinstance(images, (list, tuple)):
+        images = [images]
+    out = []
+    for im in images:
+        if isinstance(im, torch.Tensor):
+            t = im.float()
+            if t.dim() == 3:
+                t = t[None]
+        elif isinstance(im, np.ndarray):
+            a = im.astype(np.float32) / (255.0 if im.dtype == np.uint8 else 1.0)
+            t = torch.from_numpy(a).permute(2, 0, 1)[None]
+        else:  # PIL
+            if im.size != (width, height):
+                from PIL import Image
+                im = im.resize((width, height), resample=Image.LANCZOS)
+            t = torch.from_numpy(np.asarray(im.convert("RGB"), dtype=np.float32) / 255.0).permute(2, 0, 1)[None]
+        if t.shape[-2:] != (height, width):
+            t = torch.nn.functional.interpolate(t, size=(height, width), mode="bilinear", align_corners=False)
+        out.append(2.0 * t - 1.0)
+    return torch.cat(out, 0)
+
+
+# overlapping tiles of the 72x128 latent grid used by the Post variant (…post.py:739-758) and the
+# offsets at which their gradients are stitched back (:776-778)
+def post_tiles(h: int, w: int):
+    """Rows [:40] | [24:], columns [:72] | [56:] on the 72x128 grid, scaled for other grids
+    (5/9, 1/3 of the height; 9/16, 7/16 of the width).  Returns (tiles, overlap_y, overlap_x)."""
+    if h % 9 or w % 16:
+        raise ValueError(f"latent grid {h}x{w} must be divisible by 9x16 for the 4-tile guidance pass")
+    th, y1 = 5 * h // 9, h // 3
+    tw, x1 = 9 * w // 16, 7 * w // 16
+    tiles = [(slice(0, th), slice(0, tw)), (slice(y1, h), slice(0, tw)), (slice(0, th), slice(x1, w)),
+             (slice(y1, h), slice(x1, w))]
+    return tiles, th - y1, tw - x1
+
+
+class StableVideoDiffusionPipeline:
+    """`variant="replace"` ≙ model/SVD_2pass_prob_uncertain.py, `variant="post"` ≙ …_post.py."""
+
+    def __init__(self, vae, image_encoder, unet, scheduler, feature_extractor=None, variant: str = "post",
+                 device: Union[str, torch.device] = "cuda:0"):
+        if variant not in ("replace", "post"):
+            raise NotImplementedError(f"unknown variant {variant}")
+        self.vae, self.image_encoder, self.unet, self.scheduler = vae, image_encoder, unet, scheduler
+        self.feature_extractor = feature_extractor
+        self.variant = variant
+        self.device = torch.device(device)
+        self.vae_scale_factor = 8
+        self._guidance_scale = None
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    # ------------------------------------------------------------------ conditioning (out-of-scope modules, called as the reference does)
+    def _encode_image(self, image, do_cfg: bool) -> torch.Tensor:
+        """…post.py:229-273 with a caller-supplied CLIP: `image_encoder` must map the pipeline's
+        image (PIL / tensor) to `.image_embeds` [1, 1024] (the antialiased 224x224 resize and CLIP
+        normalisation live with that module)."""
+        emb = self.image_encoder(image).image_embeds.to(self.device)
+        emb = emb.unsqueeze(1)
+        if do_cfg:
+            emb = torch.cat([torch.zeros_like(emb), emb])
+        return emb
+
+    def _encode_vae_image(self, image: torch.Tensor, do_cfg: bool) -> torch.Tensor:
+        """…post.py:275-298"""
+        lat = self.vae.encode(image.to(self.device)).latent_dist.mode()
+        if do_cfg:
+            lat = torch.cat([torch.zeros_like(lat), lat])
+        return lat
+
+    def _get_add_time_ids(self, fps, motion_bucket_id, noise_aug_strength, dtype, do_cfg):
+        ids = torch.tensor([[fps, motion_bucket_id, noise_aug_strength]], dtype=dtype)
+        if do_cfg:
+            ids = torch.cat([ids, ids])
+        return ids
+
+    def decode_latents(self, latents, num_frames, decode_chunk_size=14):
+        """…post.py:326-353 (VAE decode, out-of-scope module)."""
+        latents = latents.flatten(0, 1)
+        latents = 1 / self.vae.config.scaling_factor * latents
+        frames = []
+        for i in range(0, latents.shape[0], decode_chunk_size):
+            n = latents[i:i + decode_chunk_size].shape[0]
+            frames.append(self.vae.decode(latents[i:i + decode_chunk_size], num_frames=n).sample)
+        frames = torch.cat(frames, dim=0)
+        frames = frames.reshape(-1, num_frames, *frames.shape[1:]).permute(0, 2, 1, 3, 4)
+        return frames.float()
+
+    # ------------------------------------------------------------------ the hot loop
+    def _unet(self, x, t, ehs, added):
+        return self.unet(x, t, encoder_hidden_states=ehs, added_time_ids=added, return_dict=False)[0]
+
+    def _pass_replace(self, i, t, latents, image_latents, ehs, added, cond, mask, lam, do_cfg):
+        """SVD_2pass_prob_uncertain.py:691-716"""
+        sch = self.scheduler
+        x = torch.cat([latents] * 2) if do_cfg else latents
+        x = sch.scale_model_input(x, t, step_i=i).to(latents.dtype)
+        x = torch.cat([x, image_latents], dim=2)
+        noise_pred = self._unet(x, t, ehs, added)
+        if do_cfg:
+            u, c = noise_pred.chunk(2)
+            noise_pred = u + self.guidance_scale * (c - u)
+        return sch.step_interp_prob_uncertain(noise_pred, t, latents, cond, mask, lam, step_i=i).prev_sample
+
+    def _pass_post(self, i, t, latents, image_latents, ehs, added, cond, mask, lam, do_cfg):
+        """…post.py:700-800"""
+        sch = self.scheduler
+        x = torch.cat([latents] * 2) if do_cfg else latents
+        x = sch.scale_model_input(x, t, step_i=i).to(latents.dtype)
+        x = torch.cat([x, image_latents], dim=2)
+        h, w = latents.shape[-2:]
+        tiles, ov_y, ov_x = post_tiles(h, w)
+        grads = []
+        for ys, xs in tiles:                                           # :726-774, B=1, no CFG
+            sl = (slice(0, 1), slice(None), slice(None), ys, xs)
+            noise_t = self._unet(x[sl].contiguous(), t, ehs[0:1], added[0:1])
+            out = sch.step_interp(noise_t, t, latents[sl].contiguous(), cond[(slice(0, 2),) + sl[1:]].contiguous(),
+                                  mask[sl].contiguous(), lam, step_i=i, lr=0.02, compute_grad=True)
+            grads.append(out.grad)
+        g1 = torch.cat((grads[0], grads[1][:, :, :, ov_y:, :]), -2)     # :776-778
+        g2 = torch.cat((grads[2], grads[3][:, :, :, ov_y:, :]), -2)
+        g3 = torch.cat((g1, g2[:, :, :, :, ov_x:]), -1)
+        next_latents = latents - g3.half()                              # :779
+        noise_pred = self._unet(x, t, ehs, added)                       # :786-792 (input built from the ORIGINAL latents)
+        if do_cfg:
+            u, c = noise_pred.chunk(2)
+            noise_pred = u + self.guidance_scale * (c - u)
+        return sch.step_interp(noise_pred, t, next_latents, cond, mask, lam, step_i=i, compute_grad=False).prev_sample
+
+    @torch.no_grad()
+    def denoise(self, latents, image_latent_start, image_latent_end, emb_start, emb_end, added_time_ids,
+                temp_cond_latents, mask, lambda_ts, num_inference_steps: int, min_guidance_scale=1.0,
+                max_guidance_scale=3.0, one_pass: bool = False, callback: Optional[Callable] = None):
+        """The denoising loop (…post.py:656-831 / SVD_2pass_prob_uncertain.py:649-748) on prepared
+        tensors.  latents [1,F,4,h,w]; image_latent_* [B,F,4,h,w]; emb_* [B,1,D]; temp_cond_latents
+        [2,F,4,h,w] fp32 (already divided by factor_s); mask [1,F-2,4,h,w]; lambda_ts [steps,F] f64."""
+        dev = self.device
+        F = latents.shape[1]
+        do_cfg = max_guidance_scale > 1.0
+        self.scheduler.set_timesteps(num_inference_steps, device=dev)
+        timesteps = self.scheduler.timesteps
+        gs = torch.linspace(min_guidance_scale, max_guidance_scale, F).unsqueeze(0).to(dev, latents.dtype)
+        self._guidance_scale = _append_dims(gs, latents.ndim)
+        weight_fw = torch.linspace(1, 0, F)[None, :, None, None, None].to(device=dev, dtype=latents.dtype)
+        step = self._pass_post if self.variant == "post" else self._pass_replace
+        mask = mask.to(dev)
+        lambda_ts = lambda_ts.to(dev)
+        cond_bw, mask_bw, lam_bw = temp_cond_latents.flip(dims=[1]), mask.flip(dims=[1]), lambda_ts.flip(dims=[1])
+        for i, t in enumerate(timesteps):
+            fw = step(i, t, latents, image_latent_start, emb_start, added_time_ids, temp_cond_latents, mask, lambda_ts,
+                      do_cfg)
+            if one_pass:
+                latents = fw
+            else:
+                bw = step(i, t, latents.flip(dims=[1]), image_latent_end, emb_end, added_time_ids, cond_bw, mask_bw,
+                          lam_bw, do_cfg)
+                latents = weight_fw * fw + (1 - weight_fw) * bw.flip(dims=[1])      # :828 / :736
+            if callback is not None:
+                callback(i, t, latents)
+        return latents
+
+    @torch.no_grad()
+    def __call__(self, image, temp_cond, mask, lambda_ts, height: int = 576, width: int = 1024,
+                 num_frames: Optional[int] = None, num_inference_steps: int = 25, min_guidance_scale: float = 1.0,
+                 max_guidance_scale: float = 3.0, fps: int = 7, motion_bucket_id: int = 127,
+                 noise_aug_strength: float = 0.02, decode_chunk_size: Optional[int] = None,
+                 num_videos_per_prompt: Optional[int] = 1, generator=None, latents: Optional[torch.Tensor] = None,
+                 output_type: Optional[str] = "pil", callback_on_step_end=None, return_dict: bool = True,
+                 latent_num: int = 1, one_pass: bool = False, dtype: torch.dtype = torch.float16,
+                 aug_noise: Optional[torch.Tensor] = None):
+        if callback_on_step_end is not None:
+            raise NotImplementedError
+        if latent_num != 1 or num_videos_per_prompt != 1:
+            raise NotImplementedError("latent_num / num_videos_per_prompt other than 1 are unused by SYN3R")
+        dev = self.device
+        num_frames = num_frames if num_frames is not None else 25
+        decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else num_frames
+        if not isinstance(image, (list, tuple)):
+            image = [image]
+        if len(temp_cond) != num_frames - 1:
+            raise ValueError(f"temp_cond must hold {num_frames - 1} images (warped views + the end view)")
+        do_cfg = max_guidance_scale > 1.0
+        emb_start = self._encode_image(image[0], do_cfg).to(dtype)            # :544
+        emb_end = self._encode_image(temp_cond[-1], do_cfg).to(dtype)         # :546
+        fps = fps - 1
+        img = preprocess_images(image, height, width).to(dev)
+        img_end = preprocess_images(temp_cond[-1:], height, width).to(dev)
+        mask = mask.to(dev).unsqueeze(1).unsqueeze(0).repeat(1, 1, 4, 1, 1)   # :557-558
+        tc = preprocess_images(list(temp_cond), height, width).to(dev)
+        if aug_noise is not None:          # extension: caller-supplied augmentation noise (…post.py:583 draws it)
+            noise = aug_noise.to(dev, img.dtype)
+        elif generator is not None:
+            noise = torch.randn(img.shape, generator=generator, dtype=img.dtype).to(dev)
+        else:
+            noise = torch.randn(img.shape, device=dev, dtype=img.dtype)
+
+        def to_latents(x, out_dtype):                                          # :568-580
+            x = x + noise_aug_strength * noise
+            return self._encode_vae_image(x, do_cfg).to(out_dtype).unsqueeze(1)
+
+        lat_start = to_latents(img[0:1], dtype)
+        lat_end = to_latents(img_end[0:1], dtype)
+        cond = torch.cat([to_latents(tc[k:k + 1], torch.float32) for k in range(tc.shape[0])], dim=1)
+        cond = torch.cat((lat_start.float(), cond), dim=1) / 5.6                # :601-610 (factor_s)
+        lat_start = lat_start.repeat(1, num_frames, 1, 1, 1)
+        lat_end = lat_end.repeat(1, num_frames, 1, 1, 1)
+        added = self._get_add_time_ids(fps, motion_bucket_id, noise_aug_strength, dtype, do_cfg).to(dev)
+        self.scheduler.set_timesteps(num_inference_steps, device=dev)
+        shape = (1, num_frames, 4, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if latents is None:
+            latents = torch.randn(shape, generator=generator, dtype=dtype).to(dev) if generator is not None else \
+                torch.randn(shape, device=dev, dtype=dtype)
+        latents = latents.to(dev, dtype) * self.scheduler.init_noise_sigma      # prepare_latents
+        latents = self.denoise(latents, lat_start, lat_end, emb_start, emb_end, added, cond, mask, lambda_ts,
+                               num_inference_steps, min_guidance_scale, max_guidance_scale, one_pass=one_pass)
+        if output_type == "latent":
+            frames = latents
+        else:
+            frames = self.decode_latents(latents.float(), num_frames, decode_chunk_size)
+            frames = tensor2vid(frames, output_type)
+        if not return_dict:
+            return frames
+        return StableVideoDiffusionPipelineOutput(frames=frames)
+
+
+def tensor2vid(video: torch.Tensor, output_type: str = "np"):
+    """[B,C,F,H,W] in [-1,1] -> per batch item a [F,H,W,C] array in [0,1] (or PIL list)."""
+    outs = []
+    for b in range(video.shape[0]):
+        v = ((video[b].permute(1, 2, 3, 0) / 2 + 0.5).clamp(0, 1)).cpu().numpy()
+        if output_type == "pil":
+            from PIL import Image
+            v = [Image.fromarray((f * 255).round().astype("uint8")) for f in v]
+        outs.append(v)
+    return outs

@@ -1,0 +1,51 @@
+"""Host-side orchestrator numerics vs the reference's own methods (golden from model/diffusionGS.py)."""
+import numpy as np
+import torch
+
+from oracle import golden_inputs as GI
+from syn3r_amd import orchestrator as O
+
+
+def test_pose_interpolation_and_dists_match_reference(golden_dir):
+    g = np.load(golden_dir / "orchestrator.npz")
+    for k, (a, b) in enumerate(GI.orch_pose_pairs()):
+        poses = O.pose_interpolation(a, b)
+        assert poses.shape == (25, 4, 4) and poses.dtype == np.float32
+        np.testing.assert_allclose(poses, g[f"poses{k}"], atol=1e-6)
+        np.testing.assert_allclose(poses[0], a, atol=1e-6)
+        np.testing.assert_allclose(poses[-1], b, atol=1e-6)
+        d, idx = O.compute_dists(poses)
+        assert idx == int(g[f"idx{k}"])
+        np.testing.assert_allclose(d, g[f"dists{k}"], atol=1e-6)
+
+
+def test_search_hypers_v2_matches_reference(golden_dir):
+    g = np.load(golden_dir / "orchestrator.npz")
+    for k, m in enumerate(GI.orch_masks()):
+        lam = O.search_hypers_v2(torch.from_numpy(m))
+        assert lam.dtype == torch.float64 and lam.shape == (100, 25)
+        np.testing.assert_array_equal(lam.numpy(), g[f"lambda{k}"])
+        assert (lam[:, 0] == 1).all() and (lam[:, -1] == 1).all()
+
+
+def test_mask_pooling_and_dilate():
+    rng = np.random.default_rng(0)
+    x = rng.random((576, 1024))
+    p = O.block_mean_pool(x)
+    assert p.shape == (72, 128)
+    np.testing.assert_allclose(p[3, 5], x[24:32, 40:48].mean())
+    m = np.zeros((20, 30)); m[10, 12] = 255.0; m[0, 0] = 255.0
+    d = O.dilate5x5(m)
+    assert d[8:13, 10:15].min() == 255.0 and d[7, 12] == 0 and d[2, 2] == 255.0 and d[3, 3] == 0
+
+
+def test_fuse_uncertainty_shapes_and_limits():
+    rng = np.random.default_rng(1)
+    warped = rng.random((23, 576, 1024, 3)).astype(np.float32)
+    warped[:, :50] = 0.0                                   # unwarped (black) band -> fully uncertain
+    gs = warped.copy()
+    soft = np.zeros((23, 576, 1024), np.float32)
+    masks, cond, unc = O.fuse_uncertainty(warped, gs, soft)
+    assert masks.shape == (23, 72, 128) and masks.dtype == torch.float32
+    assert float(masks[:, :6].min()) == 1.0 and float(masks[:, 8:].max()) < 1e-6
+    assert len(cond) == 23 and cond[0].shape == (576, 1024, 3)

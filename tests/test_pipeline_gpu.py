@@ -1,0 +1,58 @@
+"""SVD two-pass pipelines (P1 "Post", P2 "Replace"): the HIP pipeline's loop logic vs latents produced by the
+REFERENCE pipeline classes' own __call__ (run on the CPU with the mock CLIP / VAE / UNet of
+oracle/pipeline_mocks.py; tests/golden/pipeline_mock.npz).  The scheduler steps inside run on the HIP kernels."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline_mocks as PM
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pipe(variant, dev):
+    from syn3r_amd.pipeline.svd_2pass import StableVideoDiffusionPipeline
+    from syn3r_amd.schedulers.scheduling_euler_discrete import SVD_XT_SCHEDULER_CONFIG, EulerDiscreteScheduler
+    return StableVideoDiffusionPipeline(PM.MockVAE(), PM.MockImageEncoder(), PM.MockUNet().to(dev),
+                                        EulerDiscreteScheduler(**SVD_XT_SCHEDULER_CONFIG), variant=variant, device=dev)
+
+
+def run(variant, dev, **kw):
+    inp = PM.pipeline_inputs(seed=0)
+    pipe = make_pipe(variant, dev)
+    res = pipe([im.to(dev) for im in inp["image"]], temp_cond=[t.to(dev) for t in inp["temp_cond"]],
+               mask=inp["mask"].clone(), lambda_ts=inp["lambda_ts"], num_frames=25, decode_chunk_size=8,
+               num_inference_steps=3, latent_num=1, latents=inp["latents"].clone(), output_type="latent",
+               dtype=torch.float32, aug_noise=inp["noise"], **kw)
+    return res.frames
+
+
+@pytest.mark.parametrize("variant", ["post", "replace"])
+def test_pipeline_latents_match_reference(variant, gpu, golden_dir):
+    g = np.load(golden_dir / "pipeline_mock.npz")[variant]
+    lat = run(variant, gpu)
+    assert lat.shape == (1, 25, 4, 72, 128) and lat.dtype == torch.float32
+    a = lat.cpu().numpy()[..., ::3, ::3]
+    scale = np.abs(g).max()
+    # three denoise steps at sigma 700 -> ~1: selection ties with the quantile cut-off may flip single latents
+    bad = np.abs(a - g) > 2e-3 * scale
+    assert bad.mean() < 2e-3, (bad.mean(), np.abs(a - g).max(), scale)
+
+
+def test_one_pass_is_forward_only(gpu):
+    """BASELINE configs[1] "SVD_1pass": forward-in-time pass only == two-pass with the blend weight forced to 1."""
+    lat1 = run("replace", gpu, one_pass=True)
+    lat2 = run("replace", gpu)
+    assert lat1.shape == lat2.shape
+    # frame 0 has blend weight 1 for the forward pass in the two-pass run of the LAST step only; the runs differ elsewhere
+    assert not torch.allclose(lat1, lat2)
+    assert torch.isfinite(lat1).all()
+
+
+def test_pipeline_argument_errors(gpu):
+    pipe = make_pipe("post", gpu)
+    inp = PM.pipeline_inputs(seed=0)
+    with pytest.raises(ValueError):
+        pipe(inp["image"], temp_cond=inp["temp_cond"][:5], mask=inp["mask"], lambda_ts=inp["lambda_ts"], num_frames=25)
+    with pytest.raises(NotImplementedError):
+        make_pipe("1pass_prob", gpu)
