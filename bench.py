@@ -119,7 +119,9 @@ def cpu_baseline_raster(args):
     """Oracle (CPU restatement, kind='port') on a bounded sample: same 200k-Gaussian scene rendered
     fwd+bwd at 1/4 resolution per axis; pixel work is scaled by 16 to the full frame."""
     from oracle import raster_oracle as RO
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box exposes many host cores but grants ~16 to a 1-GPU job: oversubscribing them stalls for minutes
+    ncores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(ncores)
     N = args.gaussians
     H, W = args.height // 4, args.width // 4
     m, s, q, o, sh = RO.synthetic_gaussians(N, seed=args.seed)
