@@ -259,6 +259,16 @@ int syn3r_gemm_f16(const void* A, long long lda, const void* W, void* out, long 
                    void* stream);
 
 /*
+ * FeedForward's first projection fused with its GEGLU gate (attention.py:608-665, activations.py GEGLU):
+ * out[M,D] = h * gelu_erf(g) with [h | g] = A[M,K] . W[2D,K]^T + bias, h and g rounded to fp16 first as
+ * the reference's projection output is.  Wpacked / bias_packed hold the rows of W regrouped per tile of
+ * 80 output columns as [80 hidden rows | 80 gate rows] (zero rows past D): ceil(D/80)*160 rows
+ * (syn3r_amd.unet.ops.pack_geglu).
+ */
+int syn3r_gemm_geglu_f16(const void* A, long long lda, const void* Wpacked, const void* bias_packed, void* out,
+                         long long ldc, int M, int D, int K, void* stream);
+
+/*
  * 3x3 Conv2d, padding 1, on NHWC fp16 (resnet.py:274,290; downsampling.py:116-148 with stride 2;
  * upsampling.py:172-183 with upsample != 0: nearest-2x of the input fused into the gather).
  * X [NB,Hi,Wi,Cin], W [Cout, 3, 3, Cin] (= the Conv2d weight permuted to OHWI), Cin % 64 == 0.

@@ -26,6 +26,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 constexpr float kNegBig = -1.0e30f;
+constexpr float kLog2e = 1.4426950408889634f;
 
 // position of key kk (0..31) inside a 32-key group so that an accumulator-sourced B fragment
 // (k-step s, lane half h, element j  <->  key 16 s + 8 (j>>2) + 4 h + (j&3)) reads 8 contiguous halfs
@@ -161,20 +162,25 @@ __global__ void __launch_bounds__(ATHREADS) k_attn_spatial(AttnParams p) {
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[g][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
-        m_run = m_new;
+        const float mneg = -m_new * kLog2e;
         float ls = 0.f;
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float e = __expf(st[g][r] - m_new);
+                float e = __builtin_amdgcn_exp2f(fmaf(st[g][r], kLog2e, mneg));   // exp(s - m): one fma + v_exp_f32
                 st[g][r] = e;
                 ls += e;
             }
-        l_run = l_run * alpha + ls;
+        // rescale the running sums only when some query's maximum moved (wave-uniform test)
+        if (__ballot(m_new != m_run) != 0ull) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+            l_run *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
+            m_run = m_new;
+        }
+        l_run += ls;
         // O^T += V^T . P
 #pragma unroll
         for (int g = 0; g < 2; ++g)

@@ -53,6 +53,8 @@ struct GemmParams {
     int Ho, Wo, Hi, Wi, Cin, stride, ups;
     // temporal conv: F frames of HW rows each (row = (b*F + f)*HW + p)
     int F, HW;
+    // GEGLU epilogue: W rows are packed per 160-row tile as [80 hidden | 80 gate]; out has geglu_D columns
+    int geglu_D;
 };
 
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
@@ -238,6 +240,34 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_gemm(GemmParams p) {
     }
     __builtin_amdgcn_wave_barrier();
     __syncthreads();
+    if (p.geglu_D > 0) {
+        // activations.py GEGLU.forward: hidden * gelu(gate).  Wave (wm,0) staged the 80 hidden columns and
+        // (wm,1) the 80 gate columns of the same 64 rows (fp16, as the reference's projection output);
+        // each of the two waves finishes 32 of those rows.
+        const __half* hs = (const __half*)smem_raw + (wm * 2 + 0) * (WM * EPI_LD);
+        const __half* gs = (const __half*)smem_raw + (wm * 2 + 1) * (WM * EPI_LD);
+        const int nout0 = tile_n * WN;
+        for (int q = lane; q < 32 * (WN / 8); q += 64) {
+            int row = wn * 32 + q / (WN / 8), ch = q % (WN / 8);
+            int m = gm0 + row, n = nout0 + ch * 8;
+            if (m >= p.M || n >= p.geglu_D) continue;
+            half8 hv = *(const half8*)(hs + row * EPI_LD + ch * 8);
+            half8 gv = *(const half8*)(gs + row * EPI_LD + ch * 8);
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float g = (float)gv[e];
+                float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752f));
+                o[e] = (_Float16)((float)hv[e] * ge);
+            }
+            if (n + 8 <= p.geglu_D) {
+                *(half8*)(p.out + (long long)m * p.ldc + n) = o;
+            } else {
+                for (int e = 0; e < 8 && n + e < p.geglu_D; ++e) ((_Float16*)p.out)[(long long)m * p.ldc + n + e] = o[e];
+            }
+        }
+        return;
+    }
     // 64 rows x 10 chunks of 8 halfs per wavefront
 #pragma unroll 2
     for (int q = lane; q < WM * (WN / 8); q += 64) {
@@ -315,6 +345,23 @@ extern "C" int syn3r_gemm_f16(const void* A, long long lda, const void* W, void*
     int rc = check_common(p, "gemm_f16");
     if (rc) return rc;
     SYN3R_REQUIRE(lda % 8 == 0 && lda >= K, "gemm_f16: lda=%lld must be >= K and a multiple of 8", lda);
+    return launch<MODE_DENSE>(p, (hipStream_t)stream);
+}
+
+extern "C" int syn3r_gemm_geglu_f16(const void* A, long long lda, const void* Wpacked, const void* bias_packed, void* out,
+                                    long long ldc, int M, int D, int K, void* stream) {
+    GemmParams p{};
+    const int tiles = (D + WN - 1) / WN;
+    p.A = (const __half*)A; p.lda = lda; p.W = (const __half*)Wpacked; p.out = (__half*)out; p.ldc = ldc;
+    p.bias = (const __half*)bias_packed; p.s_acc = 1.0f; p.M = M; p.N = tiles * BN; p.K = K; p.geglu_D = D;
+    SYN3R_REQUIRE(D > 0, "gemm_geglu_f16: bad D=%d", D);
+    SYN3R_REQUIRE(ldc >= D && ldc % 8 == 0, "gemm_geglu_f16: ldc=%lld must be >= D and a multiple of 8", ldc);
+    long long save = p.ldc;
+    p.ldc = ((long long)p.N + 7) / 8 * 8 > p.ldc ? (long long)p.N : p.ldc;   // check_common compares ldc with the packed N
+    int rc = check_common(p, "gemm_geglu_f16");
+    if (rc) return rc;
+    p.ldc = save;
+    SYN3R_REQUIRE(lda % 8 == 0 && lda >= K, "gemm_geglu_f16: lda=%lld must be >= K and a multiple of 8", lda);
     return launch<MODE_DENSE>(p, (hipStream_t)stream);
 }
 

@@ -61,6 +61,32 @@ __global__ void k_gn_stats(const __half* __restrict__ x, int R, int C, int rows_
     }
 }
 
+// Fixed-order reduction of the per-chunk partials -> (mean, rstd) per (sample, group).
+// One 256-thread block per sample: 8 threads per group stride over the chunks, then a fixed
+// 3-step shuffle tree (bitwise reproducible).
+__global__ void __launch_bounds__(256) k_gn_finalize(const float* __restrict__ partial, int chunks, float inv_n, float eps,
+                                                     float* __restrict__ mr) {
+    const int sample = blockIdx.x;
+    const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    float s1 = 0.f, s2 = 0.f;
+    for (int ch = sub; ch < chunks; ch += 8) {
+        const float* st = partial + (((size_t)sample * chunks + ch) * 32 + g) * 2;
+        s1 += st[0];
+        s2 += st[1];
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+        s1 += __shfl_down(s1, o, 8);
+        s2 += __shfl_down(s2, o, 8);
+    }
+    if (sub == 0) {
+        float mean = s1 * inv_n;
+        float var = fmaxf(s2 * inv_n - mean * mean, 0.0f);
+        mr[((size_t)sample * 32 + g) * 2] = mean;
+        mr[((size_t)sample * 32 + g) * 2 + 1] = rsqrtf(var + eps);
+    }
+}
+
 template <bool SILU>
 __global__ void k_gn_apply(const __half* __restrict__ x, __half* __restrict__ y, int R, int C, int rows_per_block,
                            const float* __restrict__ stats, const __half* __restrict__ gamma,
@@ -72,21 +98,13 @@ __global__ void k_gn_apply(const __half* __restrict__ x, __half* __restrict__ y,
     const int r_begin = blockIdx.x * rows_per_block;
     const int r_end = min(R, r_begin + rows_per_block);
     const int cpg = C / 32;
-    const float inv_n = 1.0f / ((float)R * (float)cpg);
     float a[8], b[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         int c = cv * 8 + e;
         int g = c / cpg;
-        float s1 = 0.f, s2 = 0.f;
-        for (int ch = 0; ch < (int)gridDim.x; ++ch) {
-            const float* st = stats + (((size_t)sample * gridDim.x + ch) * 32 + g) * 2;
-            s1 += st[0];
-            s2 += st[1];
-        }
-        float mean = s1 * inv_n;
-        float var = fmaxf(s2 * inv_n - mean * mean, 0.0f);
-        float rstd = rsqrtf(var + eps);
+        const float* st = stats + ((size_t)sample * 32 + g) * 2;   // (mean, rstd) from k_gn_finalize
+        float mean = st[0], rstd = st[1];
         float ga = (float)((const _Float16*)gamma)[c], be = (float)((const _Float16*)beta)[c];
         a[e] = rstd * ga;
         b[e] = be - mean * rstd * ga;
@@ -105,17 +123,23 @@ __global__ void k_gn_apply(const __half* __restrict__ x, __half* __restrict__ y,
     }
 }
 
-// ---------------------------------------------------------------- LayerNorm (one wavefront per row)
-constexpr int LN_MAXV = 8;   // up to 8 vectors of 8 channels per lane: C <= 4096
+// ---------------------------------------------------------------- LayerNorm
+// LPR lanes cooperate on one row (64/LPR rows per wavefront), each lane holding up to LN_MAXV vectors of
+// 8 channels: C = 320 -> 8 lanes x 5 vectors, every lane busy (one wavefront per row would idle 24 of 64).
+constexpr int LN_MAXV = 8;
 
+template <int LPR>
 __global__ void __launch_bounds__(256) k_layernorm(const __half* __restrict__ x, __half* __restrict__ y,
                                                    __half* __restrict__ xsum, const __half* __restrict__ addvec,
                                                    int rows_per_vec, long long M, int C,
                                                    const __half* __restrict__ gamma, const __half* __restrict__ beta,
                                                    float eps) {
+    constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const int sub = lane % LPR;
+    long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool live = row < M;
+    if (!live) row = M - 1;                     // keep the lanes in the shuffles
     const int cvec = C >> 3;
     const __half* src = x + row * C;
     const __half* add = addvec ? addvec + (row / rows_per_vec) * C : nullptr;
@@ -123,35 +147,38 @@ __global__ void __launch_bounds__(256) k_layernorm(const __half* __restrict__ x,
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
-        int cv = lane + 64 * k;
+        int cv = sub + LPR * k;
         if (cv < cvec) {
             half8 h = *(const half8*)(src + cv * 8);
             if (add) {
                 half8 a = *(const half8*)(add + cv * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) h[e] = h[e] + a[e];   // fp16 add, as the reference's tensor add
-                if (xsum) *(half8*)(xsum + row * C + cv * 8) = h;
+                if (xsum && live) *(half8*)(xsum + row * C + cv * 8) = h;
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) { v[k][e] = (float)h[e]; s += v[k][e]; }
         }
     }
-    s = wave_sum(s);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const float mean = s / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
-        int cv = lane + 64 * k;
+        int cv = sub + LPR * k;
         if (cv < cvec) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { float d = v[k][e] - mean; q += d * d; }
         }
     }
-    q = wave_sum(q);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
     const float rstd = rsqrtf(q / (float)C + eps);
+    if (!live) return;
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
-        int cv = lane + 64 * k;
+        int cv = sub + LPR * k;
         if (cv < cvec) {
             half8 g = *(const half8*)(gamma + cv * 8), b = *(const half8*)(beta + cv * 8), o;
 #pragma unroll
@@ -204,7 +231,7 @@ extern "C" size_t syn3r_groupnorm_workspace_bytes(int samples, int rows) {
     if (samples <= 0 || rows <= 0) return 0;
     int chunks, rpb;
     gn_geometry(samples, rows, chunks, rpb);
-    return (size_t)samples * chunks * 32 * 2 * sizeof(float);
+    return (size_t)samples * chunks * 32 * 2 * sizeof(float) + (size_t)samples * 32 * 2 * sizeof(float);
 }
 
 extern "C" int syn3r_groupnorm_f16(const void* x, void* y, int samples, int rows, int C, const void* gamma,
@@ -225,14 +252,17 @@ extern "C" int syn3r_groupnorm_f16(const void* x, void* y, int samples, int rows
     gn_geometry(samples, rows, chunks, rows_per_block);
     dim3 grid(chunks, samples);
     size_t lds = (size_t)threads * 16 * sizeof(float);
-    SYN3R_LAUNCH(k_gn_stats, grid, dim3(threads), lds, stream, (const __half*)x, rows, C, rows_per_block,
-                 (float*)workspace);
+    float* partial = (float*)workspace;
+    float* meanrstd = partial + (size_t)samples * chunks * 64;
+    SYN3R_LAUNCH(k_gn_stats, grid, dim3(threads), lds, stream, (const __half*)x, rows, C, rows_per_block, partial);
+    SYN3R_LAUNCH(k_gn_finalize, dim3(samples), dim3(256), 0, stream, (const float*)partial, chunks,
+                 1.0f / ((float)rows * (float)(C / 32)), eps, meanrstd);
     if (silu)
         SYN3R_LAUNCH(k_gn_apply<true>, grid, dim3(threads), 0, stream, (const __half*)x, (__half*)y, rows, C,
-                     rows_per_block, (const float*)workspace, (const __half*)gamma, (const __half*)beta, eps);
+                     rows_per_block, (const float*)meanrstd, (const __half*)gamma, (const __half*)beta, eps);
     else
         SYN3R_LAUNCH(k_gn_apply<false>, grid, dim3(threads), 0, stream, (const __half*)x, (__half*)y, rows, C,
-                     rows_per_block, (const float*)workspace, (const __half*)gamma, (const __half*)beta, eps);
+                     rows_per_block, (const float*)meanrstd, (const __half*)gamma, (const __half*)beta, eps);
     SYN3R_LAUNCH_CHECK("groupnorm launch");
     return SYN3R_OK;
 }
@@ -242,10 +272,21 @@ extern "C" int syn3r_layernorm_f16(const void* x, void* y, void* xsum, const voi
     SYN3R_REQUIRE(x && y && gamma && beta, "layernorm: null tensor");
     SYN3R_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "layernorm: bad sizes M=%lld C=%d", M, C);
     SYN3R_REQUIRE(!addvec || rows_per_vec > 0, "layernorm: rows_per_vec required with addvec");
-    long long blocks = (M + 3) / 4;
+    const int cvec = C / 8;
+    int lpr = 8;
+    while (lpr < 64 && (cvec + lpr - 1) / lpr > 5) lpr *= 2;       // <= 5 vectors per lane where possible
+    long long rows_per_block = 4 * (64 / lpr);
+    long long blocks = (M + rows_per_block - 1) / rows_per_block;
     SYN3R_REQUIRE(blocks < (1ll << 31), "layernorm: too many rows");
-    SYN3R_LAUNCH(k_layernorm, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const __half*)x, (__half*)y,
-                 (__half*)xsum, (const __half*)addvec, rows_per_vec, M, C, (const __half*)gamma, (const __half*)beta, eps);
+#define LN_LAUNCH(L_)                                                                                                   \
+    SYN3R_LAUNCH(k_layernorm<L_>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const __half*)x,          \
+                 (__half*)y, (__half*)xsum, (const __half*)addvec, rows_per_vec, M, C, (const __half*)gamma,              \
+                 (const __half*)beta, eps)
+    if (lpr == 8) LN_LAUNCH(8);
+    else if (lpr == 16) LN_LAUNCH(16);
+    else if (lpr == 32) LN_LAUNCH(32);
+    else LN_LAUNCH(64);
+#undef LN_LAUNCH
     SYN3R_LAUNCH_CHECK("layernorm launch");
     return SYN3R_OK;
 }

@@ -30,8 +30,24 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool = False
 
 
+_host_cache: dict = {}
+
+
+def _host_floats(m: torch.Tensor):
+    """Camera matrices / background live on the GPU in FSGS cameras; the ABI takes them by value.
+    One device->host read per distinct tensor version (cached), not per render call."""
+    key = (m.data_ptr(), m._version, m.device.index, m.numel())
+    hit = _host_cache.get(key)
+    if hit is None:
+        if len(_host_cache) > 4096:
+            _host_cache.clear()
+        hit = L.host_f32(m.detach().to("cpu", torch.float32).reshape(-1).tolist())
+        _host_cache[key] = hit
+    return hit
+
+
 def _host16(m: torch.Tensor):
-    return L.host_f32(m.detach().to("cpu", torch.float32).reshape(-1).tolist())
+    return _host_floats(m)
 
 
 class _Rasterize(torch.autograd.Function):
@@ -53,8 +69,8 @@ class _Rasterize(torch.autograd.Function):
         if m3.shape != (N, 3) or sc.shape != (N, 3) or ro.shape != (N, 4) or op.shape != (N,) or sh.shape != (N, M, 3):
             raise ValueError("rasteriser: inconsistent Gaussian tensor shapes")
         view, proj = _host16(s.viewmatrix), _host16(s.projmatrix)
-        campos = L.host_f32(s.campos.detach().cpu().reshape(-1).tolist())
-        bg = L.host_f32(s.bg.detach().cpu().reshape(-1).tolist())
+        campos = _host_floats(s.campos)
+        bg = _host_floats(s.bg)
         stream = L.stream_ptr(dev)
 
         geom = torch.empty(lib.syn3r_raster_geom_bytes(N), dtype=torch.uint8, device=dev)

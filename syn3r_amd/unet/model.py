@@ -288,6 +288,11 @@ class UNetSpatioTemporalConditionModel:
                 pre = k[: -len("to_q.weight")]
                 pk[pre + "qkv"] = torch.cat([p.t[pre + "to_q.weight"], p.t[pre + "to_k.weight"],
                                              p.t[pre + "to_v.weight"]], 0).contiguous()
+        for k in list(p.t):
+            if k.endswith(".net.0.proj.weight"):
+                pre = k[: -len("weight")]
+                wp, bp, D = ops.pack_geglu(p.t[k], p.t[pre + "bias"])
+                pk[pre + "geglu_w"], pk[pre + "geglu_b"] = wp, bp
         self.packed = pk
         self.alpha = {k: torch.sigmoid(t.float()).to(H) for k, t in p.t.items() if k.endswith("mix_factor")}
 
@@ -332,8 +337,9 @@ class UNetSpatioTemporalConditionModel:
         return ops.linear(v, self.w(pre + ".to_out.0.weight"), self.w(pre + ".to_out.0.bias"))
 
     def _ff(self, pre: str, x: torch.Tensor, **epilogue) -> torch.Tensor:
-        g = ops.linear(x, self.w(pre + ".net.0.proj.weight"), self.w(pre + ".net.0.proj.bias"))
-        return ops.linear(ops.geglu(g), self.w(pre + ".net.2.weight"), self.w(pre + ".net.2.bias"), **epilogue)
+        wp = self.w(pre + ".net.0.proj.geglu_w")
+        g = ops.linear_geglu(x, wp, self.w(pre + ".net.0.proj.geglu_b"), self.p.shapes[pre + ".net.0.proj.weight"][0] // 2)
+        return ops.linear(g, self.w(pre + ".net.2.weight"), self.w(pre + ".net.2.bias"), **epilogue)
 
     def _transformer(self, pre: str, x: torch.Tensor, st: dict, ch: int, heads: int) -> torch.Tensor:
         B, F, h, w_ = st["B"], st["F"], st["h"], st["w"]

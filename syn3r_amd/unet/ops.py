@@ -57,6 +57,36 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
+def pack_geglu(weight: torch.Tensor, bias: torch.Tensor):
+    """Regroup the [2D, K] GEGLU projection (hidden rows, then gate rows) per 80-column output tile as
+    [80 hidden | 80 gate] rows, zero-padded: the layout syn3r_gemm_geglu_f16 expects."""
+    D2, K = weight.shape
+    D = D2 // 2
+    tiles = (D + 79) // 80
+    wp = torch.zeros((tiles * 160, K), dtype=weight.dtype, device=weight.device)
+    bp = torch.zeros((tiles * 160,), dtype=bias.dtype, device=bias.device)
+    for t in range(tiles):
+        n = min(80, D - 80 * t)
+        wp[160 * t:160 * t + n] = weight[80 * t:80 * t + n]
+        wp[160 * t + 80:160 * t + 80 + n] = weight[D + 80 * t:D + 80 * t + n]
+        bp[160 * t:160 * t + n] = bias[80 * t:80 * t + n]
+        bp[160 * t + 80:160 * t + 80 + n] = bias[D + 80 * t:D + 80 * t + n]
+    return wp.contiguous(), bp.contiguous(), D
+
+
+def linear_geglu(x: torch.Tensor, wpacked: torch.Tensor, bpacked: torch.Tensor, D: int) -> torch.Tensor:
+    """geglu(x @ W^T + b) in one kernel: [M,K] -> [M,D]."""
+    dev = _chk(wpacked, bpacked)
+    L.require_gpu(x)
+    M, K = x.shape
+    out = torch.empty((M, D), dtype=H, device=dev)
+    rc = L.load().syn3r_gemm_geglu_f16(x.data_ptr(), x.stride(0), L.ptr(wpacked), L.ptr(bpacked), L.ptr(out), D, M, D, K,
+                                       L.stream_ptr(dev))
+    L.check(rc, "syn3r_gemm_geglu_f16")
+    _count("gemm", 2.0 * M * 2 * D * K)
+    return out
+
+
 def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride: int = 1,
             upsample: bool = False, rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0,
             residual: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0) -> torch.Tensor:

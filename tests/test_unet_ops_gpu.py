@@ -175,6 +175,21 @@ def test_geglu(gpu):
     close(ops.geglu(x), hid * Fn.gelu(gate))
 
 
+@pytest.mark.parametrize("M,D,K", [(500, 1280, 320), (300, 256, 64), (77, 80, 128), (1000, 2560, 640)])
+def test_gemm_geglu_fused(M, D, K, gpu):
+    """Fused projection + gate vs the two-step fp32 reference; also bit-equal to the unfused HIP kernels."""
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(D)
+    x, w, b = rnd(g, M, K, dev=gpu), rnd(g, 2 * D, K, scale=K ** -0.5, dev=gpu), rnd(g, 2 * D, dev=gpu)
+    wp, bp, d = ops.pack_geglu(w, b)
+    assert d == D and wp.shape[0] == ((D + 79) // 80) * 160
+    out = ops.linear_geglu(x, wp, bp, D)
+    proj = (x.float() @ w.float().T + b.float()).to(H).float()      # projection rounded to fp16, as the reference
+    hid, gate = proj.chunk(2, dim=-1)
+    close(out, hid * Fn.gelu(gate))
+    assert torch.equal(out, ops.geglu(ops.linear(x, w, b)))
+
+
 def test_ops_reject_bad_input(gpu):
     from syn3r_amd import _lib
     from syn3r_amd.unet import ops
