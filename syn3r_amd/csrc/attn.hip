@@ -13,8 +13,10 @@
 // so a lane owns ONE query column and its keys sit in the accumulator registers: the row max /
 // sum is a register reduction plus one lane^32 exchange (no 32-lane shuffles).  The probability
 // tile is then used directly from the accumulator as the B operand of O^T += V^T.P (the k order
-// of an accumulator-sourced fragment is permuted; V^T is written to LDS in that same order, XOR-
-// swizzled so the 16-byte fragment reads are conflict-free).
+// of an accumulator-sourced fragment is permuted: element j of lane half h is key 16s + 8(j>>2) + 4h + (j&3)).
+// V stays row-major [key][d] in LDS (16-byte coalesced staging) and its transposed A fragments come from
+// gfx950's ds_read_b64_tr_b16: each 16-lane group fetches a 4-key x 16-d block column-major, two reads
+// (keys r0..r0+3 and r0+8..r0+11) make exactly the permuted 8-key fragment.
 #include "common.h"
 
 using namespace syn3r;
@@ -24,18 +26,27 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+// V tile [keys][64 d] row-major, 16-byte chunks XOR-swizzled by (key>>1)&3 so that the 4 rows of a
+// transposed-read block fall on different banks; 8-byte pieces stay intact.
+__device__ __forceinline__ int v_off(int key, int d) { return key * 64 + ((((d >> 3) ^ ((key >> 1) & 3)) << 3) | (d & 7)); }
+
+// A fragment of O^T += V^T.P for d = d0 + (lane&31): keys r0 + {0..3} and r0 + 8 + {0..3} (r0 includes 4*h)
+__device__ __forceinline__ half8 v_frag_tr(const __half* vs, int r0, int d0, int lane) {
+    const int i = lane & 15, q = i >> 2, pc = i & 3;
+    const int c = d0 + ((lane >> 4) & 1) * 16 + 4 * pc;
+    typedef __attribute__((address_space(3))) fp16x4 lds4;
+    fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds4*)(vs + v_off(r0 + q, c)));
+    fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds4*)(vs + v_off(r0 + 8 + q, c)));
+    half8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r[e] = (_Float16)a[e]; r[4 + e] = (_Float16)b[e]; }
+    return r;
+}
 
 constexpr float kNegBig = -1.0e30f;
 constexpr float kLog2e = 1.4426950408889634f;
-
-// position of key kk (0..31) inside a 32-key group so that an accumulator-sourced B fragment
-// (k-step s, lane half h, element j  <->  key 16 s + 8 (j>>2) + 4 h + (j&3)) reads 8 contiguous halfs
-__device__ __forceinline__ int key_pos(int kk) {
-    int s = kk >> 4, rem = kk & 15;
-    int h = (rem >> 2) & 1;
-    int j = ((rem >> 3) << 2) | (rem & 3);
-    return s * 16 + h * 8 + j;
-}
 
 __device__ __forceinline__ half8 pack8(const float16v& p, int s) {
     half8 r;
@@ -59,7 +70,7 @@ constexpr int BQ = 128, BKV = 64, ATHREADS = 256;
 
 __global__ void __launch_bounds__(ATHREADS) k_attn_spatial(AttnParams p) {
     __shared__ __attribute__((aligned(16))) __half Ks[2][BKV * 64];
-    __shared__ __attribute__((aligned(16))) __half Vt[2][64 * BKV];
+    __shared__ __attribute__((aligned(16))) __half Vs[2][BKV * 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lq = lane & 31, h = lane >> 5;
     const int qblocks = (p.S + BQ - 1) / BQ;
@@ -110,13 +121,7 @@ __global__ void __launch_bounds__(ATHREADS) k_attn_spatial(AttnParams p) {
         for (int i = 0; i < 2; ++i) {
             int key = s_key0 + 32 * i;
             *(uint4*)(&Ks[buf][key * 64 + ((s_chunk ^ (key & 7)) << 3)]) = rk[i];
-            int pos = (key & 32) + key_pos(key & 31);
-            const __half* ve = (const __half*)&rv[i];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                int d = s_chunk * 8 + e;
-                Vt[buf][d * BKV + ((((pos >> 3) ^ (d & 7)) << 3) | (pos & 7))] = ve[e];
-            }
+            *(uint4*)(&Vs[buf][v_off(key, s_chunk * 8)]) = rv[i];
         }
     };
 
@@ -187,11 +192,9 @@ __global__ void __launch_bounds__(ATHREADS) k_attn_spatial(AttnParams p) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 half8 pf = pack8(st[g], s);
-                int chunk = (g * 32 + s * 16 + h * 8) >> 3;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    int d = dt * 32 + lq;
-                    half8 vf = *(const half8*)(&Vt[cur][d * BKV + ((chunk ^ (d & 7)) << 3)]);
+                    half8 vf = v_frag_tr(Vs[cur], g * 32 + s * 16 + 4 * h, dt * 32, lane);
                     ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[dt], 0, 0, 0);
                 }
             }
@@ -217,7 +220,7 @@ __global__ void __launch_bounds__(ATHREADS) k_attn_spatial(AttnParams p) {
 
 // One wavefront per (batch, pixel, head); 4 wavefronts per block.
 __global__ void __launch_bounds__(ATHREADS) k_attn_temporal(AttnParams p, long long nitems) {
-    __shared__ __attribute__((aligned(16))) __half Vt[4][64 * 32];
+    __shared__ __attribute__((aligned(16))) __half Vsm[4][32 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lq = lane & 31, h = lane >> 5;
     long long item = (long long)blockIdx.x * 4 + wv;
@@ -242,21 +245,15 @@ __global__ void __launch_bounds__(ATHREADS) k_attn_temporal(AttnParams p, long l
         qf[ks] = t;
         kf[ks] = *(const half8*)(ksrc + ks * 16 + 8 * h);
     }
-    // V^T into LDS in accumulator-fragment key order: 32 keys x 8 chunks = 256 chunks, 4 per lane
-    __half* vt = Vt[wv];
+    // V row-major [32 keys][64 d] into this wavefront's LDS slice: 256 chunks of 16 bytes, 4 per lane
+    __half* vs = Vsm[wv];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int q = lane + 64 * i;
         int key = q >> 3, ch = q & 7;
         uint4 rv = make_uint4(0, 0, 0, 0);
         if (key < F) rv = *(const uint4*)(p.v + row_of(key) * p.ld + hd * 64 + ch * 8);
-        int pos = key_pos(key);
-        const __half* ve = (const __half*)&rv;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int d = ch * 8 + e;
-            vt[d * 32 + ((((pos >> 3) ^ (d & 3)) << 3) | (pos & 7))] = ve[e];
-        }
+        *(uint4*)(vs + v_off(key, ch * 8)) = rv;
     }
     float16v st;
 #pragma unroll
@@ -286,11 +283,9 @@ __global__ void __launch_bounds__(ATHREADS) k_attn_temporal(AttnParams p, long l
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         half8 pf = pack8(st, s);
-        int chunk = (s * 16 + h * 8) >> 3;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-            int d = dt * 32 + lq;
-            half8 vf = *(const half8*)(vt + d * 32 + ((chunk ^ (d & 3)) << 3));
+            half8 vf = v_frag_tr(vs, s * 16 + 4 * h, dt * 32, lane);
             ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[dt], 0, 0, 0);
         }
     }
