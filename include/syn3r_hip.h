@@ -258,6 +258,9 @@ int syn3r_gemm_f16(const void* A, long long lda, const void* W, void* out, long 
                    const void* aux, long long ldaux, float s_acc, float s_res, float s_aux, int M, int N, int K,
                    void* stream);
 
+/* Tuning hook: force the GEMM block height (128 or 256 rows; 0 = library default). */
+int syn3r_gemm_set_tile(int bm);
+
 /*
  * FeedForward's first projection fused with its GEGLU gate (attention.py:608-665, activations.py GEGLU):
  * out[M,D] = h * gelu_erf(g) with [h | g] = A[M,K] . W[2D,K]^T + bias, h and g rounded to fp16 first as

@@ -11,7 +11,7 @@
 // which covers bias, the time-embedding add (resnet.py:352), residual adds, the Sk=1
 // cross-attention broadcast and the AlphaBlender mix (resnet.py:789-802).
 //
-// CDNA4 mapping: 256x160x64 block tile, 512 threads = 8 wavefronts (4 along M x 2 along N),
+// CDNA4 mapping: BMx160x64 block tile (BM = 128: 256 threads = 4 wavefronts, two blocks per CU; BM = 256: 512 threads),
 // each wavefront 64x80 = 4x5 tiles of v_mfma_f32_16x16x32_f16 (f32 accumulate).  Operands are
 // staged global -> registers -> LDS (XOR-swizzled 16-byte chunks, conflict-free ds_read_b128
 // fragment reads), double-buffered: the loads of k-tile t+1 are issued before the MFMAs of tile t
@@ -29,12 +29,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // 16-byte staging register (native vector: stays in VGPRs)
 
-constexpr int BM = 256, BN = 160, BK = 64;
-constexpr int NTHREADS = 512;
+constexpr int BN = 160, BK = 64;
 constexpr int WM = 64, WN = 80;            // per-wavefront output tile
 constexpr int TM = WM / 16, TN = WN / 16;  // 4 x 5 MFMA tiles
-constexpr int A_TILE = BM * BK;            // halfs
-constexpr int B_TILE = BN * BK;
+constexpr int B_TILE = BN * BK;            // halfs
+// Two block shapes: BM = 256 (512 threads, 1 block/CU) and BM = 128 (256 threads, 2 independent
+// blocks/CU whose barrier phases de-synchronise: while one block stages / waits, the other issues MFMAs).
 constexpr int EPI_LD = 88;                 // padded row stride (halfs) of the epilogue staging tile
 
 enum { MODE_DENSE = 0, MODE_CONV2D = 1, MODE_TCONV = 2 };
@@ -65,8 +65,12 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
 
-template <int MODE>
-__global__ void __launch_bounds__(NTHREADS, 2) k_gemm(GemmParams p) {
+template <int MODE, int BM>
+__global__ void __launch_bounds__(BM * 2, 2) k_gemm(GemmParams p) {
+    constexpr int NTHREADS = BM * 2;
+    constexpr int A_TILE = BM * BK;
+    constexpr int RSTEP = NTHREADS / 8;             // rows covered by one staging sweep
+    constexpr int B_ITERS = (BN * 8 + NTHREADS - 1) / NTHREADS;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __half* As = (__half*)smem_raw;                 // [2][BM][BK]
     __half* Bs = As + 2 * A_TILE;                   // [2][BN][BK]
@@ -81,13 +85,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_gemm(GemmParams p) {
 
     // ---- per-thread staging assignment
     const int a_chunk = tid & 7;
-    const int a_row0 = tid >> 3;                    // rows a_row0 + 64*i, i = 0..3
+    const int a_row0 = tid >> 3;                    // rows a_row0 + RSTEP*i, i = 0..3
     long long a_off[4];                             // dense: element offset of the row; conv: pixel index pieces
     int a_n[4], a_y[4], a_x[4];                     // conv: sample / output y / output x ; tconv: frame index in a_y
     bool a_ok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int m = m0 + a_row0 + 64 * i;
+        int m = m0 + a_row0 + RSTEP * i;
         a_ok[i] = m < p.M;
         int mc = a_ok[i] ? m : p.M - 1;
         if constexpr (MODE == MODE_DENSE) {
@@ -108,10 +112,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_gemm(GemmParams p) {
         }
     }
     const int b_chunk = tid & 7;
-    long long b_off[3];
-    bool b_ok[3];
+    long long b_off[B_ITERS];
+    bool b_ok[B_ITERS];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < B_ITERS; ++i) {
         int q = tid + NTHREADS * i;
         int row = q >> 3;
         b_ok[i] = (q < BN * 8);
@@ -124,7 +128,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_gemm(GemmParams p) {
     const int nkt = p.K / BK;
     const int cpb = (MODE == MODE_DENSE) ? 1 : p.Cin / BK;   // k-tiles per tap
 
-    u32x4 ra[4], rb[3];
+    u32x4 ra[4], rb[B_ITERS];
     auto load_tile = [&](int kt) {
         const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
         if constexpr (MODE == MODE_DENSE) {
@@ -157,7 +161,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_gemm(GemmParams p) {
         }
         const int kb = kt * BK + b_chunk * 8;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < B_ITERS; ++i) {
             if (b_ok[i]) rb[i] = (b_off[i] >= 0) ? *(const u32x4*)(p.W + b_off[i] + kb) : z;
         }
     };
@@ -165,9 +169,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_gemm(GemmParams p) {
         __half* as = As + buf * A_TILE;
         __half* bs = Bs + buf * B_TILE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(u32x4*)(as + swz(a_row0 + 64 * i, a_chunk)) = ra[i];
+        for (int i = 0; i < 4; ++i) *(u32x4*)(as + swz(a_row0 + RSTEP * i, a_chunk)) = ra[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < B_ITERS; ++i) {
             int q = tid + NTHREADS * i;
             if (b_ok[i]) *(u32x4*)(bs + swz(q >> 3, b_chunk)) = rb[i];
         }
@@ -300,22 +304,29 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_gemm(GemmParams p) {
     }
 }
 
-constexpr size_t kGemmLds = (size_t)2 * (A_TILE + B_TILE) * sizeof(__half);   // 106,496 B
-static_assert(8 * WM * EPI_LD * sizeof(__half) <= kGemmLds, "epilogue staging must fit in the tile buffers");
+int g_tile_bm = 0;   // 0 = heuristic, else forced 128 / 256 (syn3r_gemm_set_tile, tuning only)
 
-template <int MODE>
-int launch(const GemmParams& p, hipStream_t stream) {
+template <int MODE, int BM>
+int launch_bm(const GemmParams& p, hipStream_t stream) {
+    constexpr size_t lds = (size_t)2 * (BM * BK + B_TILE) * sizeof(__half);   // 106,496 B (BM 256) / 73,728 B (BM 128)
+    static_assert((BM / 64) * 2 * WM * EPI_LD * sizeof(__half) <= lds, "epilogue staging must fit in the tile buffers");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)kGemmLds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm<MODE, BM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm)");
         attr_set = true;
     }
     int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    SYN3R_LAUNCH(k_gemm<MODE>, dim3(tiles), dim3(NTHREADS), kGemmLds, stream, p);
+    SYN3R_LAUNCH((k_gemm<MODE, BM>), dim3(tiles), dim3(BM * 2), lds, stream, p);
     SYN3R_LAUNCH_CHECK("gemm launch");
     return SYN3R_OK;
+}
+
+template <int MODE>
+int launch(const GemmParams& p, hipStream_t stream) {
+    int bm = g_tile_bm ? g_tile_bm : 128;
+    return bm == 256 ? launch_bm<MODE, 256>(p, stream) : launch_bm<MODE, 128>(p, stream);
 }
 
 int check_common(const GemmParams& p, const char* who) {
@@ -332,6 +343,12 @@ int check_common(const GemmParams& p, const char* who) {
 }
 
 }  // namespace
+
+extern "C" int syn3r_gemm_set_tile(int bm) {
+    SYN3R_REQUIRE(bm == 0 || bm == 128 || bm == 256, "gemm_set_tile: bm must be 0, 128 or 256");
+    g_tile_bm = bm;
+    return SYN3R_OK;
+}
 
 extern "C" int syn3r_gemm_f16(const void* A, long long lda, const void* W, void* out, long long ldc, const void* bias,
                               const void* rowvec, long long ldrv, int rows_per_vec, const void* residual,
