@@ -36,32 +36,35 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 }
 
 // Sum v[k] over the 64 lanes; on return lane 4k holds the total of value k in the return value.
+// The two widest exchange levels use gfx950's half/row swaps (v_permlane32_swap, v_permlane16_swap): one
+// VALU instruction moves BOTH directions of the exchange (lower lanes keep value k and receive the
+// partner's k, upper lanes keep k+8 and receive the partner's k+8), so a level is a swap and an add per
+// surviving value — no LDS-pipe ds_bpermute and no selects.  The xor-8 level is a DPP row rotate.
 __device__ __forceinline__ float butterfly16(float (&v)[16], int lane) {
     float w8[8], w4[4], w2[2];
-    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+    const bool b3 = lane & 8, b2 = lane & 4;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float send = b5 ? v[k] : v[k + 8];
-        float keep = b5 ? v[k + 8] : v[k];
-        w8[k] = keep + __shfl_xor(send, 32, 64);
+    for (int k = 0; k < 8; ++k) {   // lanes 32-63 of v[k] <-> lanes 0-31 of v[k+8]
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v[k]), __float_as_int(v[k + 8]), false, false);
+        w8[k] = __int_as_float(r[0]) + __int_as_float(r[1]);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float send = b4 ? w8[k] : w8[k + 4];
-        float keep = b4 ? w8[k + 4] : w8[k];
-        w4[k] = keep + __shfl_xor(send, 16, 64);
+    for (int k = 0; k < 4; ++k) {   // odd 16-lane rows of w8[k] <-> even rows of w8[k+4]
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(w8[k]), __float_as_int(w8[k + 4]), false, false);
+        w4[k] = __int_as_float(r[0]) + __int_as_float(r[1]);
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 2; ++k) {   // xor 8 == rotate the 16-lane row by 8
         float send = b3 ? w4[k] : w4[k + 2];
         float keep = b3 ? w4[k + 2] : w4[k];
-        w2[k] = keep + __shfl_xor(send, 8, 64);
+        int recv = __builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128 /* row_ror:8 */, 0xF, 0xF, false);
+        w2[k] = keep + __int_as_float(recv);
     }
     float send = b2 ? w2[0] : w2[1];
     float keep = b2 ? w2[1] : w2[0];
     float w1 = keep + __shfl_xor(send, 4, 64);
-    w1 += __shfl_xor(w1, 1, 64);
-    w1 += __shfl_xor(w1, 2, 64);
+    w1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w1), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false));
+    w1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w1), 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, false));
     return w1;   // value index = bit2 + 2*bit3 + 4*bit4 + 8*bit5 = lane >> 2
 }
 
