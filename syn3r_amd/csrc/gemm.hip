@@ -65,6 +65,98 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
 
+// Shared epilogue: acc (+bias +rowvec) -> fp16 through LDS -> row-contiguous 16-byte stores (+residual, +aux),
+// or the GEGLU gate.  Must be entered by every wavefront of the block after the last LDS tile read.
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc)[TM][TN], char* smem_raw, int lane,
+                                              int wv, int wm, int wn, int m0, int n0, int tile_n) {
+    const int fr = lane & 15, fq = lane >> 4;
+    __half* st = (__half*)smem_raw + wv * (WM * EPI_LD);
+    const int gm0 = m0 + wm * WM, gn0 = n0 + wn * WN;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int col = j * 16 + fr;
+        int n = gn0 + col;
+        float bv = (p.bias && n < p.N) ? __half2float(p.bias[n]) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = i * 16 + fq * 4 + r;
+                float v = acc[i][j][r] + bv;
+                if (p.rowvec) {
+                    int m = gm0 + row;
+                    // rows_per_vec > 0: one vector per block of rows; < 0: vector index = m mod |rows_per_vec|
+                    if (m < p.M && n < p.N) {
+                        int vi = p.rows_per_vec > 0 ? m / p.rows_per_vec : m % (-p.rows_per_vec);
+                        v += __half2float(p.rowvec[(long long)vi * p.ldrv + n]);
+                    }
+                }
+                st[row * EPI_LD + col] = __float2half_rn(v * p.s_acc);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if (p.geglu_D > 0) {
+        // activations.py GEGLU.forward: hidden * gelu(gate).  Wave (wm,0) staged the 80 hidden columns and
+        // (wm,1) the 80 gate columns of the same 64 rows (fp16, as the reference's projection output);
+        // each of the two waves finishes 32 of those rows.
+        const __half* hs = (const __half*)smem_raw + (wm * 2 + 0) * (WM * EPI_LD);
+        const __half* gs = (const __half*)smem_raw + (wm * 2 + 1) * (WM * EPI_LD);
+        const int nout0 = tile_n * WN;
+        for (int q = lane; q < 32 * (WN / 8); q += 64) {
+            int row = wn * 32 + q / (WN / 8), ch = q % (WN / 8);
+            int m = gm0 + row, n = nout0 + ch * 8;
+            if (m >= p.M || n >= p.geglu_D) continue;
+            half8 hv = *(const half8*)(hs + row * EPI_LD + ch * 8);
+            half8 gv = *(const half8*)(gs + row * EPI_LD + ch * 8);
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float g = (float)gv[e];
+                float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752f));
+                o[e] = (_Float16)((float)hv[e] * ge);
+            }
+            if (n + 8 <= p.geglu_D) {
+                *(half8*)(p.out + (long long)m * p.ldc + n) = o;
+            } else {
+                for (int e = 0; e < 8 && n + e < p.geglu_D; ++e) ((_Float16*)p.out)[(long long)m * p.ldc + n + e] = o[e];
+            }
+        }
+        return;
+    }
+    // 64 rows x 10 chunks of 8 halfs per wavefront
+#pragma unroll 2
+    for (int q = lane; q < WM * (WN / 8); q += 64) {
+        int row = q / (WN / 8), ch = q - row * (WN / 8);
+        int m = gm0 + row, n = gn0 + ch * 8;
+        if (m >= p.M || n >= p.N) continue;
+        half8 v = *(const half8*)(st + row * EPI_LD + ch * 8);
+        if (p.residual || p.aux) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+            if (p.residual) {
+                half8 rv = *(const half8*)(p.residual + (long long)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += p.s_res * (float)rv[e];
+            }
+            if (p.aux) {
+                half8 av = *(const half8*)(p.aux + (long long)m * p.ldaux + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += p.s_aux * (float)av[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (_Float16)f[e];
+        }
+        if (n + 8 <= p.N) {
+            *(half8*)(p.out + (long long)m * p.ldc + n) = v;
+        } else {
+            for (int e = 0; e < 8 && n + e < p.N; ++e) ((_Float16*)p.out)[(long long)m * p.ldc + n + e] = v[e];
+        }
+    }
+}
+
 template <int MODE, int BM>
 __global__ void __launch_bounds__(BM * 2, 2) k_gemm(GemmParams p) {
     constexpr int NTHREADS = BM * 2;
@@ -216,95 +308,196 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm(GemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: acc (+bias +rowvec) -> fp16 through LDS -> row-contiguous 16-byte stores
-    __half* st = (__half*)smem_raw + wv * (WM * EPI_LD);
-    const int gm0 = m0 + wm * WM, gn0 = n0 + wn * WN;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        int col = j * 16 + fr;
-        int n = gn0 + col;
-        float bv = (p.bias && n < p.N) ? __half2float(p.bias[n]) : 0.0f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int row = i * 16 + fq * 4 + r;
-                float v = acc[i][j][r] + bv;
-                if (p.rowvec) {
-                    int m = gm0 + row;
-                    // rows_per_vec > 0: one vector per block of rows; < 0: vector index = m mod |rows_per_vec|
-                    if (m < p.M && n < p.N) {
-                        int vi = p.rows_per_vec > 0 ? m / p.rows_per_vec : m % (-p.rows_per_vec);
-                        v += __half2float(p.rowvec[(long long)vi * p.ldrv + n]);
-                    }
-                }
-                st[row * EPI_LD + col] = __float2half_rn(v * p.s_acc);
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    __syncthreads();
-    if (p.geglu_D > 0) {
-        // activations.py GEGLU.forward: hidden * gelu(gate).  Wave (wm,0) staged the 80 hidden columns and
-        // (wm,1) the 80 gate columns of the same 64 rows (fp16, as the reference's projection output);
-        // each of the two waves finishes 32 of those rows.
-        const __half* hs = (const __half*)smem_raw + (wm * 2 + 0) * (WM * EPI_LD);
-        const __half* gs = (const __half*)smem_raw + (wm * 2 + 1) * (WM * EPI_LD);
-        const int nout0 = tile_n * WN;
-        for (int q = lane; q < 32 * (WN / 8); q += 64) {
-            int row = wn * 32 + q / (WN / 8), ch = q % (WN / 8);
-            int m = gm0 + row, n = nout0 + ch * 8;
-            if (m >= p.M || n >= p.geglu_D) continue;
-            half8 hv = *(const half8*)(hs + row * EPI_LD + ch * 8);
-            half8 gv = *(const half8*)(gs + row * EPI_LD + ch * 8);
-            half8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float g = (float)gv[e];
-                float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752f));
-                o[e] = (_Float16)((float)hv[e] * ge);
-            }
-            if (n + 8 <= p.geglu_D) {
-                *(half8*)(p.out + (long long)m * p.ldc + n) = o;
-            } else {
-                for (int e = 0; e < 8 && n + e < p.geglu_D; ++e) ((_Float16*)p.out)[(long long)m * p.ldc + n + e] = o[e];
-            }
-        }
-        return;
-    }
-    // 64 rows x 10 chunks of 8 halfs per wavefront
-#pragma unroll 2
-    for (int q = lane; q < WM * (WN / 8); q += 64) {
-        int row = q / (WN / 8), ch = q - row * (WN / 8);
-        int m = gm0 + row, n = gn0 + ch * 8;
-        if (m >= p.M || n >= p.N) continue;
-        half8 v = *(const half8*)(st + row * EPI_LD + ch * 8);
-        if (p.residual || p.aux) {
-            float f[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
-            if (p.residual) {
-                half8 rv = *(const half8*)(p.residual + (long long)m * p.ldr + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] += p.s_res * (float)rv[e];
-            }
-            if (p.aux) {
-                half8 av = *(const half8*)(p.aux + (long long)m * p.ldaux + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] += p.s_aux * (float)av[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (_Float16)f[e];
-        }
-        if (n + 8 <= p.N) {
-            *(half8*)(p.out + (long long)m * p.ldc + n) = v;
-        } else {
-            for (int e = 0; e < 8 && n + e < p.N; ++e) ((_Float16*)p.out)[(long long)m * p.ldc + n + e] = v[e];
-        }
-    }
+    gemm_epilogue(p, acc, smem_raw, lane, wv, wm, wn, m0, n0, tile_n);
 }
 
-int g_tile_bm = 0;   // 0 = heuristic, else forced 128 / 256 (syn3r_gemm_set_tile, tuning only)
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA pipelined variant (default).  global_load_lds (16 B per lane, per-lane source address = an
+// im2col gather for the convolutions, a zero page for padding / out-of-range rows) writes straight into a
+// 3-stage LDS ring; a counted s_waitcnt vmcnt leaves the next stage's DMA in flight across ONE raw
+// s_barrier per k-tile, so two k-tiles (104 KB per CU) of loads are always outstanding and no VGPRs or
+// ds_write instructions are spent on staging.  The LDS image is lane-linear per wave-instruction (8 rows x
+// 128 B), so the XOR swizzle is applied to the per-lane SOURCE chunk and undone by the fragment reads.
+// hipcc would put s_waitcnt vmcnt(0) in front of any ds_read it can see while a DMA is pending, so the
+// fragment reads are inline asm (ds_read_b128 + counted lgkmcnt, operands tied through "+v").
+__device__ __half g_zero_page[64];   // zero-initialised: source of padded chunks
+
+constexpr int DMA_STAGES = 3;
+constexpr int DMA_A_BYTES = 256 * BK * 2;                 // 32768
+constexpr int DMA_B_BYTES = BN * BK * 2;                  // 20480
+constexpr int DMA_STAGE_BYTES = DMA_A_BYTES + DMA_B_BYTES;  // 53248
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+#define DS_READ128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+
+template <int MODE>
+__global__ void __launch_bounds__(512, 2) k_gemm_dma(GemmParams p) {
+    constexpr int BM = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const unsigned bid = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- DMA assignment: lane -> (row within an 8-row piece, destination slot); source chunk un-swizzled
+    const int prow = lane >> 3;
+    const int csrc = (lane & 7) ^ prow;                 // source 16-byte chunk that lands in slot (lane & 7)
+    const __half* zero = g_zero_page;
+    const __half* a_base[4];
+    int a_n[4], a_y[4], a_x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + wv * 32 + i * 8 + prow;
+        bool ok = m < p.M;
+        int mc = ok ? m : p.M - 1;
+        if constexpr (MODE == MODE_DENSE) {
+            a_base[i] = p.A + (long long)mc * p.lda + csrc * 8;
+            a_n[i] = a_y[i] = a_x[i] = 0;
+        } else if constexpr (MODE == MODE_CONV2D) {
+            int hw = p.Ho * p.Wo;
+            a_n[i] = mc / hw;
+            int r = mc - a_n[i] * hw;
+            a_y[i] = r / p.Wo;
+            a_x[i] = r - a_y[i] * p.Wo;
+            a_base[i] = p.A + csrc * 8;
+        } else {
+            a_y[i] = (mc / p.HW) % p.F;
+            a_n[i] = a_x[i] = 0;
+            a_base[i] = p.A + (long long)mc * p.Cin + csrc * 8;
+        }
+    }
+    const int nb = wv < 4 ? 3 : 2;                      // B pieces issued by this wavefront (20 in total)
+    const int b_first = wv < 4 ? wv * 3 : 12 + (wv - 4) * 2;
+    const __half* b_base[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int n = n0 + (b_first + j) * 8 + prow;
+        b_base[j] = (j < nb && n < p.N) ? p.W + (long long)n * p.K + csrc * 8 : nullptr;
+    }
+    const int cpb = (MODE == MODE_DENSE) ? 1 : p.Cin / BK;
+
+    auto issue_stage = [&](int kt, int buf) {
+        char* st = smem_raw + buf * DMA_STAGE_BYTES;
+        if constexpr (MODE == MODE_DENSE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_base[i] + kt * BK), (lds_void_t*)(st + (wv * 4 + i) * 1024), 16, 0, 0);
+        } else if constexpr (MODE == MODE_CONV2D) {
+            const int tap = kt / cpb, c0 = (kt - tap * cpb) * BK;
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const int Hg = p.ups ? p.Hi * 2 : p.Hi, Wg = p.ups ? p.Wi * 2 : p.Wi;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int yy = a_y[i] * p.stride + dy, xx = a_x[i] * p.stride + dx;
+                bool ok = yy >= 0 && yy < Hg && xx >= 0 && xx < Wg;
+                if (p.ups) { yy >>= 1; xx >>= 1; }
+                long long off = (((long long)a_n[i] * p.Hi + yy) * p.Wi + xx) * p.Cin + c0;
+                const __half* src = ok ? a_base[i] + off : zero;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wv * 4 + i) * 1024), 16, 0, 0);
+            }
+        } else {
+            const int tap = kt / cpb, c0 = (kt - tap * cpb) * BK;
+            const int df = tap - 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int ff = a_y[i] + df;
+                bool ok = ff >= 0 && ff < p.F;
+                const __half* src = ok ? a_base[i] + (long long)df * p.HW * p.Cin + c0 : zero;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wv * 4 + i) * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j < nb) {
+                const __half* src = b_base[j] ? b_base[j] + kt * BK : zero;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + DMA_A_BYTES + (b_first + j) * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    float4v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = p.K / BK;
+    issue_stage(0, 0);
+    if (nkt > 1) issue_stage(1, 1);
+
+    // fragment addressing (byte offsets inside a stage)
+    const int fr = lane & 15, fq = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const unsigned a_row = (unsigned)((wm * WM + fr) * 128);
+    const unsigned b_row = (unsigned)(DMA_A_BYTES + (wn * WN + fr) * 128);
+    const unsigned sw0 = (unsigned)(((0 + fq) ^ (fr & 7)) << 4), sw1 = (unsigned)(((4 + fq) ^ (fr & 7)) << 4);
+
+    int buf = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        // stage kt has landed once at most one later stage (6..7 loads of this wavefront) is still in flight
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkt) {
+            int nbuf = buf + 2; if (nbuf >= DMA_STAGES) nbuf -= DMA_STAGES;
+            issue_stage(kt + 2, nbuf);      // overwrites the stage read in iteration kt-1 (all waves are past it)
+        }
+        const unsigned sb = lds0 + (unsigned)buf * DMA_STAGE_BYTES;
+        half8 a0[TM], b0[TN], a1[TM], b1[TN];
+        {
+            const unsigned aa = sb + a_row + sw0, ba = sb + b_row + sw0;
+            DS_READ128(a0[0], aa, 0); DS_READ128(a0[1], aa, 2048); DS_READ128(a0[2], aa, 4096); DS_READ128(a0[3], aa, 6144);
+            DS_READ128(b0[0], ba, 0); DS_READ128(b0[1], ba, 2048); DS_READ128(b0[2], ba, 4096); DS_READ128(b0[3], ba, 6144);
+            DS_READ128(b0[4], ba, 8192);
+        }
+        {
+            const unsigned aa = sb + a_row + sw1, ba = sb + b_row + sw1;
+            DS_READ128(a1[0], aa, 0); DS_READ128(a1[1], aa, 2048); DS_READ128(a1[2], aa, 4096); DS_READ128(a1[3], aa, 6144);
+            DS_READ128(b1[0], ba, 0); DS_READ128(b1[1], ba, 2048); DS_READ128(b1[2], ba, 4096); DS_READ128(b1[3], ba, 6144);
+            DS_READ128(b1[4], ba, 8192);
+        }
+        asm volatile("s_waitcnt lgkmcnt(9)"
+                     : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(b0[4]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // keep the second wait behind the first MFMA group
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]), "+v"(b1[4]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+        if (++buf == DMA_STAGES) buf = 0;
+    }
+    __syncthreads();   // every wavefront is done reading the ring before the epilogue reuses it
+    gemm_epilogue(p, acc, smem_raw, lane, wv, wm, wn, m0, n0, tile_n);
+}
+
+template <int MODE>
+int launch_dma(const GemmParams& p, hipStream_t stream) {
+    constexpr size_t lds = (size_t)DMA_STAGES * DMA_STAGE_BYTES;   // 159,744 B
+    static_assert(8 * WM * EPI_LD * sizeof(__half) <= lds, "epilogue staging must fit in the ring");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_dma<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_dma)");
+        attr_set = true;
+    }
+    int tiles = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+    SYN3R_LAUNCH(k_gemm_dma<MODE>, dim3(tiles), dim3(512), lds, stream, p);
+    SYN3R_LAUNCH_CHECK("gemm_dma launch");
+    return SYN3R_OK;
+}
+
+int g_tile_bm = 0;   // 0 = LDS-DMA kernel (default); 128 / 256 = register-staged kernel of that block height
 
 template <int MODE, int BM>
 int launch_bm(const GemmParams& p, hipStream_t stream) {
@@ -325,8 +518,8 @@ int launch_bm(const GemmParams& p, hipStream_t stream) {
 
 template <int MODE>
 int launch(const GemmParams& p, hipStream_t stream) {
-    int bm = g_tile_bm ? g_tile_bm : 128;
-    return bm == 256 ? launch_bm<MODE, 256>(p, stream) : launch_bm<MODE, 128>(p, stream);
+    if (g_tile_bm == 0) return launch_dma<MODE>(p, stream);
+    return g_tile_bm == 256 ? launch_bm<MODE, 256>(p, stream) : launch_bm<MODE, 128>(p, stream);
 }
 
 int check_common(const GemmParams& p, const char* who) {
