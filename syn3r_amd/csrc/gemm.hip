@@ -72,27 +72,56 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
     const int fr = lane & 15, fq = lane >> 4;
     __half* st = (__half*)smem_raw + wv * (WM * EPI_LD);
     const int gm0 = m0 + wm * WM, gn0 = n0 + wn * WN;
+    // The MFMAs are issued with the weight fragment as the A operand, so acc[i][j][r] is
+    // C[row i*16 + (lane&15)][col j*16 + (lane>>4)*4 + r]: four CONSECUTIVE output columns per lane ->
+    // one 8-byte LDS store per accumulator tile (20 per lane).
+    typedef _Float16 half4e __attribute__((ext_vector_type(4)));
+    float bias4[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        int col = j * 16 + fr;
-        int n = gn0 + col;
-        float bv = (p.bias && n < p.N) ? __half2float(p.bias[n]) : 0.0f;
+        const int n = gn0 + j * 16 + fq * 4;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int r = 0; r < 4; ++r) bias4[j][r] = 0.0f;
+        if (p.bias) {
+            if (n + 4 <= p.N) {
+                half4e b = *(const half4e*)(p.bias + n);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int row = i * 16 + fq * 4 + r;
-                float v = acc[i][j][r] + bv;
-                if (p.rowvec) {
-                    int m = gm0 + row;
-                    // rows_per_vec > 0: one vector per block of rows; < 0: vector index = m mod |rows_per_vec|
-                    if (m < p.M && n < p.N) {
-                        int vi = p.rows_per_vec > 0 ? m / p.rows_per_vec : m % (-p.rows_per_vec);
-                        v += __half2float(p.rowvec[(long long)vi * p.ldrv + n]);
-                    }
-                }
-                st[row * EPI_LD + col] = __float2half_rn(v * p.s_acc);
+                for (int r = 0; r < 4; ++r) bias4[j][r] = (float)b[r];
+            } else {
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) bias4[j][r] = __half2float(p.bias[n + r]);
             }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = i * 16 + fr;
+        const int m = gm0 + row;
+        const __half* rv = nullptr;
+        if (p.rowvec && m < p.M) {
+            // rows_per_vec > 0: one vector per block of rows; < 0: vector index = m mod |rows_per_vec|
+            int vi = p.rows_per_vec > 0 ? m / p.rows_per_vec : m % (-p.rows_per_vec);
+            rv = p.rowvec + (long long)vi * p.ldrv;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = j * 16 + fq * 4;
+            const int n = gn0 + col;
+            float add[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) add[r] = bias4[j][r];
+            if (rv) {
+                if (n + 4 <= p.N) {
+                    half4e t = *(const half4e*)(rv + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) add[r] += (float)t[r];
+                } else {
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) add[r] += __half2float(rv[n + r]);
+                }
+            }
+            half4e o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (_Float16)((acc[i][j][r] + add[r]) * p.s_acc);
+            *(half4e*)(st + row * EPI_LD + col) = o;
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -302,7 +331,7 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm(GemmParams p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nkt) store_tile(cur ^ 1);
         __syncthreads();
@@ -467,14 +496,14 @@ __global__ void __launch_bounds__(512, 2) k_gemm_dma(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0[j], a0[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);   // keep the second wait behind the first MFMA group
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]), "+v"(b1[4]));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], a1[i], acc[i][j], 0, 0, 0);
         if (++buf == DMA_STAGES) buf = 0;
     }
     __syncthreads();   // every wavefront is done reading the ring before the epilogue reuses it
