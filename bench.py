@@ -56,7 +56,9 @@ class RasterLoop:
 
     def __init__(self, args, dev):
         from syn3r_amd import synthetic as RO
+        from syn3r_amd import raster
         from syn3r_amd.raster import GaussianRasterizationSettings, GaussianRasterizer
+        raster.set_pair_count_mode("async")      # training-loop mode: no host round trip per render (checked below)
         m, s, q, o, sh = RO.synthetic_gaussians(args.gaussians, seed=args.seed)
         view, proj, campos, tfx, tfy = RO.look_at_camera(args.height, args.width)
         f = lambda t: t.to(dev).requires_grad_(True)
@@ -191,6 +193,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        from syn3r_amd import raster as _r
+        _r.flush_pair_checks()                     # every render's pair list was complete (raises otherwise)
         barrier()
         dt = time.perf_counter() - t0
     log(f"timed region done: {dt:.3f} s")

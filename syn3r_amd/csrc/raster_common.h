@@ -38,7 +38,7 @@ static_assert(sizeof(Splat) == 48, "Splat must be 48 bytes");
 
 // Geometry state carved from the caller's buffer (all arrays 256-byte aligned).
 struct GeomState {
-    unsigned* header;        // [0] = number of (Gaussian, tile) pairs
+    unsigned* header;        // [0] = number of (Gaussian, tile) pairs, [1] = 1 if a render ran out of pair capacity
     float* depths;           // [N]
     float* means2D;          // [N,2]
     float* cov3D;            // [N,6]
@@ -72,7 +72,8 @@ size_t sort_scratch_bytes(size_t n);
 int exclusive_scan_u32(const unsigned* in, unsigned* out, size_t n, unsigned* total_out, void* scratch,
                        hipStream_t stream);
 int radix_sort_pairs(unsigned long long* keys_a, unsigned* vals_a, unsigned long long* keys_b, unsigned* vals_b,
-                     size_t n, int nbits, void* scratch, hipStream_t stream, int* result_in_b);
+                     size_t n, int nbits, void* scratch, hipStream_t stream, int* result_in_b,
+                     const unsigned* n_dev = nullptr);
 
 size_t geom_bytes(int N);
 size_t image_bytes(int H, int W);

@@ -244,7 +244,8 @@ __global__ void __launch_bounds__(256) k_dup_keys(int N, const float* __restrict
                                                   const unsigned* __restrict__ offsets,
                                                   const int* __restrict__ radii, int gx, int gy,
                                                   unsigned long long* __restrict__ keys,
-                                                  unsigned* __restrict__ vals) {
+                                                  unsigned* __restrict__ vals, unsigned cap,
+                                                  unsigned* __restrict__ header) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     int r = radii[i];
@@ -256,14 +257,21 @@ __global__ void __launch_bounds__(256) k_dup_keys(int N, const float* __restrict
     for (int y = y0; y < y1; ++y)
         for (int x = x0; x < x1; ++x) {
             unsigned long long key = ((unsigned long long)(unsigned)(y * gx + x) << 32) | dbits;
-            keys[off] = key;
-            vals[off] = (unsigned)i;
+            if (off < cap) {
+                keys[off] = key;
+                vals[off] = (unsigned)i;
+            } else {
+                header[1] = 1u;   // capacity overflow (asynchronous mode only): the caller re-renders
+            }
             ++off;
         }
 }
 
-__global__ void __launch_bounds__(256) k_tile_ranges(long long P, const unsigned long long* __restrict__ keys,
+__global__ void __launch_bounds__(256) k_tile_ranges(long long P_cap, const unsigned* __restrict__ header,
+                                                     const unsigned long long* __restrict__ keys,
                                                      uint2* __restrict__ ranges) {
+    long long P = (long long)header[0];
+    if (P > P_cap) P = P_cap;
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     unsigned cur = (unsigned)(keys[i] >> 32);
@@ -401,7 +409,9 @@ extern "C" int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, cons
     fill_camera(cam, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W);
     SYN3R_LAUNCH(k_preprocess, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
                        scales, rotations, opacities, shs, confidence, scale_modifier, cam, radii, g);
-    int rc = exclusive_scan_u32(g.tiles_touched, g.point_offsets, (size_t)N, g.header, g.scan_scratch, stream);
+    int rc = check_hip(hipMemsetAsync(g.header, 0, 16, stream), "memset header");
+    if (rc) return rc;
+    rc = exclusive_scan_u32(g.tiles_touched, g.point_offsets, (size_t)N, g.header, g.scan_scratch, stream);
     if (rc) return rc;
     SYN3R_LAUNCH_CHECK("raster_preprocess launch");
     if (num_rendered_host) {
@@ -438,15 +448,17 @@ extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const i
     if (rc) return rc;
     unsigned* point_list = bn.vals_a;
     if (P > 0) {
+        // P is the pair CAPACITY of the binning buffer; the live count is read from the geometry header on
+        // the device, so the caller may pass an estimate and skip the device->host read of the exact count
         SYN3R_LAUNCH(k_dup_keys, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, g.means2D, g.depths,
-                           g.point_offsets, radii, gx, gy, bn.keys_a, bn.vals_a);
+                           g.point_offsets, radii, gx, gy, bn.keys_a, bn.vals_a, (unsigned)P, g.header);
         int in_b = 0;
         rc = radix_sort_pairs(bn.keys_a, bn.vals_a, bn.keys_b, bn.vals_b, (size_t)P, 32 + bits_for((unsigned)tiles),
-                              bn.sort_scratch, stream, &in_b);
+                              bn.sort_scratch, stream, &in_b, g.header);
         if (rc) return rc;
         const unsigned long long* keys = in_b ? bn.keys_b : bn.keys_a;
         point_list = in_b ? bn.vals_b : bn.vals_a;
-        SYN3R_LAUNCH(k_tile_ranges, dim3(ceil_div(P, 256)), dim3(256), 0, stream, P, keys, im.ranges);
+        SYN3R_LAUNCH(k_tile_ranges, dim3(ceil_div(P, 256)), dim3(256), 0, stream, P, g.header, keys, im.ranges);
     }
     SYN3R_LAUNCH(k_render, dim3((unsigned)tiles), dim3(kTilePix), 0, stream, H, W, gx, gy, im.ranges, point_list,
                        g.splats, bg[0], bg[1], bg[2], im.n_contrib, im.final_T, out_color, out_depth, out_alpha);

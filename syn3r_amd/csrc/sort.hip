@@ -132,8 +132,17 @@ constexpr int kSortRounds = 16;                               // keys per thread
 constexpr int kSortChunk = kSortThreads * kSortRounds;        // 4096 keys per block
 constexpr int kWaveChunk = 64 * kSortRounds;                  // 1024 keys per wave, contiguous
 
-__global__ void __launch_bounds__(kSortThreads) k_hist(const unsigned long long* __restrict__ keys, size_t n,
-                                                      int shift, unsigned* __restrict__ hist, unsigned nblocks) {
+// n_dev != nullptr: the element count lives on the device (clamped to the capacity n)
+__device__ __forceinline__ size_t live_count(size_t n, const unsigned* __restrict__ n_dev) {
+    if (!n_dev) return n;
+    size_t d = *n_dev;
+    return d < n ? d : n;
+}
+
+__global__ void __launch_bounds__(kSortThreads) k_hist(const unsigned long long* __restrict__ keys, size_t n_cap,
+                                                      const unsigned* __restrict__ n_dev, int shift,
+                                                      unsigned* __restrict__ hist, unsigned nblocks) {
+    const size_t n = live_count(n_cap, n_dev);
     __shared__ unsigned h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -150,8 +159,10 @@ __global__ void __launch_bounds__(kSortThreads) k_hist(const unsigned long long*
 __global__ void __launch_bounds__(kSortThreads) k_scatter(const unsigned long long* __restrict__ keys_in,
                                                          const unsigned* __restrict__ vals_in,
                                                          unsigned long long* __restrict__ keys_out,
-                                                         unsigned* __restrict__ vals_out, size_t n, int shift,
+                                                         unsigned* __restrict__ vals_out, size_t n_cap,
+                                                         const unsigned* __restrict__ n_dev, int shift,
                                                          const unsigned* __restrict__ bases, unsigned nblocks) {
+    const size_t n = live_count(n_cap, n_dev);
     __shared__ unsigned wh[kSortWaves][256];   // per-wave digit counts, then running offsets
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < kSortWaves * 256; i += kSortThreads) (&wh[0][0])[i] = 0;
@@ -223,7 +234,7 @@ size_t sort_scratch_bytes(size_t n) {
 // Sorts bits [0, nbits) of the keys; nbits is rounded up to a multiple of 8.
 // Ping-pongs between (keys_a, vals_a) and (keys_b, vals_b); returns which buffer holds the result.
 int radix_sort_pairs(unsigned long long* keys_a, unsigned* vals_a, unsigned long long* keys_b, unsigned* vals_b,
-                     size_t n, int nbits, void* scratch, hipStream_t stream, int* result_in_b) {
+                     size_t n, int nbits, void* scratch, hipStream_t stream, int* result_in_b, const unsigned* n_dev) {
     *result_in_b = 0;
     if (n == 0) return SYN3R_OK;
     size_t nblocks = (n + kSortChunk - 1) / kSortChunk;
@@ -236,12 +247,12 @@ int radix_sort_pairs(unsigned long long* keys_a, unsigned* vals_a, unsigned long
     unsigned long long* kout = keys_b; unsigned* vout = vals_b;
     for (int p = 0; p < passes; ++p) {
         int shift = 8 * p;
-        SYN3R_LAUNCH(k_hist, dim3((unsigned)nblocks), dim3(kSortThreads), 0, stream, kin, n, shift, hist,
+        SYN3R_LAUNCH(k_hist, dim3((unsigned)nblocks), dim3(kSortThreads), 0, stream, kin, n, n_dev, shift, hist,
                            (unsigned)nblocks);
         int rc = exclusive_scan_u32(hist, hist, 256 * nblocks, nullptr, scan_scratch, stream);
         if (rc) return rc;
         SYN3R_LAUNCH(k_scatter, dim3((unsigned)nblocks), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n,
-                           shift, hist, (unsigned)nblocks);
+                           n_dev, shift, hist, (unsigned)nblocks);
         unsigned long long* tk = kin; kin = kout; kout = tk;
         unsigned* tv = vin; vin = vout; vout = tv;
     }
@@ -271,5 +282,5 @@ extern "C" int syn3r_sort_pairs(unsigned long long* keys, unsigned* vals, unsign
         return SYN3R_E_WORKSPACE;
     }
     return radix_sort_pairs(keys, vals, keys_tmp, vals_tmp, (size_t)n, nbits, workspace, (hipStream_t)stream,
-                            result_in_tmp);
+                            result_in_tmp, nullptr);
 }

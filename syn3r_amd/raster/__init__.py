@@ -50,6 +50,48 @@ def _host16(m: torch.Tensor):
     return _host_floats(m)
 
 
+# ---- pair-count mode ------------------------------------------------------------------------------------
+# "sync"  (default): read the exact number of (Gaussian, tile) pairs back after the projection stage, as the
+#                    published implementation does, and size the binning buffer exactly.
+# "async" (opt-in, training loops): size the binning buffer from the previous call of the same shape (x1.5),
+#                    let the kernels read the live count on the device, and check the overflow flag of call k
+#                    at call k+1 (or at `flush_pair_checks()`): a call that overflowed raises then — its image
+#                    was built from a truncated pair list.  Removes the one host<->device round trip per render.
+_pair_mode = "sync"
+_capacity: dict = {}
+_pending: dict = {}
+
+
+def set_pair_count_mode(mode: str) -> None:
+    global _pair_mode
+    if mode not in ("sync", "async"):
+        raise ValueError("pair-count mode must be 'sync' or 'async'")
+    _pair_mode = mode
+
+
+def _check_pending(key, wait: bool):
+    item = _pending.get(key)
+    if item is None:
+        return
+    evt, host, cap = item
+    if not wait and not evt.query():
+        evt.synchronize()
+    else:
+        evt.synchronize()
+    del _pending[key]
+    P, overflow = int(host[0]), int(host[1])
+    _capacity[key] = max(_capacity.get(key, 0), int(P * 1.5) + 4096)
+    if overflow or P > cap:
+        raise L.Syn3rError(f"rasteriser (async pair-count mode): the previous render needed {P} pairs but the binning "
+                           f"buffer held {cap}; that image is invalid — capacity has been raised, render again")
+
+
+def flush_pair_checks() -> None:
+    """Verify the overflow flag of every render still unchecked (call at the end of a training loop)."""
+    for key in list(_pending):
+        _check_pending(key, wait=True)
+
+
 class _Rasterize(torch.autograd.Function):
     debug_state = None
 
@@ -76,13 +118,22 @@ class _Rasterize(torch.autograd.Function):
         geom = torch.empty(lib.syn3r_raster_geom_bytes(N), dtype=torch.uint8, device=dev)
         image = torch.empty(lib.syn3r_raster_image_bytes(H, W), dtype=torch.uint8, device=dev)
         radii = torch.empty(N, dtype=torch.int32, device=dev)
+        key = (dev.index, N, H, W)
+        use_async = _pair_mode == "async" and not s.debug
+        if use_async:
+            _check_pending(key, wait=False)
+        use_async = use_async and key in _capacity
         P = C.c_longlong(0)
         rc = lib.syn3r_raster_preprocess(N, int(s.sh_degree), M, L.ptr(m3), L.ptr(sc), L.ptr(ro), L.ptr(op), L.ptr(sh),
                                          L.ptr(cf), float(s.scale_modifier), view, proj, campos, float(s.tanfovx),
-                                         float(s.tanfovy), H, W, L.ptr(radii), L.ptr(geom), geom.numel(), C.byref(P),
-                                         stream)
+                                         float(s.tanfovy), H, W, L.ptr(radii), L.ptr(geom), geom.numel(),
+                                         None if use_async else C.byref(P), stream)
         L.check(rc, "syn3r_raster_preprocess")
-        P = int(P.value)
+        if use_async:
+            P = _capacity[key]                          # capacity; the kernels read the live count on the device
+        else:
+            P = int(P.value)
+            _capacity[key] = max(_capacity.get(key, 0), int(P * 1.5) + 4096)
         binning = torch.empty(lib.syn3r_raster_binning_bytes(P), dtype=torch.uint8, device=dev)
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
@@ -92,6 +143,12 @@ class _Rasterize(torch.autograd.Function):
                                      binning.numel(), L.ptr(image), image.numel(), P, L.ptr(color), L.ptr(depth),
                                      L.ptr(alpha), C.byref(plist), stream)
         L.check(rc, "syn3r_raster_render")
+        if use_async:
+            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host.copy_(geom[:8].view(torch.int32), non_blocking=True)
+            evt = torch.cuda.Event()
+            evt.record(torch.cuda.current_stream(dev))
+            _pending[key] = (evt, host, P)
         if s.debug:   # expose the binning / image state (tile ranges, sorted list) to the parity tests
             tiles = ((W + 15) // 16) * ((H + 15) // 16)
             a256 = lambda x: (x + 255) & ~255

@@ -149,3 +149,34 @@ def test_rasterizer_rejects_bad_arguments(gpu):
         r(f(sc["m"]), None, f(sc["o"]), colors_precomp=f(sc["m"]), scales=f(sc["s"]), rotations=f(sc["q"]))
     with pytest.raises(ValueError):
         r(f(sc["m"]), None, f(sc["o"])[:10], shs=f(sc["sh"]), scales=f(sc["s"]), rotations=f(sc["q"]))
+
+
+def test_async_pair_count_mode_matches_sync(gpu):
+    """Training-loop mode: binning capacity from the previous call, live count read on the device.
+    Same image, and an undersized capacity is reported at the next check."""
+    from syn3r_amd import raster
+    sc = scene(1200, 64, 96, seed=21)
+    (c_sync, _, d_sync, a_sync), _, _ = hip_render(sc, gpu)
+    raster.set_pair_count_mode("async")
+    try:
+        key = (gpu.index, sc["N"], sc["H"], sc["W"])
+        raster._capacity.pop(key, None)
+        outs = []
+        for _ in range(3):                      # first call sizes exactly, the next two run without the read-back
+            from syn3r_amd.raster import GaussianRasterizationSettings, GaussianRasterizer
+            f = lambda t: t.to(gpu, torch.float32)
+            st = GaussianRasterizationSettings(sc["H"], sc["W"], sc["tfx"], sc["tfy"], f(sc["bg"]), 1.0, f(sc["view"]),
+                                               f(sc["proj"]), 3, f(sc["campos"]), False, False)
+            outs.append(GaussianRasterizer(st)(f(sc["m"]), None, f(sc["o"]), shs=f(sc["sh"]), scales=f(sc["s"]),
+                                               rotations=f(sc["q"])))
+        raster.flush_pair_checks()
+        for c, _, d, a in outs:
+            assert torch.equal(c, c_sync) and torch.equal(d, d_sync) and torch.equal(a, a_sync)
+        raster._capacity[key] = 16               # force an overflow
+        GaussianRasterizer(st)(f(sc["m"]), None, f(sc["o"]), shs=f(sc["sh"]), scales=f(sc["s"]), rotations=f(sc["q"]))
+        with pytest.raises(Exception):
+            raster.flush_pair_checks()
+        assert raster._capacity[key] > 16
+    finally:
+        raster._pending.clear()
+        raster.set_pair_count_mode("sync")
