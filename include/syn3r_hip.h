@@ -53,6 +53,9 @@ const char* syn3r_arch(void);
  * line per kernel into buf and clears the trace.
  */
 int syn3r_trace_enable(int on);
+/* restrict the tracer to kernels whose name contains one of the comma-separated substrings ("" = all):
+ * two event records per launch cost a few microseconds, which matters for 30-microsecond kernels */
+int syn3r_trace_filter(const char* substrings);
 int syn3r_trace_report(char* buf, size_t cap);
 
 /* ------------------------------------------------------------------------

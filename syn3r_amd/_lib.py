@@ -27,6 +27,7 @@ SIGNATURES = {
     "syn3r_version": (c_i, []),
     "syn3r_arch": (C.c_char_p, []),
     "syn3r_trace_enable": (c_i, [c_i]),
+    "syn3r_trace_filter": (c_i, [C.c_char_p]),
     "syn3r_trace_report": (c_i, [C.c_char_p, c_sz]),
     "syn3r_inverse_warp_workspace_bytes": (c_sz, [c_i]),
     "syn3r_inverse_warp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i,
@@ -165,7 +166,11 @@ class kernel_trace:
     """Context manager: per-kernel HIP-event timing of everything launched inside.
     `.result` maps kernel name -> (calls, total_ms)."""
 
+    def __init__(self, only: str = ""):
+        self.only = only
+
     def __enter__(self):
+        load().syn3r_trace_filter(self.only.encode())
         load().syn3r_trace_enable(1)
         self.result = {}
         return self

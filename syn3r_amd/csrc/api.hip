@@ -27,6 +27,7 @@ namespace {
 struct Span { std::string name; hipEvent_t a, b; };
 std::mutex g_mu;
 bool g_on = false;
+std::string g_filter;   // comma-separated substrings; empty = every kernel
 std::vector<Span> g_spans;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t get_event() {
@@ -38,21 +39,43 @@ hipEvent_t get_event() {
 }  // namespace
 
 bool trace_on() { return g_on; }
+static bool wanted(const char* name) {
+    if (g_filter.empty()) return true;
+    size_t pos = 0;
+    while (pos <= g_filter.size()) {
+        size_t end = g_filter.find(',', pos);
+        if (end == std::string::npos) end = g_filter.size();
+        if (end > pos && strstr(name, g_filter.substr(pos, end - pos).c_str())) return true;
+        pos = end + 1;
+    }
+    return false;
+}
+static thread_local bool t_open = false;
+
 void trace_begin(const char* name, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_mu);
+    t_open = wanted(name);
+    if (!t_open) return;
     Span s{name, get_event(), get_event()};
     hipEventRecord(s.a, stream);
     g_spans.push_back(s);
 }
 void trace_end(hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_spans.empty()) hipEventRecord(g_spans.back().b, stream);
+    if (t_open && !g_spans.empty()) hipEventRecord(g_spans.back().b, stream);
+    t_open = false;
 }
 }  // namespace syn3r
 
 extern "C" int syn3r_trace_enable(int on) {
     std::lock_guard<std::mutex> lk(syn3r::g_mu);
     syn3r::g_on = on != 0;
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_trace_filter(const char* substrings) {
+    std::lock_guard<std::mutex> lk(syn3r::g_mu);
+    syn3r::g_filter = substrings ? substrings : "";
     return SYN3R_OK;
 }
 

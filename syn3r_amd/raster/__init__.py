@@ -70,20 +70,21 @@ def set_pair_count_mode(mode: str) -> None:
 
 
 def _check_pending(key, wait: bool):
-    item = _pending.get(key)
-    if item is None:
-        return
-    evt, host, cap = item
-    if not wait and not evt.query():
+    """Examine finished renders of this shape (all of them if `wait`), oldest first; never blocks the host
+    unless asked to or more than 8 renders are unchecked."""
+    queue = _pending.get(key)
+    while queue:
+        evt, host, cap = queue[0]
+        if not (wait or len(queue) > 8 or evt.query()):
+            break
         evt.synchronize()
-    else:
-        evt.synchronize()
-    del _pending[key]
-    P, overflow = int(host[0]), int(host[1])
-    _capacity[key] = max(_capacity.get(key, 0), int(P * 1.5) + 4096)
-    if overflow or P > cap:
-        raise L.Syn3rError(f"rasteriser (async pair-count mode): the previous render needed {P} pairs but the binning "
-                           f"buffer held {cap}; that image is invalid — capacity has been raised, render again")
+        queue.pop(0)
+        P, overflow = int(host[0]), int(host[1])
+        _capacity[key] = max(_capacity.get(key, 0), int(P * 1.5) + 4096)
+        if overflow or P > cap:
+            queue.clear()
+            raise L.Syn3rError(f"rasteriser (async pair-count mode): a previous render needed {P} pairs but the binning "
+                               f"buffer held {cap}; that image is invalid — capacity has been raised, render again")
 
 
 def flush_pair_checks() -> None:
@@ -148,7 +149,7 @@ class _Rasterize(torch.autograd.Function):
             host.copy_(geom[:8].view(torch.int32), non_blocking=True)
             evt = torch.cuda.Event()
             evt.record(torch.cuda.current_stream(dev))
-            _pending[key] = (evt, host, P)
+            _pending.setdefault(key, []).append((evt, host, P))
         if s.debug:   # expose the binning / image state (tile ranges, sorted list) to the parity tests
             tiles = ((W + 15) // 16) * ((H + 15) // 16)
             a256 = lambda x: (x + 255) & ~255

@@ -1,0 +1,71 @@
+"""BASELINE.json full-size configurations through size-independent properties (the oracle cannot run these
+sizes in seconds): 200k Gaussians at 1920x1080, and the SVD-XT UNet at [2,14,8,72,128]."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_raster_200k_1080p_properties(gpu):
+    from syn3r_amd import synthetic as SY
+    from syn3r_amd.raster import GaussianRasterizationSettings, GaussianRasterizer, _Rasterize
+    N, H, W = 200_000, 1080, 1920
+    m, s, q, o, sh = SY.synthetic_gaussians(N, seed=1234)
+    view, proj, campos, tfx, tfy = SY.look_at_camera(H, W)
+    f = lambda t: t.to(gpu).requires_grad_(True)
+    p = [f(m), f(s), f(q), f(o), f(sh)]
+    st = GaussianRasterizationSettings(H, W, tfx, tfy, torch.zeros(3, device=gpu), 1.0, view.to(gpu), proj.to(gpu), 3,
+                                       campos.to(gpu), False, True)
+    color, radii, depth, alpha = GaussianRasterizer(st)(p[0], torch.zeros(N, 3, device=gpu), p[3], shs=p[4],
+                                                        scales=p[1], rotations=p[2])
+    dbg = _Rasterize.debug_state
+    P = dbg["num_rendered"]
+    assert P > N                                     # every visible Gaussian touches at least one tile
+    # tile ranges partition the sorted list; inside a tile depths are non-decreasing (sortedness)
+    ranges = dbg["ranges"].cpu().numpy().astype(np.int64)
+    plist = dbg["point_list"].cpu().numpy()
+    depths = dbg["depths"].cpu().numpy()
+    nonempty = ranges[ranges[:, 1] > ranges[:, 0]]
+    assert nonempty[:, 1].max() == P and (nonempty[:, 1] - nonempty[:, 0]).sum() == P
+    d = depths[plist]
+    brk = np.zeros(P, bool)
+    brk[nonempty[:, 0]] = True
+    assert np.all((np.diff(d) >= 0) | brk[1:])
+    counts = np.bincount(plist, minlength=N)
+    assert counts.sum() == P and np.array_equal(counts > 0, radii.cpu().numpy() > 0)   # each visible Gaussian is listed
+    # image-space invariants
+    a = alpha.detach()
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 and torch.isfinite(color).all()
+    assert float((depth.detach() >= 0).float().mean()) == 1.0
+    assert float(depth.detach().max()) <= 6.0 + 1e-3          # alpha-weighted z of Gaussians in [2, 6]
+    # linearity of the backward in the incoming gradient
+    g = torch.randn_like(color)
+    grads1 = torch.autograd.grad(color, p, grad_outputs=g, retain_graph=True)
+    grads2 = torch.autograd.grad(color, p, grad_outputs=2.0 * g, retain_graph=False)
+    for g1, g2 in zip(grads1, grads2):
+        assert torch.isfinite(g1).all()
+        scale = g1.abs().max().item() + 1e-20
+        assert (g2 - 2.0 * g1).abs().max().item() <= 2e-3 * scale     # float atomics: order-dependent last bits
+
+
+def test_unet_svd_xt_full_size_properties(gpu):
+    from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel
+    unet = UNetSpatioTemporalConditionModel().init_random(gpu, seed=3)
+    g = torch.Generator(device=gpu).manual_seed(0)
+    x = torch.randn(2, 14, 8, 72, 128, generator=g, device=gpu).half()
+    ehs = torch.randn(2, 1, 1024, generator=g, device=gpu).half()
+    added = torch.tensor([[6.0, 127.0, 0.02]] * 2, device=gpu).half()
+    y1 = unet(x, torch.tensor(1.6378), ehs, added)[0]
+    assert y1.shape == (2, 14, 4, 72, 128) and torch.isfinite(y1).all()
+    y2 = unet(x, torch.tensor(1.6378), ehs, added)[0]
+    assert torch.equal(y1, y2)                                   # no atomics anywhere in the UNet path
+    # identical batch items with identical context give identical outputs (CFG halves are independent then)
+    xs = x[:1].repeat(2, 1, 1, 1, 1)
+    es = ehs[1:].repeat(2, 1, 1)
+    ys = unet(xs, torch.tensor(1.6378), es, added)[0]
+    assert torch.equal(ys[0], ys[1])
+    # B = 1 tile shapes of the guidance pass (40x72 and 48x72 latents)
+    for hh in (40, 48):
+        yt = unet(x[:1, :, :, :hh, :72].contiguous(), torch.tensor(0.5), ehs[:1], added[:1])[0]
+        assert yt.shape == (1, 14, 4, hh, 72) and torch.isfinite(yt).all()
