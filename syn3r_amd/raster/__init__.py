@@ -35,15 +35,19 @@ _host_cache: dict = {}
 
 def _host_floats(m: torch.Tensor):
     """Camera matrices / background live on the GPU in FSGS cameras; the ABI takes them by value.
-    One device->host read per distinct tensor version (cached), not per render call."""
-    key = (m.data_ptr(), m._version, m.device.index, m.numel())
+    One device->host read per tensor OBJECT and version (the cache holds a weak reference to the tensor, so
+    a recycled device address or an in-place update can never alias a stale copy)."""
+    import weakref
+    key = id(m)
     hit = _host_cache.get(key)
-    if hit is None:
-        if len(_host_cache) > 4096:
-            _host_cache.clear()
-        hit = L.host_f32(m.detach().to("cpu", torch.float32).reshape(-1).tolist())
-        _host_cache[key] = hit
-    return hit
+    if hit is not None and hit[0]() is m and hit[1] == m._version:
+        return hit[2]
+    if len(_host_cache) > 1024:
+        for k in [k for k, v in _host_cache.items() if v[0]() is None]:
+            del _host_cache[k]
+    vals = L.host_f32(m.detach().to("cpu", torch.float32).reshape(-1).tolist())
+    _host_cache[key] = (weakref.ref(m), m._version, vals)
+    return vals
 
 
 def _host16(m: torch.Tensor):
