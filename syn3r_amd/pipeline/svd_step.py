@@ -89,5 +89,22 @@ class SvdStepBench:
         flops = self.flops_per_unit[cand[best]] * units
         ach = flops / (ms / 1e3) / 1e12
         return dict(bound="mfma", kernel=best, achieved=round(ach, 1), peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / MFMA_F16_PEAK_TFLOPS, 4), traffic=None, avg_ms=round(ms / calls, 4), calls=calls,
-                    algorithmic_flops_per_unit=self.flops_per_unit)
+                    frac=round(ach / MFMA_F16_PEAK_TFLOPS, 4), traffic=_pmc_traffic(best), avg_ms=round(ms / calls, 4),
+                    calls=calls, algorithmic_flops_per_unit=self.flops_per_unit)
+
+
+def _pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*/traffic.json;
+    bench.py cannot run the profiler on itself).  None if no profile of this kernel is committed."""
+    import json
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[2] / "profiles"
+    for f in sorted(root.glob("r*/traffic.json"), reverse=True):
+        try:
+            rec = json.loads(f.read_text()).get(kernel)
+        except (OSError, ValueError):
+            continue
+        if rec:
+            return dict(hbm_bytes_per_launch=rec["hbm_bytes_per_launch"], source=str(f.relative_to(root.parent)),
+                        note="PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, averaged over the launches of the profiled run")
+    return None
