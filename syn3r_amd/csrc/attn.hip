@@ -68,7 +68,7 @@ struct AttnParams {
 
 constexpr int BQ = 128, BKV = 64, ATHREADS = 256;
 
-__global__ void __launch_bounds__(ATHREADS) k_attn_spatial(AttnParams p) {
+__global__ void __launch_bounds__(ATHREADS, 2) k_attn_spatial(AttnParams p) {
     __shared__ __attribute__((aligned(16))) __half Ks[2][BKV * 64];
     __shared__ __attribute__((aligned(16))) __half Vs[2][BKV * 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(ATHREADS) k_attn_spatial(AttnParams p) {
 }
 
 // One wavefront per (batch, pixel, head); 4 wavefronts per block.
-__global__ void __launch_bounds__(ATHREADS) k_attn_temporal(AttnParams p, long long nitems) {
+__global__ void __launch_bounds__(ATHREADS, 2) k_attn_temporal(AttnParams p, long long nitems) {
     __shared__ __attribute__((aligned(16))) __half Vsm[4][32 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lq = lane & 31, h = lane >> 5;
