@@ -148,12 +148,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the SYN3R hot path has no CPU fallback)")
+    # rehearsal knobs (not used by the driver): all ranks on one GPU and/or gloo instead of RCCL
+    if os.environ.get("SYN3R_BENCH_SINGLE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("SYN3R_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if backend == "nccl" else torch.device("cpu")     # where collective payloads live
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     from syn3r_amd import _lib as L
     L.load()
 
@@ -199,14 +207,14 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
     log(f"timed region done: {dt:.3f} s")
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_max = float(tmax.item())
 
     # one collective at the end: fixed-size per-rank record (scene id, iters/s, svd units/s, wall)
     rec = torch.tensor([rank, args.raster_iters * args.steps / dt, (args.steps / dt) if loop_b else 0.0, dt],
-                       device=dev, dtype=torch.float32)
+                       device=cdev, dtype=torch.float32)
     if dist is not None:
         allrec = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(allrec, rec)
