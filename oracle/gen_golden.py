@@ -224,6 +224,12 @@ def gen_orchestrator():
         out[f"idx{k}"] = np.int64(idx)
     for k, m in enumerate(GI.orch_masks()):
         out[f"lambda{k}"] = DiffusionGS.search_hypers_v2(None, torch.from_numpy(m), "/tmp").numpy()
+    # perturbation candidates draw from the unseeded global np.random: seed it for the fixture
+    a, b = GI.orch_pose_pairs()[0]
+    anchors = DiffusionGS.pose_interpolation(None, a, b)[::4]
+    np.random.seed(1234)
+    cands = DiffusionGS._perturb_interp_pose_candidates(None, anchors, perturb_num=5)
+    out["perturbed"] = np.array(cands)
     np.savez_compressed(GOLD / "orchestrator.npz", **out)
     print("orchestrator", {k: getattr(v, "shape", ()) for k, v in out.items()})
 

@@ -149,3 +149,90 @@ def warp_images_bw(intrinsics: np.ndarray, interpolated_poses: Sequence[np.ndarr
     aux = dict(masks_ero=np.stack(masks_ero).astype(np.uint8), soft_masks_reproj=torch.cat(soft_pool).to(torch.float32),
                soft_masks_reproj_ori=np.stack(soft_ori).astype(np.float32), cond_images_ori=cond_ori)
     return image_l / 255.0, image_r / 255.0, torch.cat(masks), cond_image, aux
+
+
+# ---------------------------------------------------------------------------------------------- O2
+def _perturb_interp_pose_candidates(anchor_poses, perturb_num: int = 5, rng=None):
+    """diffusionGS.py:653-714 — per anchor: the pose itself + `perturb_num` copies jittered by
+    N(0, 0.1 x nearest-neighbour distance) in translation and N(0, 0.1 deg) xyz Euler rotation.
+    The reference draws from the unseeded global `np.random`; `rng` (anything with `.normal`) defaults to
+    that module so that seeding `np.random` reproduces the reference draw for draw."""
+    rng = np.random if rng is None else rng
+    translations = np.array([pose[:3, 3] for pose in anchor_poses])
+    dists = np.linalg.norm(translations[:, None, :] - translations[None, :, :], axis=-1)
+    np.fill_diagonal(dists, np.max(dists))
+    nn_dists = np.min(dists, axis=1)
+    out = []
+    for i, pose in enumerate(anchor_poses):
+        group = [anchor_poses[i].astype(np.float32)]
+        for _ in range(perturb_num):
+            p = pose.copy()
+            p[:3, 3] += rng.normal(0, nn_dists[i] * 0.1, size=3)
+            rot_noise = R.from_euler("xyz", rng.normal(0, 0.1, size=3) * np.array([1, 1, 1]), degrees=True)
+            p[:3, :3] = (rot_noise * R.from_matrix(pose[:3, :3])).as_matrix()
+            group.append(p.astype(np.float32))
+        out.append(group)
+    return out
+
+
+def _perturb_and_select_interp_poses(anchor_poses, ref_poses, K, render: Callable, perturb_num: int = 5, rng=None,
+                                     device="cuda:0"):
+    """diffusionGS.py:716-766 — for every anchor pick the candidate whose inverse warp from the nearest
+    reference view is MOST uncertain (max mean(1 - soft_mask_reproj), bandwidth 20).
+    `render(pose) -> (image (H,W,3) float, depth (H,W) float)` is the reference's `render_GS`.
+    All candidates that share a reference view go through ONE batched `syn3r_inverse_warp` call
+    (the reference issues 150 separate warps per view pair)."""
+    from .solver_utils.forward_warp import inverse_warp_batch
+    dev = torch.device(device)
+    refs = [render(p) for p in ref_poses]
+    ref_t = np.array([p[:3, 3] for p in ref_poses])
+    groups = _perturb_interp_pose_candidates(anchor_poses, perturb_num, rng)
+    Kt = torch.as_tensor(np.asarray(K), dtype=torch.float32)
+    # bucket (group, candidate) by nearest reference view
+    buckets: dict = {}
+    for gi, group in enumerate(groups):
+        for ci, pose in enumerate(group):
+            nn = int(np.argmin(np.linalg.norm(ref_t - pose[:3, 3], axis=1)))
+            buckets.setdefault(nn, []).append((gi, ci, pose))
+    unc = [[0.0] * len(g) for g in groups]
+    for nn, items in buckets.items():
+        img = torch.as_tensor(refs[nn][0], dtype=torch.float32, device=dev)
+        if img.shape[-1] == 3:
+            img = img.permute(2, 0, 1).contiguous()
+        dep = torch.as_tensor(refs[nn][1], dtype=torch.float32, device=dev)
+        dps = torch.stack([torch.as_tensor(render(p)[1], dtype=torch.float32) for _, _, p in items]).to(dev)
+        poses = torch.as_tensor(np.stack([p for _, _, p in items]), dtype=torch.float32)
+        out = inverse_warp_batch(img, dep, dps, torch.as_tensor(ref_poses[nn], dtype=torch.float32), poses, Kt,
+                                 bandwidth=20)
+        m = (1 - out["soft_mask_reproj"]).mean(dim=(1, 2)).cpu().numpy()
+        for (gi, ci, _), u in zip(items, m):
+            unc[gi][ci] = float(u)
+    return [group[int(np.argmax(u))] for group, u in zip(groups, unc)]
+
+
+# ---------------------------------------------------------------------------------------------- O4
+def consistency_check_from_nearby_images_bw(intrinsics, interpolated_poses, images, depths, device="cuda:0",
+                                            window_radius: int = 1):
+    """diffusionGS.py:1300-1361 — every frame is checked against its +-1 neighbours (bandwidth 10):
+    geometric uncertainty 1 - mean(soft_mask_reproj), intensity uncertainty
+    1 - exp(-(|mean warped - image|_2 / 0.1)^3).  images (H,W,3) float, depths (H,W)."""
+    dev = torch.device(device)
+    K = torch.as_tensor(np.asarray(intrinsics), dtype=torch.float32)
+    imgs = [torch.as_tensor(im, dtype=torch.float32, device=dev).permute(2, 0, 1).contiguous() for im in images]
+    deps = [torch.as_tensor(d[None], dtype=torch.float32, device=dev) for d in depths]
+    poses = [torch.as_tensor(p, dtype=torch.float32) for p in interpolated_poses]
+    uncertainty_masks, intensity_uncertainty_masks = [], []
+    n = len(poses)
+    for cur in range(n):
+        masks, warps = [], []
+        for ref in range(cur - window_radius, cur + window_radius + 1):
+            if ref == cur or ref < 0 or ref >= n:
+                continue
+            wd = inverse_warp(imgs[ref], deps[ref], deps[cur], poses[ref], poses[cur], K, bandwidth=10)
+            masks.append(wd["soft_mask_reproj"])
+            warps.append(wd["warped_img"])
+        uncertainty_masks.append(1 - torch.stack(masks).mean(dim=0))
+        warped = torch.stack(warps).mean(dim=0)
+        intensity_conf = torch.exp(-((torch.norm(warped - imgs[cur], dim=0)) / 0.1) ** 3)
+        intensity_uncertainty_masks.append(1 - intensity_conf)
+    return uncertainty_masks, intensity_uncertainty_masks

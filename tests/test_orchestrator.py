@@ -49,3 +49,15 @@ def test_fuse_uncertainty_shapes_and_limits():
     assert masks.shape == (23, 72, 128) and masks.dtype == torch.float32
     assert float(masks[:, :6].min()) == 1.0 and float(masks[:, 8:].max()) < 1e-6
     assert len(cond) == 23 and cond[0].shape == (576, 1024, 3)
+
+
+def test_perturb_candidates_match_reference(golden_dir):
+    """Same global-np.random draws as the reference method when seeded identically."""
+    g = np.load(golden_dir / "orchestrator.npz")
+    a, b = GI.orch_pose_pairs()[0]
+    anchors = O.pose_interpolation(a, b)[::4]
+    np.random.seed(1234)
+    cands = np.array(O._perturb_interp_pose_candidates(anchors, perturb_num=5))
+    assert cands.shape == (7, 6, 4, 4) and cands.dtype == np.float32
+    np.testing.assert_allclose(cands, g["perturbed"], atol=1e-6)
+    np.testing.assert_array_equal(cands[:, 0], anchors)          # candidate 0 is the unperturbed anchor

@@ -145,3 +145,42 @@ def test_forward_warp_mask_and_shape_asserts(gpu):
     assert not mask2.all()
     with pytest.raises(AssertionError):
         forward_warp(frame[:, :, :2], None, *a)
+
+
+def test_orchestrator_select_and_nearby_consistency(gpu):
+    """O2 / O4 on the HIP warps: batched perturb-and-select equals the one-by-one reference procedure, and the
+    nearby-frame consistency masks equal the formula applied to single inverse warps."""
+    from syn3r_amd import orchestrator as O
+    from syn3r_amd.solver_utils.forward_warp import inverse_warp
+    c = GI.warp_case("small")
+    H, W = c["H"], c["W"]
+
+    def render(pose):                      # synthetic stand-in for render_GS: pose-dependent depth, fixed image
+        shift = float(pose[0, 3])
+        return c["img"].transpose(1, 2, 0), (c["depth"] + np.float32(0.05 * shift)).astype(np.float32)
+
+    poses = O.pose_interpolation(c["pose1"], c["pose2"], num=5)
+    np.random.seed(7)
+    sel = O._perturb_and_select_interp_poses(poses, [c["pose1"], c["pose2"]], c["K"], render, perturb_num=3, device=gpu)
+    assert len(sel) == 5 and all(s.shape == (4, 4) for s in sel)
+    # reproduce the selection one warp at a time (diffusionGS.py:738-763)
+    np.random.seed(7)
+    groups = O._perturb_interp_pose_candidates(poses, 3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    refs = [c["pose1"], c["pose2"]]
+    for gi, group in enumerate(groups):
+        u = []
+        for p in group:
+            nn = int(np.argmin([np.linalg.norm(r[:3, 3] - p[:3, 3]) for r in refs]))
+            wd = inverse_warp(t(render(refs[nn])[0].transpose(2, 0, 1)), t(render(refs[nn])[1])[None], t(render(p)[1])[None],
+                              t(refs[nn]), t(p), t(c["K"]), bandwidth=20)
+            u.append(float((1 - wd["soft_mask_reproj"]).mean()))
+        assert np.array_equal(sel[gi], group[int(np.argmax(u))])
+    imgs = [render(p)[0] for p in poses]
+    deps = [render(p)[1] for p in poses]
+    um, im = O.consistency_check_from_nearby_images_bw(c["K"], poses, imgs, deps, device=gpu)
+    assert len(um) == 5 and um[0].shape == (H, W) and im[2].shape == (H, W)
+    wd = inverse_warp(t(imgs[1].transpose(2, 0, 1)), t(deps[1])[None], t(deps[0])[None], t(poses[1]), t(poses[0]), t(c["K"]),
+                      bandwidth=10)
+    assert torch.allclose(um[0], 1 - wd["soft_mask_reproj"])
+    assert float(im[2].min()) >= 0 and float(im[2].max()) <= 1
