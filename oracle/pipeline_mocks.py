@@ -39,6 +39,12 @@ class MockVAE:
     def to(self, *a, **k):
         return self
 
+    def decode(self, z, num_frames=None):
+        """latents -> images: pseudo-inverse of the channel mix, 8x nearest upsampling."""
+        inv = torch.linalg.pinv(self.MIX.to(z.device).float())
+        img = torch.einsum("co,bohw->bchw", inv, z.float())
+        return SimpleNamespace(sample=torch.nn.functional.interpolate(img, scale_factor=8, mode="nearest"))
+
     def encode(self, image):
         pooled = torch.nn.functional.avg_pool2d(image.float(), 8)
         lat = torch.einsum("oc,bchw->bohw", self.MIX.to(image.device), pooled)

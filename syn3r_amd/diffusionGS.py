@@ -1,0 +1,221 @@
+"""`DiffusionGS` — the reference orchestrator's call surface (`model/diffusionGS.py:39,1668`) on the HIP hot path.
+
+`DiffusionGS(GSTrainer, num_input_views, save_dir, diffusion_type, interp_type, debug, input_args).run(refine_cycles)`
+keeps the reference's constructor, method names, artefact names (`dense_views…cyc{c}_view{i}.pt` with keys `views`,
+`poses`) and control flow:
+
+    init_GS -> for each cycle: densify_views (per view pair: _interpolate_between_gs_v3 -> svd_render) -> refine_GS
+
+What runs where: the rasteriser behind `gsTrainer.render_view` / `training`, the inverse warps, the UNet and the
+scheduler steps are HIP kernels; poses, masks and the lambda schedule are host numerics (`syn3r_amd.orchestrator`).
+Everything stays on the device between stages (the reference round-trips through numpy and PNG files,
+diffusionGS.py:151-169,1447-1475).  Out of scope and therefore rejected: dust3r/GMFlow point-cloud densification
+(`num_views_for_pcd_densification > 1`, sources absent — SURVEY.md N2) and the forward-warp interpolation variant.
+CLIP and the temporal VAE are passed in as modules (`svd_components`), see `pipeline/svd_2pass.py`.
+"""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import orchestrator as O
+from .gs.trainer import Camera
+from .pipeline.svd_2pass import StableVideoDiffusionPipeline
+from .schedulers.scheduling_euler_discrete import SVD_XT_SCHEDULER_CONFIG, EulerDiscreteScheduler
+
+
+def _resize_linear(x: np.ndarray, height: int, width: int) -> np.ndarray:
+    """cv2.resize(..., INTER_LINEAR) (diffusionGS.py:804-805): pixel-centre-aligned bilinear, no antialiasing."""
+    t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    chw = t[None, None] if t.dim() == 2 else t.permute(2, 0, 1)[None]
+    out = torch.nn.functional.interpolate(chw, size=(height, width), mode="bilinear", align_corners=False)
+    return (out[0, 0] if t.dim() == 2 else out[0].permute(1, 2, 0)).numpy()
+
+
+def _resize_nearest(x: np.ndarray, height: int, width: int) -> np.ndarray:
+    """cv2.resize(..., INTER_NEAREST) (diffusionGS.py:1387-1406): source index floor(dst * scale)."""
+    ys = np.minimum((np.arange(height) * (x.shape[0] / height)).astype(np.int64), x.shape[0] - 1)
+    xs = np.minimum((np.arange(width) * (x.shape[1] / width)).astype(np.int64), x.shape[1] - 1)
+    return x[ys][:, xs]
+
+
+class DiffusionGS:
+    def __init__(self, GSTrainer, num_input_views=12, save_dir=None, diffusion_type="2Pass", interp_type="forward_warp",
+                 debug=False, input_args=None, svd_components: Optional[dict] = None, num_inference_steps: int = 100,
+                 diffusion_size=(576, 1024)):
+        self.args = input_args
+        self.cam_confidence = self.args.cam_confidence
+        self.pseudo_cam_sampling_rate = self.args.pseudo_cam_sampling_rate
+        self.fps_keyframe_sampling = getattr(self.args, "fps_keyframe_sampling", 0)
+        self.debug = debug
+        self.gsTrainer = GSTrainer
+        self.dust3r = getattr(GSTrainer, "dust3r", None)
+        self.num_input_views = num_input_views
+        self.save_dir = save_dir
+        self.interp_type = interp_type
+        assert self.interp_type in ["forward_warp", "backward_warp"]
+        self.densify_type = self.args.densify_type
+        self.refine_epoch = 0
+        self.latent_num = 1
+        cam0 = self.get_TrainCameras()[0]
+        self.gs_height, self.gs_width = int(cam0.image_height), int(cam0.image_width)
+        K, _ = cam0.get_calib_matrix_nerf()
+        self.gs_intrinsics = K.numpy()
+        self.diffusion_height, self.diffusion_width = diffusion_size
+        sx, sy = self.diffusion_width / self.gs_width, self.diffusion_height / self.gs_height
+        self.diffusion_intrinsics = self.gs_intrinsics.copy()        # diffusionGS.py:72-87
+        self.diffusion_intrinsics[0] *= sx
+        self.diffusion_intrinsics[1] *= sy
+        # only these two are accepted by the reference (diffusionGS.py:115-124)
+        if diffusion_type == "2PassProbUncertain":
+            self.variant = "replace"
+        elif diffusion_type == "2PassProbUncertainPost":
+            self.variant = "post"
+        else:
+            raise NotImplementedError(f"diffusion_type {diffusion_type} not supported")
+        self.diffusion_type = diffusion_type
+        self.svd_components = svd_components
+        self.num_inference_steps = num_inference_steps
+        self.device = cam0.world_view_transform.device
+
+    # ------------------------------------------------------------------ GS side
+    def get_TrainCameras(self, ordered=False):
+        return self.gsTrainer.scene.getTrainCameras()
+
+    def init_GS(self, cycle=0):
+        """diffusionGS.py:137-141 — HOT LOOP A."""
+        self.gsTrainer.training(0, epoch_indicator=cycle)
+
+    def render_GS(self, idx=None, pose=None, return_alpha=False):
+        """diffusionGS.py:143-172 -> (w2c pose, image, depth[, alpha]).  As the reference: a TRAINING view returns
+        its ground-truth image HWC in [0,255]; a free pose returns the render CHW in [0,1]."""
+        assert (idx is None and pose is not None) or (idx is not None and pose is None)
+        if idx is not None:
+            cam = self.get_TrainCameras()[idx]
+            pose = cam.world_view_transform.transpose(0, 1).cpu().numpy()
+            image = cam.get_image().permute([1, 2, 0]).cpu().numpy() * 255
+            res = self.gsTrainer.render_view(cam)
+        else:
+            tpl = self.get_TrainCameras()[0]
+            cam = Camera(colmap_id=-1, R=pose[:3, :3].T, T=pose[:3, 3], FoVx=tpl.FoVx, FoVy=tpl.FoVy,
+                         image=tpl.original_image, gt_alpha_mask=None, image_name=None, uid=None,
+                         data_device=self.device, cam_confidence=1.0)
+            res = self.gsTrainer.render_view(cam)
+            image = res["render"].detach().squeeze().cpu().numpy()
+        depth = res["depth"].detach().squeeze().cpu().numpy()
+        if return_alpha:
+            return pose, image, depth, res["alpha"].detach().squeeze().cpu().numpy()
+        return pose, image, depth
+
+    # ------------------------------------------------------------------ SVD side
+    def svd_render(self, image_l, image_r, masks, cond_image, output_path, lambda_ts, num_frames=25, save_prefix=""):
+        """diffusionGS.py:1088-1116.  The reference re-downloads the checkpoint by model name on every call; here the
+        modules are supplied once (`svd_components`: vae, image_encoder, unet) and stay resident."""
+        if not self.svd_components:
+            raise RuntimeError("svd_render needs svd_components={'vae':…, 'image_encoder':…, 'unet':…} (local modules; "
+                               "the reference fetches stabilityai/stable-video-diffusion-img2vid-xt by name)")
+        c = self.svd_components
+        pipe = StableVideoDiffusionPipeline(c["vae"], c["image_encoder"], c["unet"],
+                                            EulerDiscreteScheduler(**SVD_XT_SCHEDULER_CONFIG), variant=self.variant,
+                                            device=self.device)
+        assert isinstance(cond_image, list)
+        frames = pipe([image_l], temp_cond=cond_image + [image_r], mask=masks, lambda_ts=lambda_ts, num_frames=num_frames,
+                      decode_chunk_size=8, num_inference_steps=self.num_inference_steps, latent_num=self.latent_num,
+                      output_type="np", dtype=c.get("dtype", torch.float16)).frames[0]
+        return [frames[i] for i in range(frames.shape[0])]          # [H,W,3] float in [0,1] per frame
+
+    def _interpolate_between_gs_v3(self, idx1, idx2, replace=True, perturb_interp_poses=True):
+        """diffusionGS.py:774-923."""
+        pose1, image1, depth1 = self.render_GS(idx1)
+        pose2, image2, depth2 = self.render_GS(idx2)
+        interpolated_poses = list(O.pose_interpolation(pose1, pose2))
+        render = lambda p: self.render_GS(pose=p)[1:]
+        if perturb_interp_poses:
+            sel = O._perturb_and_select_interp_poses(
+                interpolated_poses, [pose1, pose2], K=self.gs_intrinsics,
+                render=lambda p: (render(p)[0].transpose(1, 2, 0), render(p)[1]), perturb_num=5, device=self.device)
+            interpolated_poses = [pose1] + sel[1:-1] + [pose2]
+        Hd, Wd = self.diffusion_height, self.diffusion_width
+        pseudo_images, pseudo_depths = [], []
+        for p in interpolated_poses:
+            _, im, dp = self.render_GS(pose=p)
+            pseudo_images.append(_resize_linear(im.transpose([1, 2, 0]), Hd, Wd))
+            pseudo_depths.append(_resize_linear(dp, Hd, Wd))
+        if self.interp_type != "backward_warp":
+            raise NotImplementedError("only --interp_type backward_warp (used by every shipped script) is implemented")
+        rs = lambda x: _resize_nearest(x, Hd, Wd)
+        image_o, image_o2, masks, cond_image, aux = O.warp_images_bw(
+            self.diffusion_intrinsics, interpolated_poses, rs(image1), rs(image2), rs(depth1), rs(depth2),
+            render_depth=lambda p: _resize_nearest(self.render_GS(pose=p)[2], Hd, Wd), device=self.device,
+            h=Hd // 8, w=Wd // 8)
+        gs_images = np.stack(pseudo_images[1:-1])
+        masks, cond_image, _ = O.fuse_uncertainty(np.stack(aux["cond_images_ori"]), gs_images,
+                                                  aux["soft_masks_reproj_ori"], h=Hd // 8, w=Wd // 8)
+        lambda_ts = O.search_hypers_v2(masks, None, type="double_end", diffusion_steps=self.num_inference_steps)
+        frames = self.svd_render(image_o, image_o2, masks, cond_image, None, lambda_ts, num_frames=len(interpolated_poses))
+        if replace:
+            frames[0], frames[-1] = image_o, image_o2
+        out = []
+        for fr in frames:                                             # back to the GS resolution, CHW in [0,1]
+            t = torch.from_numpy(np.ascontiguousarray(fr, dtype=np.float32)).permute(2, 0, 1)[None]
+            t = torch.nn.functional.interpolate(t, size=(self.gs_height, self.gs_width), mode="bicubic", align_corners=False)
+            out.append(t[0].clamp(0, 1))
+        return out, interpolated_poses, pseudo_images
+
+    def densify_views(self, cycle_num, down_sample_rate=1, densify_type="interpolate", num_views_for_pcd_densification=4):
+        """diffusionGS.py:174-340 (view densification; point-cloud densification is out of scope)."""
+        if num_views_for_pcd_densification > 1:
+            raise NotImplementedError("dust3r/GMFlow point-cloud densification is out of scope (sources absent); "
+                                      "run with --num_views_for_pcd_densification 1")
+        dense_views, dense_poses = [], []
+        os.makedirs(os.path.join(self.save_dir, "dense_views"), exist_ok=True)
+        for i in range(self.num_input_views):
+            saving_path = os.path.join(self.save_dir, "dense_views" f"interpolated_dense_views_cyc{cycle_num}_view{i}.pt")
+            if os.path.exists(saving_path):
+                data = torch.load(saving_path, weights_only=False)
+                frames, poses = data["views"], data["poses"]
+            else:
+                if densify_type == "interpolate_loop0_gs":
+                    if i == self.num_input_views - 1:
+                        break
+                    frames, poses, _ = self._interpolate_between_gs_v3(i, (i + 1) % self.num_input_views, replace=True,
+                                                                       perturb_interp_poses=True)
+                elif densify_type == "interpolate_gs_v2":
+                    frames, poses, _ = self._interpolate_between_gs_v3(i, (i + 1) % self.num_input_views, replace=True)
+                else:
+                    raise NotImplementedError(f"{densify_type} not supported")
+                if down_sample_rate < 1:
+                    idx = np.linspace(0, len(frames) - 1, int(len(frames) * down_sample_rate), dtype=int)
+                    frames, poses = [frames[k] for k in idx], [poses[k] for k in idx]
+            dense_views.extend(frames[:-1])
+            dense_poses.extend(poses[:-1])
+            if densify_type == "interpolate_loop0_gs" and i == self.num_input_views - 2:
+                dense_views.append(frames[-1])
+                dense_poses.append(poses[-1])
+            torch.save({"views": frames, "poses": poses}, saving_path)
+        return dense_views, dense_poses, None
+
+    def refine_GS(self, dense_views, dense_poses, intrinsics, cam_confidence=0.01, gs_start_iter=0,
+                  disable_densification=False, load_iteration=None, pseudo_cam_sampling_rate=1, load_ckpt=True):
+        """diffusionGS.py:1608-1643 (checkpoint reload omitted: the Gaussians stay resident)."""
+        self.gsTrainer.update_cameras(dense_views, dense_poses, intrinsics, cam_confidences=cam_confidence, append=True)
+        self.gsTrainer.reset_optimizers()
+        self.gsTrainer.reset_gs()
+        self.gsTrainer.finetune(0, self.refine_epoch, disable_densification=disable_densification,
+                                pseudo_cam_sampling_rate=pseudo_cam_sampling_rate)
+        self.refine_epoch += 1
+
+    def run(self, refine_cycles=1):
+        """diffusionGS.py:1668-1697."""
+        self.init_GS()
+        for i in range(refine_cycles):
+            dense_views, dense_poses, _ = self.densify_views(
+                cycle_num=i, down_sample_rate=1, densify_type=self.densify_type,
+                num_views_for_pcd_densification=self.args.num_views_for_pcd_densification)
+            self.refine_GS(dense_views=dense_views, dense_poses=dense_poses, intrinsics=self.gs_intrinsics,
+                           cam_confidence=self.cam_confidence, load_iteration=None,
+                           pseudo_cam_sampling_rate=self.pseudo_cam_sampling_rate, load_ckpt=(i > 0))

@@ -160,6 +160,8 @@ class GSTrainer:
 
     def update_cameras(self, views, poses, K, cam_confidences, append: bool = True):
         """diffusionGS.py:1631 — register SVD pseudo-views ([3,H,W] tensors + w2c poses) with their confidence."""
+        if np.isscalar(cam_confidences):
+            cam_confidences = [float(cam_confidences)] * len(views)
         cams = [Camera.from_w2c(np.asarray(p), np.asarray(K), v.shape[1], v.shape[2], image=v, cam_confidence=c,
                                 data_device=self.gaussians._xyz.device) for v, p, c in zip(views, poses, cam_confidences)]
         self.pseudo_cameras = (self.pseudo_cameras + cams) if append else cams

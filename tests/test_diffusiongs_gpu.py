@@ -1,0 +1,74 @@
+"""End-to-end plumbing of the orchestrator mirror: DiffusionGS.run on a tiny synthetic 3-view scene with mock
+CLIP / VAE / UNet (loop logic already pinned in test_pipeline_gpu.py) and the real HIP rasteriser, warps and
+scheduler steps; refine_cycle_num 0 == BASELINE config 1 (SVD disabled)."""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline_mocks as PM
+from oracle import raster_oracle as RO
+
+pytestmark = pytest.mark.gpu
+
+
+def build(gpu, tmp_path, iterations=20):
+    from syn3r_amd.gs import Camera, GaussianModel, GSTrainer, OptimizationParams
+    N, H, W = 800, 72, 128
+    m, s, q, o, sh = RO.synthetic_gaussians(N, seed=5, log_scale_mean=np.log(0.08))
+    logit = torch.log(o.clamp(1e-3, 1 - 1e-3) / (1 - o.clamp(1e-3, 1 - 1e-3)))
+    gt = GaussianModel(m, torch.log(s), q, logit, sh, device=gpu)
+    f = W / (2 * math.tan(math.radians(30)))
+    K = np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], dtype=np.float32)
+    poses = []
+    for dx in (-0.15, 0.0, 0.15):
+        p = np.eye(4, dtype=np.float32)
+        p[0, 3] = dx
+        poses.append(p)
+    views = []
+    tr_gt = GSTrainer(gt, [Camera.from_w2c(poses[0], K, H, W, data_device=gpu)])
+    for p in poses:
+        cam = Camera.from_w2c(p, K, H, W, data_device=gpu)
+        views.append(tr_gt.render_view(cam)["render"].detach())
+    cams = [Camera.from_w2c(p, K, H, W, image=v, data_device=gpu) for p, v in zip(poses, views)]
+    m2 = m + 0.01 * torch.randn_like(m)
+    gm = GaussianModel(m2, torch.log(s), q, logit, sh, device=gpu)
+    trainer = GSTrainer(gm, cams, OptimizationParams(iterations=iterations))
+    args = SimpleNamespace(cam_confidence=0.05, pseudo_cam_sampling_rate=0.5, fps_keyframe_sampling=0,
+                           densify_type="interpolate_gs_v2", num_views_for_pcd_densification=1)
+    return trainer, args
+
+
+def test_run_without_svd_is_plain_training(gpu, tmp_path):
+    from syn3r_amd.diffusionGS import DiffusionGS
+    trainer, args = build(gpu, tmp_path, iterations=10)
+    before = trainer.gaussians._xyz.detach().clone()
+    d = DiffusionGS(trainer, num_input_views=3, save_dir=str(tmp_path), diffusion_type="2PassProbUncertain",
+                    interp_type="backward_warp", input_args=args)
+    d.run(refine_cycles=0)                                   # config 1: init_GS only (diffusionGS.py:1668-1673)
+    assert not torch.equal(before, trainer.gaussians._xyz.detach())
+    pose, image, depth = d.render_GS(idx=1)
+    assert pose.shape == (4, 4) and image.shape == (72, 128, 3) and depth.shape == (72, 128)
+    with pytest.raises(NotImplementedError):
+        DiffusionGS(trainer, 3, str(tmp_path), "1Pass", "backward_warp", input_args=args)
+
+
+def test_one_refine_cycle_with_mock_svd(gpu, tmp_path):
+    from syn3r_amd.diffusionGS import DiffusionGS
+    trainer, args = build(gpu, tmp_path, iterations=5)
+    comps = dict(vae=PM.MockVAE(), image_encoder=PM.MockImageEncoder(), unet=PM.MockUNet().to(gpu), dtype=torch.float32)
+    d = DiffusionGS(trainer, num_input_views=3, save_dir=str(tmp_path), diffusion_type="2PassProbUncertain",
+                    interp_type="backward_warp", input_args=args, svd_components=comps, num_inference_steps=2)
+    np.random.seed(0)
+    d.run(refine_cycles=1)
+    files = sorted(p.name for p in tmp_path.iterdir() if p.suffix == ".pt")
+    assert files == [f"dense_viewsinterpolated_dense_views_cyc0_view{i}.pt" for i in range(3)]   # reference artefact names
+    data = torch.load(tmp_path / files[0], weights_only=False)
+    assert len(data["views"]) == 25 and len(data["poses"]) == 25 and data["views"][3].shape == (3, 72, 128)
+    assert len(trainer.pseudo_cameras) == 3 * 24 and trainer.pseudo_cameras[0].cam_confidence == 0.05
+    assert d.refine_epoch == 1
+    args.num_views_for_pcd_densification = 4
+    with pytest.raises(NotImplementedError):
+        d.densify_views(1, densify_type="interpolate_gs_v2", num_views_for_pcd_densification=4)
