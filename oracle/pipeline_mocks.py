@@ -19,8 +19,9 @@ class MockImageEncoder(torch.nn.Module):
         self.anchor = torch.nn.Parameter(torch.zeros(1, dtype=dtype), requires_grad=False)
 
     def forward(self, image):
-        if not isinstance(image, torch.Tensor):
-            raise TypeError("mock encoder takes tensors")
+        if not isinstance(image, torch.Tensor):      # HWC numpy image, as the orchestrator passes it
+            import numpy as np
+            image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32)).permute(2, 0, 1)
         x = image.float()
         if x.dim() == 3:
             x = x[None]
