@@ -122,7 +122,7 @@ class EulerDiscreteScheduler:
         else:
             raise ValueError(f"{cfg.timestep_spacing} is not supported. Please make sure to choose one of "
                              "'linspace', 'leading' or 'trailing'.")
-        sigmas = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
         log_sigmas = np.log(sigmas)
         if cfg.interpolation_type == "linear":
             sigmas = np.interp(timesteps, np.arange(0, len(sigmas)), sigmas)
