@@ -75,6 +75,7 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
     const float* __restrict__ dL_dalpha_out, float* __restrict__ grad_rec) {
     __shared__ float4 sm[kTilePix * 3];
     __shared__ unsigned sid[kTilePix];
+    __shared__ float sacc[kTilePix * kGradSlots];   // per-round gradient records: the 4 wavefronts meet here first
     const unsigned tile = xcd_remap(blockIdx.x, (unsigned)(gx * gy));
     const int tx = tile % gx, ty = tile / gx;
     const int lx = threadIdx.x % kTileX, ly = threadIdx.x / kTileX;
@@ -114,6 +115,9 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
             sm[threadIdx.x * 3 + 2] = src[2];
             sid[threadIdx.x] = gid;
         }
+#pragma unroll
+        for (int k = 0; k < kGradSlots / 4; ++k)
+            ((float4*)sacc)[threadIdx.x * (kGradSlots / 4) + k] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
         int cnt = min(kTilePix, todo);
         for (int j = 0; j < cnt; ++j) {
@@ -129,7 +133,8 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
 #pragma unroll
             for (int k = 0; k < 16; ++k) v[k] = 0.0f;
             if (active) {
-                T = T / (1.0f - alpha);
+                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);   // 1 ulp reciprocal: one instruction, not a 10-op IEEE divide
+                T = T * inv1ma;
                 float wgt = alpha * T;
                 // colour / depth recursion of the contribution behind this splat
                 acc_r = last_alpha * last_r + (1.0f - last_alpha) * acc_r;
@@ -140,7 +145,6 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
                 float dL_da = (b.z - acc_r) * gr + (b.w - acc_g) * gg + (c.x - acc_b) * gb + (c.y - acc_d) * gD;
                 dL_da *= T;
                 last_alpha = alpha;
-                float inv1ma = 1.0f / (1.0f - alpha);
                 dL_da += (-T_final * inv1ma) * bg_dot;   // background term of the colour output
                 dL_da += (T_final * inv1ma) * gA;        // alpha output  A = 1 - T_final
                 float dL_dG = b.y * dL_da;
@@ -156,8 +160,17 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
                 v[G_OP] = G * dL_da;
             }
             float s = butterfly16(v, lane);
-            if ((lane & 3) == 0 && (lane >> 2) < G_USED)
-                unsafeAtomicAdd(grad_rec + (size_t)sid[j] * kGradSlots + (lane >> 2), s);
+            if ((lane & 3) == 0 && (lane >> 2) < G_USED) atomicAdd(&sacc[j * kGradSlots + (lane >> 2)], s);   // LDS, 10 banks
+        }
+        // one global atomic per (tile, splat) instead of one per (wavefront, splat): 16 lanes per record, so a
+        // wave-instruction covers four contiguous 64-byte records
+        __syncthreads();
+        {
+            const int slot = threadIdx.x & 15;
+            for (int q = threadIdx.x >> 4; q < cnt; q += kTilePix / 16) {
+                float val = sacc[q * kGradSlots + slot];
+                if (slot < G_USED && val != 0.0f) unsafeAtomicAdd(grad_rec + (size_t)sid[q] * kGradSlots + slot, val);
+            }
         }
     }
 }
