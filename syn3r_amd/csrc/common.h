@@ -88,3 +88,18 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): ~14 VALU operations instead of libm's ~40.
+// Used by the GELU of the GEGLU gate, whose result is rounded to fp16 (relative step 4.9e-4).
+__device__ __forceinline__ float fast_erff(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float r = 1.0f - p * t * e;
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + fast_erff(g * 0.70710678118654752f)); }

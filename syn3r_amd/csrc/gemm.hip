@@ -143,7 +143,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float g = (float)gv[e];
-                float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752f));
+                float ge = gelu_erf(g);
                 o[e] = (_Float16)((float)hv[e] * ge);
             }
             if (n + 8 <= p.geglu_D) {
@@ -351,19 +351,24 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm(GemmParams p) {
 // fragment reads are inline asm (ds_read_b128 + counted lgkmcnt, operands tied through "+v").
 __device__ __half g_zero_page[64];   // zero-initialised: source of padded chunks
 
-constexpr int DMA_STAGES = 3;
-constexpr int DMA_A_BYTES = 256 * BK * 2;                 // 32768
 constexpr int DMA_B_BYTES = BN * BK * 2;                  // 20480
-constexpr int DMA_STAGE_BYTES = DMA_A_BYTES + DMA_B_BYTES;  // 53248
+// BM = 256: 512 threads, 3-stage ring (156 KB, one block per CU, two k-tiles of DMA in flight).
+// BM = 128: 256 threads, 2-stage ring (72 KB, TWO blocks per CU): a block's prologue DMA latency and its
+//           40-80 KB store tail (store-issue bound at ~10 B/clk/CU) are hidden behind the other block's MFMAs
+//           instead of idling the CU; costs 1.4x the L2->LDS bytes per output row (B tile per 128 rows).
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 #define DS_READ128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
 
-template <int MODE>
-__global__ void __launch_bounds__(512, 2) k_gemm_dma(GemmParams p) {
-    constexpr int BM = 256;
+template <int MODE, int BM>
+__global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
+    constexpr int DMA_STAGES = BM == 256 ? 3 : 2;
+    constexpr int NWAVES = BM / 32;                          // 8 or 4
+    constexpr int DMA_A_BYTES = BM * BK * 2;
+    constexpr int DMA_STAGE_BYTES = DMA_A_BYTES + DMA_B_BYTES;
+    constexpr int NB_MAX = (20 + NWAVES - 1) / NWAVES;       // B pieces per wavefront: 3 (8 waves) or 5 (4 waves)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -401,11 +406,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm_dma(GemmParams p) {
             a_base[i] = p.A + (long long)mc * p.Cin + csrc * 8;
         }
     }
-    const int nb = wv < 4 ? 3 : 2;                      // B pieces issued by this wavefront (20 in total)
-    const int b_first = wv < 4 ? wv * 3 : 12 + (wv - 4) * 2;
-    const __half* b_base[3];
+    // B pieces issued by this wavefront (20 in total): 8 waves -> 3,3,3,3,2,2,2,2 ; 4 waves -> 5 each
+    const int nb = NWAVES == 8 ? (wv < 4 ? 3 : 2) : 5;
+    const int b_first = NWAVES == 8 ? (wv < 4 ? wv * 3 : 12 + (wv - 4) * 2) : wv * 5;
+    const __half* b_base[NB_MAX];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NB_MAX; ++j) {
         int n = n0 + (b_first + j) * 8 + prow;
         b_base[j] = (j < nb && n < p.N) ? p.W + (long long)n * p.K + csrc * 8 : nullptr;
     }
@@ -442,7 +448,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_dma(GemmParams p) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < NB_MAX; ++j) {
             if (j < nb) {
                 const __half* src = b_base[j] ? b_base[j] + kt * BK : zero;
                 __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + DMA_A_BYTES + (b_first + j) * 1024), 16, 0, 0);
@@ -469,13 +475,23 @@ __global__ void __launch_bounds__(512, 2) k_gemm_dma(GemmParams p) {
 
     int buf = 0;
     for (int kt = 0; kt < nkt; ++kt) {
-        // stage kt has landed once at most one later stage (6..7 loads of this wavefront) is still in flight
-        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (DMA_STAGES == 3) {
+            // stage kt has landed once at most one later stage (6..7 loads of this wavefront) is still in flight
+            if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            // two slots: only in the first iteration is a younger stage (9 loads) already in flight
+            if (kt == 0 && nkt > 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nkt) {
-            int nbuf = buf + 2; if (nbuf >= DMA_STAGES) nbuf -= DMA_STAGES;
-            issue_stage(kt + 2, nbuf);      // overwrites the stage read in iteration kt-1 (all waves are past it)
+        if constexpr (DMA_STAGES == 3) {
+            if (kt + 2 < nkt) {
+                int nbuf = buf + 2; if (nbuf >= DMA_STAGES) nbuf -= DMA_STAGES;
+                issue_stage(kt + 2, nbuf);      // overwrites the stage read in iteration kt-1 (all waves are past it)
+            }
+        } else {
+            if (kt >= 1 && kt + 1 < nkt) issue_stage(kt + 1, buf ^ 1);   // the slot read in iteration kt-1
         }
         const unsigned sb = lds0 + (unsigned)buf * DMA_STAGE_BYTES;
         half8 a0[TM], b0[TN], a1[TM], b1[TN];
@@ -510,20 +526,30 @@ __global__ void __launch_bounds__(512, 2) k_gemm_dma(GemmParams p) {
     gemm_epilogue(p, acc, smem_raw, lane, wv, wm, wn, m0, n0, tile_n);
 }
 
-template <int MODE>
-int launch_dma(const GemmParams& p, hipStream_t stream) {
-    constexpr size_t lds = (size_t)DMA_STAGES * DMA_STAGE_BYTES;   // 159,744 B
-    static_assert(8 * WM * EPI_LD * sizeof(__half) <= lds, "epilogue staging must fit in the ring");
+int g_dma_bm = 0;   // 0 = by shape; 128 / 256 forced (syn3r_gemm_set_tile(-128 / -256), tuning only)
+
+template <int MODE, int BM>
+int launch_dma_bm(const GemmParams& p, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(BM == 256 ? 3 : 2) * (BM * BK * 2 + DMA_B_BYTES);   // 159,744 B / 73,728 B
+    static_assert((BM / 32) * WM * EPI_LD * sizeof(__half) <= lds, "epilogue staging must fit in the ring");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_dma<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_dma<MODE, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_dma)");
         attr_set = true;
     }
-    int tiles = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
-    SYN3R_LAUNCH(k_gemm_dma<MODE>, dim3(tiles), dim3(512), lds, stream, p);
+    int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    SYN3R_LAUNCH((k_gemm_dma<MODE, BM>), dim3(tiles), dim3(BM * 2), lds, stream, p);
     SYN3R_LAUNCH_CHECK("gemm_dma launch");
     return SYN3R_OK;
+}
+
+template <int MODE>
+int launch_dma(const GemmParams& p, hipStream_t stream) {
+    // measured on MI355X (tools/gemm_bench.py): two 128-row blocks per CU win on every UNet shape except the
+    // wide feed-forward expansions at C = 1280, where re-reading the 160-column B tile per 128 rows costs more
+    int bm = g_dma_bm ? g_dma_bm : ((p.N >= 5120 && p.K >= 1280) ? 256 : 128);
+    return bm == 128 ? launch_dma_bm<MODE, 128>(p, stream) : launch_dma_bm<MODE, 256>(p, stream);
 }
 
 int g_tile_bm = 0;   // 0 = LDS-DMA kernel (default); 128 / 256 = register-staged kernel of that block height
@@ -567,8 +593,9 @@ int check_common(const GemmParams& p, const char* who) {
 }  // namespace
 
 extern "C" int syn3r_gemm_set_tile(int bm) {
-    SYN3R_REQUIRE(bm == 0 || bm == 128 || bm == 256, "gemm_set_tile: bm must be 0, 128 or 256");
-    g_tile_bm = bm;
+    SYN3R_REQUIRE(bm == 0 || bm == 128 || bm == 256 || bm == -128 || bm == -256, "gemm_set_tile: bm must be 0, +-128 or +-256");
+    if (bm < 0) { g_tile_bm = 0; g_dma_bm = -bm; }          // LDS-DMA kernel with a forced block height
+    else { g_tile_bm = bm; g_dma_bm = 0; }                  // 0: LDS-DMA by shape; > 0: register-staged kernel
     return SYN3R_OK;
 }
 

@@ -62,22 +62,22 @@ __global__ void k_gn_stats(const __half* __restrict__ x, int R, int C, int rows_
 }
 
 // Fixed-order reduction of the per-chunk partials -> (mean, rstd) per (sample, group).
-// One 256-thread block per sample: 8 threads per group stride over the chunks, then a fixed
-// 3-step shuffle tree (bitwise reproducible).
-__global__ void __launch_bounds__(256) k_gn_finalize(const float* __restrict__ partial, int chunks, float inv_n, float eps,
+// One 1024-thread block per sample: 32 threads per group stride over the chunks, then a fixed
+// 5-step shuffle tree (bitwise reproducible).
+__global__ void __launch_bounds__(1024) k_gn_finalize(const float* __restrict__ partial, int chunks, float inv_n, float eps,
                                                      float* __restrict__ mr) {
     const int sample = blockIdx.x;
-    const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const int g = threadIdx.x >> 5, sub = threadIdx.x & 31;
     float s1 = 0.f, s2 = 0.f;
-    for (int ch = sub; ch < chunks; ch += 8) {
+    for (int ch = sub; ch < chunks; ch += 32) {
         const float* st = partial + (((size_t)sample * chunks + ch) * 32 + g) * 2;
         s1 += st[0];
         s2 += st[1];
     }
 #pragma unroll
-    for (int o = 4; o > 0; o >>= 1) {
-        s1 += __shfl_down(s1, o, 8);
-        s2 += __shfl_down(s2, o, 8);
+    for (int o = 16; o > 0; o >>= 1) {
+        s1 += __shfl_down(s1, o, 32);
+        s2 += __shfl_down(s2, o, 32);
     }
     if (sub == 0) {
         float mean = s1 * inv_n;
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) k_geglu(const __half* __restrict__ x, __h
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float g = (float)gv[e];
-            float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752f));
+            float ge = gelu_erf(g);
             o[e] = (_Float16)((float)hv[e] * ge);
         }
         *(half8*)(y + row * D + cv * 8) = o;
@@ -255,7 +255,7 @@ extern "C" int syn3r_groupnorm_f16(const void* x, void* y, int samples, int rows
     float* partial = (float*)workspace;
     float* meanrstd = partial + (size_t)samples * chunks * 64;
     SYN3R_LAUNCH(k_gn_stats, grid, dim3(threads), lds, stream, (const __half*)x, rows, C, rows_per_block, partial);
-    SYN3R_LAUNCH(k_gn_finalize, dim3(samples), dim3(256), 0, stream, (const float*)partial, chunks,
+    SYN3R_LAUNCH(k_gn_finalize, dim3(samples), dim3(1024), 0, stream, (const float*)partial, chunks,
                  1.0f / ((float)rows * (float)(C / 32)), eps, meanrstd);
     if (silu)
         SYN3R_LAUNCH(k_gn_apply<true>, grid, dim3(threads), 0, stream, (const __half*)x, (__half*)y, rows, C,

@@ -38,6 +38,11 @@ for bm in BMS:
           w = (torch.randn(N, K, device=dev) * K ** -0.5).to(H)
           ms = timeit(lambda: ops.linear(a, w))
           rows.append((name, tag, M, N, K, ms, 2.0 * M * N * K / ms / 1e9))
+      a = torch.randn(M, C, device=dev).to(H)
+      w8 = (torch.randn(8 * C, C, device=dev) * C ** -0.5).to(H)
+      wp, bp, D = ops.pack_geglu(w8, torch.zeros(8 * C, device=dev, dtype=H))
+      ms = timeit(lambda: ops.linear_geglu(a, wp, bp, D))
+      rows.append((name, "ff1+geglu", M, 8 * C, C, ms, 2.0 * M * 8 * C * C / ms / 1e9))
       h, w_ = {"L0": (72, 128), "L1": (36, 64), "L2": (18, 32), "L3": (9, 16)}[name]
       xi = x.view(BF, h, w_, C)
       wc = (torch.randn(C, 3, 3, C, device=dev) * (9 * C) ** -0.5).to(H)

@@ -1,0 +1,19 @@
+"""Per-kernel device time of one SVD (step, pass) unit (developer tool)."""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+from syn3r_amd import _lib as L
+from syn3r_amd.pipeline.svd_step import SvdStepBench
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 14
+b = SvdStepBench(F, torch.device("cuda", 0))
+b.step_pass(); torch.cuda.synchronize()
+n = 3
+with L.kernel_trace() as tr:
+    for _ in range(n):
+        b.step_pass()
+    torch.cuda.synchronize()
+tot = sum(v[1] for v in tr.result.values())
+for k, (c, ms) in sorted(tr.result.items(), key=lambda kv: -kv[1][1]):
+    print(f"{k:28s} {c // n:5d} launches  {ms / n:8.3f} ms  {100 * ms / tot:5.1f} %")
+print(f"total traced {tot / n:.2f} ms per unit")
