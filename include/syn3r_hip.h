@@ -50,7 +50,8 @@ const char* syn3r_arch(void);
  * Per-kernel timing for bench.py's roofline line: while enabled, every kernel
  * launch is bracketed by HIP events recorded on the launch stream.
  * syn3r_trace_report synchronises them, writes one "kernel calls total_ms"
- * line per kernel into buf and clears the trace.
+ * line per kernel into buf and clears the trace.  on = 2 additionally puts
+ * the contraction shape into the kernel name (per-shape tuning tables).
  */
 int syn3r_trace_enable(int on);
 /* restrict the tracer to kernels whose name contains one of the comma-separated substrings ("" = all):

@@ -166,19 +166,20 @@ class kernel_trace:
     """Context manager: per-kernel HIP-event timing of everything launched inside.
     `.result` maps kernel name -> (calls, total_ms)."""
 
-    def __init__(self, only: str = ""):
+    def __init__(self, only: str = "", detail: bool = False):
         self.only = only
+        self.detail = detail    # contraction launches are reported per shape
 
     def __enter__(self):
         load().syn3r_trace_filter(self.only.encode())
-        load().syn3r_trace_enable(1)
+        load().syn3r_trace_enable(2 if self.detail else 1)
         self.result = {}
         return self
 
     def __exit__(self, *exc):
         lib = load()
         lib.syn3r_trace_enable(0)
-        buf = C.create_string_buffer(1 << 16)
+        buf = C.create_string_buffer(1 << 18)
         lib.syn3r_trace_report(buf, len(buf))
         for line in buf.value.decode().splitlines():
             name, calls, ms = line.rsplit(" ", 2)

@@ -27,6 +27,7 @@ namespace {
 struct Span { std::string name; hipEvent_t a, b; };
 std::mutex g_mu;
 bool g_on = false;
+bool g_detail = false;
 std::string g_filter;   // comma-separated substrings; empty = every kernel
 std::vector<Span> g_spans;
 std::vector<hipEvent_t> g_pool;
@@ -39,6 +40,7 @@ hipEvent_t get_event() {
 }  // namespace
 
 bool trace_on() { return g_on; }
+bool trace_detail() { return g_detail; }
 static bool wanted(const char* name) {
     if (g_filter.empty()) return true;
     size_t pos = 0;
@@ -70,6 +72,7 @@ void trace_end(hipStream_t stream) {
 extern "C" int syn3r_trace_enable(int on) {
     std::lock_guard<std::mutex> lk(syn3r::g_mu);
     syn3r::g_on = on != 0;
+    syn3r::g_detail = on == 2;
     return SYN3R_OK;
 }
 

@@ -24,6 +24,7 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Optional per-kernel timing with HIP events on the launch stream (syn3r_trace_* in the ABI).
 bool trace_on();
+bool trace_detail();   // syn3r_trace_enable(2): contraction launches carry their shape in the name
 void trace_begin(const char* name, hipStream_t stream);
 void trace_end(hipStream_t stream);
 
@@ -47,6 +48,14 @@ struct Mat3d { double m[9]; };
 #define SYN3R_LAUNCH(kernel, grid, block, shmem, stream, ...)                        \
     do {                                                                             \
         if (syn3r::trace_on()) syn3r::trace_begin(#kernel, stream);                  \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);         \
+        if (syn3r::trace_on()) syn3r::trace_end(stream);                             \
+    } while (0)
+
+// same, with an explicit trace name (template instantiations, per-shape detail)
+#define SYN3R_LAUNCH_NAMED(name, kernel, grid, block, shmem, stream, ...)            \
+    do {                                                                             \
+        if (syn3r::trace_on()) syn3r::trace_begin(name, stream);                     \
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);         \
         if (syn3r::trace_on()) syn3r::trace_end(stream);                             \
     } while (0)

@@ -76,6 +76,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
     // C[row i*16 + (lane&15)][col j*16 + (lane>>4)*4 + r]: four CONSECUTIVE output columns per lane ->
     // one 8-byte LDS store per accumulator tile (20 per lane).
     typedef _Float16 half4e __attribute__((ext_vector_type(4)));
+    // The residual rows this lane will add in the store loop are requested NOW, so their HBM latency hides
+    // behind the accumulator -> LDS staging and the block barrier (10 x 16 B per lane; the MFMA fragments
+    // are dead here, so the registers are free).
+    half8 res[WM * (WN / 8) / 64];
+    if (p.residual && p.geglu_D <= 0) {
+#pragma unroll
+        for (int it = 0; it < WM * (WN / 8) / 64; ++it) {
+            const int q = lane + it * 64;
+            int row = q / (WN / 8), ch = q - row * (WN / 8);
+            int m = gm0 + row, n = gn0 + ch * 8;
+            if (m < p.M && n + 8 <= p.N) res[it] = *(const half8*)(p.residual + (long long)m * p.ldr + n);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) res[it][e] = (m < p.M && n + e < p.N) ? ((const _Float16*)p.residual)[(long long)m * p.ldr + n + e] : (_Float16)0.f;
+            }
+        }
+    }
     float bias4[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -155,8 +172,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
         return;
     }
     // 64 rows x 10 chunks of 8 halfs per wavefront
-#pragma unroll 2
-    for (int q = lane; q < WM * (WN / 8); q += 64) {
+    constexpr int NQ = WM * (WN / 8) / 64;   // 10 stores per lane
+#pragma unroll
+    for (int it = 0; it < NQ; ++it) {
+        const int q = lane + it * 64;
         int row = q / (WN / 8), ch = q - row * (WN / 8);
         int m = gm0 + row, n = gn0 + ch * 8;
         if (m >= p.M || n >= p.N) continue;
@@ -166,9 +185,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
             if (p.residual) {
-                half8 rv = *(const half8*)(p.residual + (long long)m * p.ldr + n);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] += p.s_res * (float)rv[e];
+                for (int e = 0; e < 8; ++e) f[e] += p.s_res * (float)res[it][e];
             }
             if (p.aux) {
                 half8 av = *(const half8*)(p.aux + (long long)m * p.ldaux + n);
@@ -539,7 +557,12 @@ int launch_dma_bm(const GemmParams& p, hipStream_t stream) {
         attr_set = true;
     }
     int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    SYN3R_LAUNCH((k_gemm_dma<MODE, BM>), dim3(tiles), dim3(BM * 2), lds, stream, p);
+    char name[96];
+    if (trace_on()) {
+        if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_dma<%d,%d>[M%d,N%d,K%d,e%d]", MODE, BM, p.M, p.N, p.K, p.geglu_D > 0 ? 2 : (p.residual != nullptr));
+        else snprintf(name, sizeof(name), "k_gemm_dma<%d,%d>", MODE, BM);
+    }
+    SYN3R_LAUNCH_NAMED(name, (k_gemm_dma<MODE, BM>), dim3(tiles), dim3(BM * 2), lds, stream, p);
     SYN3R_LAUNCH_CHECK("gemm_dma launch");
     return SYN3R_OK;
 }

@@ -9,11 +9,11 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 14
 b = SvdStepBench(F, torch.device("cuda", 0))
 b.step_pass(); torch.cuda.synchronize()
 n = 3
-with L.kernel_trace() as tr:
+with L.kernel_trace(detail=len(sys.argv) > 2) as tr:
     for _ in range(n):
         b.step_pass()
     torch.cuda.synchronize()
 tot = sum(v[1] for v in tr.result.values())
 for k, (c, ms) in sorted(tr.result.items(), key=lambda kv: -kv[1][1]):
-    print(f"{k:28s} {c // n:5d} launches  {ms / n:8.3f} ms  {100 * ms / tot:5.1f} %")
+    print(f"{k:44s} {c // n:5d} launches  {ms / n:8.3f} ms  {100 * ms / tot:5.1f} %")
 print(f"total traced {tot / n:.2f} ms per unit")
