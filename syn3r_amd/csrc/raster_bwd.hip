@@ -91,7 +91,8 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
     const float T_final = inside ? final_T[pix] : 0.0f;
     float T = T_final;
     const int last_contributor = inside ? (int)n_contrib[pix] : 0;
-    int contributor = total;
+    const float sx0 = (float)(tx * kTileX), sx1 = sx0 + (float)(kTileX - 1);
+    const float sy0 = (float)(ty * kTileY + (threadIdx.x >> 6) * 4), sy1 = sy0 + 3.0f;
     float gr = 0.f, gg = 0.f, gb = 0.f, gD = 0.f, gA = 0.f;
     if (inside) {
         gr = dL_dcolor[pix]; gg = dL_dcolor[hw + pix]; gb = dL_dcolor[2 * hw + pix];
@@ -119,9 +120,20 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
         for (int k = 0; k < kGradSlots / 4; ++k)
             ((float4*)sacc)[threadIdx.x * (kGradSlots / 4) + k] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
-        int cnt = min(kTilePix, todo);
-        for (int j = 0; j < cnt; ++j) {
-            --contributor;
+        const int cnt = min(kTilePix, todo);
+        // visit list of this wavefront's 16 x 4 strip (see k_render): one lane-test per staged splat, then a
+        // scalar walk over the ballot; splats that cannot reach alpha >= 1/255 on the strip are never evaluated
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+          bool hit = false;
+          if (c0 + lane < cnt) {
+              const float4 ta = sm[(c0 + lane) * 3], tb = sm[(c0 + lane) * 3 + 1];
+              hit = splat_reaches_rect(ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, sx0, sx1, sy0, sy1);
+          }
+          unsigned long long vm = __ballot(hit);
+          while (vm) {
+            const int j = c0 + (int)__builtin_ctzll(vm);
+            vm &= vm - 1;
+            const int contributor = total - 1 - (rd * kTilePix + j);
             float4 a = sm[j * 3], b = sm[j * 3 + 1], c = sm[j * 3 + 2];
             float dx = a.x - fx, dy = a.y - fy;
             float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
@@ -161,6 +173,7 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
             }
             float s = butterfly16(v, lane);
             if ((lane & 3) == 0 && (lane >> 2) < G_USED) atomicAdd(&sacc[j * kGradSlots + (lane >> 2)], s);   // LDS, 10 banks
+          }
         }
         // one global atomic per (tile, splat) instead of one per (wavefront, splat): 16 lanes per record, so a
         // wave-instruction covers four contiguous 64-byte records

@@ -82,6 +82,38 @@ GeomState carve_geom(void* buf, int N);
 ImageState carve_image(void* buf, int H, int W);
 BinningState carve_binning(void* buf, long long P);
 
+#ifdef __HIPCC__
+// Conservative reach test used by the blend kernels to build per-wavefront visit lists: can the splat
+// (pixel mean (mx,my), conic (A,B,C), opacity op) reach alpha >= kAlphaMin at ANY pixel centre of the
+// rectangle [x0,x1] x [y0,y1]?  alpha = op * exp(-q/2) with q the conic's quadratic form, so the question is
+// whether min q over the rectangle is <= 2 ln(255 op).  q is convex with its minimum at the mean: inside the
+// rectangle the minimum is 0, otherwise it lies on an edge facing the mean, where q is a 1-D parabola whose
+// clamped vertex is closed-form.  A margin keeps every pair the per-pixel test could accept despite rounding;
+// pairs rejected here contribute exactly nothing in the unculled traversal, so results are unchanged.
+__device__ __forceinline__ bool splat_reaches_rect(float mx, float my, float A, float B, float C, float op, float x0,
+                                                   float x1, float y0, float y1) {
+    if (!(A > 0.0f && C > 0.0f)) return true;              // not a proper conic: let the per-pixel test decide
+    const float thr = 2.0f * __logf(255.0f * op);          // q must not exceed this (NaN / negative: unreachable)
+    const float dx0 = x0 - mx, dx1 = x1 - mx, dy0 = y0 - my, dy1 = y1 - my;
+    const bool inx = dx0 <= 0.0f && dx1 >= 0.0f, iny = dy0 <= 0.0f && dy1 >= 0.0f;
+    float qmin = 0.0f;
+    if (!(inx && iny)) {
+        qmin = 3.0e38f;
+        if (!inx) {                                        // the vertical edge facing the mean
+            const float dx = dx0 > 0.0f ? dx0 : dx1;
+            const float dy = fminf(fmaxf(-B * dx / C, dy0), dy1);
+            qmin = A * dx * dx + 2.0f * B * dx * dy + C * dy * dy;
+        }
+        if (!iny) {                                        // the horizontal edge facing the mean
+            const float dy = dy0 > 0.0f ? dy0 : dy1;
+            const float dx = fminf(fmaxf(-B * dy / A, dx0), dx1);
+            qmin = fminf(qmin, A * dx * dx + 2.0f * B * dx * dy + C * dy * dy);
+        }
+    }
+    return qmin <= thr + (1.0e-3f + 1.0e-4f * thr);
+}
+#endif
+
 // camera passed by value to kernels
 struct Camera {
     float view[16];     // world->view, column-major (x' = v[0]x + v[4]y + v[8]z + v[12])
