@@ -73,10 +73,10 @@ class RasterLoop:
         self.P = 0
 
     def iteration(self):
-        from syn3r_amd.raster import _Rasterize
+        from syn3r_amd.gs.train_ops import l1_loss
         p = self.p
         color, radii, depth, alpha = self.rast(p["m"], self.m2, p["o"], shs=p["sh"], scales=p["s"], rotations=p["q"])
-        loss = (color - self.target).abs().mean()
+        loss = l1_loss(color, self.target)
         loss.backward()
         for t in list(p.values()) + [self.m2]:
             t.grad = None

@@ -330,6 +330,29 @@ int syn3r_layernorm_f16(const void* x, void* y, void* xsum, const void* addvec, 
 /* GEGLU gate (activations.py GEGLU.forward): y[M,D] = x[:, :D] * gelu_erf(x[:, D:]) for x [M, 2D]. */
 int syn3r_geglu_f16(const void* x, void* y, long long M, int D, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Trainer-loop pieces adjacent to the rasteriser.  The reference runs them inside FSGS'
+ * gsTrainer.training()/finetune() (call sites model/diffusionGS.py:139, 1640; submodule not vendored) as
+ * torch elementwise chains; the published 3DGS step is Ll1 = |render - gt|.mean() and
+ * torch.optim.Adam(eps = 1e-15).
+ * ------------------------------------------------------------------------ */
+
+/* loss[0] = weight * mean(|image - target|) over n floats (device scalar; deterministic two-level sum).
+ * ws: syn3r_l1_loss_workspace_bytes(n) bytes of device scratch. */
+size_t syn3r_l1_loss_workspace_bytes(long long n);
+int syn3r_l1_loss(const float* image, const float* target, long long n, float weight, float* loss, void* ws,
+                  size_t ws_bytes, void* stream);
+/* grad_image[i] = grad_loss[0] * weight / n * sign(image[i] - target[i]); grad_loss is a DEVICE scalar
+ * (NULL = 1), so autograd's upstream gradient never visits the host. */
+int syn3r_l1_loss_backward(const float* image, const float* target, long long n, float weight,
+                           const float* grad_loss, float* grad_image, void* stream);
+
+/* One torch.optim.Adam update (no weight decay, no amsgrad) of n fp32 parameters in place, in torch's
+ * operation order: exp_avg.lerp_(g, 1-beta1); exp_avg_sq = beta2*exp_avg_sq + (1-beta2)*g*g;
+ * param -= lr/(1-beta1^step) * exp_avg / (sqrt(exp_avg_sq)/sqrt(1-beta2^step) + eps).  step is 1-based. */
+int syn3r_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                    float beta1, float beta2, float eps, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,13 +6,12 @@
 // reference CUDA source absent).  Gradients are validated against autograd
 // through oracle/raster_oracle.py.
 //
-// MI355X mapping: per splat a wavefront has up to 64 pixel contributions to 10 quantities.
-// They are summed with a 17-shuffle butterfly (16 padded values over 64 lanes: 8+4+2+1
-// exchange steps halve the live values while doubling the lanes summed, then 2 quad steps),
-// which leaves value k on lane 4k; those 16 lanes issue ONE atomic wave-instruction onto a
-// contiguous 64-byte gradient record (MI355X float atomics want contiguous segments,
-// MI355X_MICROARCH.md "Global float atomics").  Wavefronts where no pixel contributes skip
-// the splat entirely.
+// MI355X mapping: each wavefront owns a 16 x 4 pixel strip of the tile and walks only the splats that can
+// reach alpha >= 1/255 on that strip (splat_reaches_rect, raster_common.h).  Per visited splat the up to 64
+// pixel contributions to 10 quantities are summed by reduce12 (two half/row swap levels + DPP row rotates,
+// 30 VALU instructions), accumulated per (tile, splat) in LDS across the four wavefronts, and flushed with
+// ONE atomic per record slot onto a contiguous 64-byte gradient record (MI355X float atomics want
+// contiguous segments, MI355X_MICROARCH.md "Global float atomics").
 #include "common.h"
 #include "raster_common.h"
 
@@ -35,39 +34,37 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     return start + k;
 }
 
-// Sum v[k] over the 64 lanes; on return lane 4k holds the total of value k in the return value.
-// The two widest exchange levels use gfx950's half/row swaps (v_permlane32_swap, v_permlane16_swap): one
-// VALU instruction moves BOTH directions of the exchange (lower lanes keep value k and receive the
-// partner's k, upper lanes keep k+8 and receive the partner's k+8), so a level is a swap and an add per
-// surviving value — no LDS-pipe ds_bpermute and no selects.  The xor-8 level is a DPP row rotate.
-__device__ __forceinline__ float butterfly16(float (&v)[16], int lane) {
-    float w8[8], w4[4], w2[2];
-    const bool b3 = lane & 8, b2 = lane & 4;
+// Sum each of 12 per-lane values over the 64 lanes.  Returns, on lane l with (l & 15) < 3, the total of value
+// 3 * (l >> 4) + (l & 15)  (each 16-lane row ends up owning three consecutive values).
+// Two transposing levels use gfx950's half/row swaps (v_permlane32_swap, v_permlane16_swap): one VALU
+// instruction moves BOTH directions of the exchange, so a level costs a swap and an add per surviving value
+// and halves the number of live registers (12 -> 6 -> 3).  The last four levels stay inside a 16-lane row and
+// are v_add_f32 with a DPP row rotate (shift and add in one instruction); no LDS-pipe ds_bpermute anywhere.
+__device__ __forceinline__ float reduce12(float (&v)[12], int lane) {
+    float w6[6], w3[3];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {   // lanes 32-63 of v[k] <-> lanes 0-31 of v[k+8]
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v[k]), __float_as_int(v[k + 8]), false, false);
-        w8[k] = __int_as_float(r[0]) + __int_as_float(r[1]);
+    for (int k = 0; k < 6; ++k) {   // lanes 32-63 of v[k] <-> lanes 0-31 of v[k+6]: lower half owns k, upper k+6
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v[k]), __float_as_int(v[k + 6]), false, false);
+        w6[k] = __int_as_float(r[0]) + __int_as_float(r[1]);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {   // odd 16-lane rows of w8[k] <-> even rows of w8[k+4]
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(w8[k]), __float_as_int(w8[k + 4]), false, false);
-        w4[k] = __int_as_float(r[0]) + __int_as_float(r[1]);
+    for (int k = 0; k < 3; ++k) {   // odd 16-lane rows of w6[k] <-> even rows of w6[k+3]: even rows own k, odd k+3
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(w6[k]), __float_as_int(w6[k + 3]), false, false);
+        w3[k] = __int_as_float(r[0]) + __int_as_float(r[1]);
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {   // xor 8 == rotate the 16-lane row by 8
-        float send = b3 ? w4[k] : w4[k + 2];
-        float keep = b3 ? w4[k + 2] : w4[k];
-        int recv = __builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128 /* row_ror:8 */, 0xF, 0xF, false);
-        w2[k] = keep + __int_as_float(recv);
+    for (int k = 0; k < 3; ++k) {
+        w3[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w3[k]), 0x128 /* row_ror:8 */, 0xF, 0xF, false));
+        w3[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w3[k]), 0x124 /* row_ror:4 */, 0xF, 0xF, false));
+        w3[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w3[k]), 0x122 /* row_ror:2 */, 0xF, 0xF, false));
+        w3[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w3[k]), 0x121 /* row_ror:1 */, 0xF, 0xF, false));
     }
-    float send = b2 ? w2[0] : w2[1];
-    float keep = b2 ? w2[1] : w2[0];
-    float w1 = keep + __shfl_xor(send, 4, 64);
-    w1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w1), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false));
-    w1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w1), 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, false));
-    return w1;   // value index = bit2 + 2*bit3 + 4*bit4 + 8*bit5 = lane >> 2
+    const int c = lane & 15;
+    return c == 0 ? w3[0] : (c == 1 ? w3[1] : w3[2]);
 }
 
+// value index -> slot of the 64-byte gradient record, for the lane layout reduce12 returns:
+// row 0 (lower half, even row) owns v[0..2], row 1 owns v[3..5], row 2 owns v[6..8], row 3 owns v[9..11]
 __global__ void __launch_bounds__(kTilePix) k_render_bwd(
     int H, int W, int gx, int gy, const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list,
     const Splat* __restrict__ splats, float bg0, float bg1, float bg2, const unsigned* __restrict__ n_contrib,
@@ -141,9 +138,9 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
             float alpha = fminf(kAlphaMax, b.y * G);
             bool active = (contributor < last_contributor) && (power <= 0.0f) && (alpha >= kAlphaMin);
             if (__ballot(active) == 0ull) continue;   // wave-uniform
-            float v[16];
+            float v[12];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = 0.0f;
+            for (int k = 0; k < 12; ++k) v[k] = 0.0f;
             if (active) {
                 const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);   // 1 ulp reciprocal: one instruction, not a 10-op IEEE divide
                 T = T * inv1ma;
@@ -171,8 +168,9 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
                 v[G_CYY] = -0.5f * gdy * dy * dL_dG;
                 v[G_OP] = G * dL_da;
             }
-            float s = butterfly16(v, lane);
-            if ((lane & 3) == 0 && (lane >> 2) < G_USED) atomicAdd(&sacc[j * kGradSlots + (lane >> 2)], s);   // LDS, 10 banks
+            float s = reduce12(v, lane);
+            const int slot = 3 * (lane >> 4) + (lane & 15);
+            if ((lane & 15) < 3 && slot < G_USED) atomicAdd(&sacc[j * kGradSlots + slot], s);   // LDS, 10 banks
           }
         }
         // one global atomic per (tile, splat) instead of one per (wavefront, splat): 16 lanes per record, so a

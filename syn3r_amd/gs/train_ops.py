@@ -1,0 +1,89 @@
+"""Fused trainer-loop operators on the HIP library: the photometric L1 loss and the Adam
+update that `gsTrainer.training()/finetune()` (call sites `model/diffusionGS.py:139,1640`; FSGS submodule not
+vendored) run as torch elementwise chains.  No CPU fallback: they raise `Syn3rError` without the extension."""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+
+from .. import _lib as L
+
+
+class _L1Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image: torch.Tensor, target: torch.Tensor, weight: float):
+        L.require_gpu(image, target)
+        if image.shape != target.shape or image.dtype != torch.float32 or target.dtype != torch.float32:
+            raise ValueError("l1_loss: image and target must be float32 tensors of the same shape")
+        image, target = image.contiguous(), target.contiguous()
+        lib = L.load()
+        n = image.numel()
+        loss = torch.empty((), dtype=torch.float32, device=image.device)
+        ws = L.workspace(image.device, lib.syn3r_l1_loss_workspace_bytes(n), "l1")
+        L.check(lib.syn3r_l1_loss(L.ptr(image), L.ptr(target), n, float(weight), L.ptr(loss), L.ptr(ws), ws.numel(),
+                                  L.stream_ptr(image.device)), "l1_loss")
+        ctx.save_for_backward(image, target)
+        ctx.weight = float(weight)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss: torch.Tensor):
+        image, target = ctx.saved_tensors
+        lib = L.load()
+        go = grad_loss.to(torch.float32).contiguous()
+        grad = torch.empty_like(image)
+        L.check(lib.syn3r_l1_loss_backward(L.ptr(image), L.ptr(target), image.numel(), ctx.weight, L.ptr(go),
+                                           L.ptr(grad), L.stream_ptr(image.device)), "l1_loss_backward")
+        return grad, None, None
+
+
+def l1_loss(image: torch.Tensor, target: torch.Tensor, weight: float = 1.0) -> torch.Tensor:
+    """`weight * (image - target).abs().mean()` as one read of both images (forward) and one read + one write
+    (backward); the upstream gradient stays on the device."""
+    return _L1Loss.apply(image, target, weight)
+
+
+class FusedAdam:
+    """`torch.optim.Adam(param_groups, eps=...)` (no weight decay / amsgrad) with one kernel per parameter tensor.
+    Keeps torch's `param_groups` / `state` layout so checkpoints and lr schedules written for the torch optimiser
+    keep working."""
+
+    def __init__(self, param_groups: Iterable[dict], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.param_groups: List[dict] = []
+        for g in param_groups:
+            g = dict(g)
+            g["params"] = list(g["params"])
+            g.setdefault("lr", lr)
+            g.setdefault("betas", betas)
+            g.setdefault("eps", eps)
+            self.param_groups.append(g)
+        self.state: dict = {}
+
+    def zero_grad(self, set_to_none: bool = True):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        lib = L.load()
+        for g in self.param_groups:
+            b1, b2 = g["betas"]
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                L.require_gpu(p)
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise ValueError("FusedAdam: parameters must be contiguous float32")
+                st = self.state.get(p)
+                if st is None:
+                    st = self.state[p] = {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+                st["step"] += 1
+                grad = p.grad.contiguous()
+                L.check(lib.syn3r_adam_step(L.ptr(p), L.ptr(grad), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
+                                            p.numel(), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+                                            int(st["step"]), L.stream_ptr(p.device)), "adam_step")

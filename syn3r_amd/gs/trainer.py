@@ -3,7 +3,8 @@
 
 The reference delegates all of this to `FSGS.utils.trainer_v4.GSTrainer` (un-vendored submodule): only the
 call surface is visible.  This module provides that surface with the published 3DGS training step
-(render -> L1 photometric loss weighted by the camera confidence -> backward -> Adam), no densification
+(render -> L1 photometric loss weighted by the camera confidence -> backward -> Adam; the loss and the
+Adam update are the fused HIP operators of `train_ops.py`), no densification
 heuristics (out of scope).  Camera conventions follow the published 3DGS/FSGS code:
 `world_view_transform` and `full_proj_transform` are the TRANSPOSED matrices.
 """
@@ -17,6 +18,7 @@ import numpy as np
 import torch
 
 from ..raster import GaussianRasterizationSettings, GaussianRasterizer
+from .train_ops import FusedAdam, l1_loss
 
 
 def _world2view(R: np.ndarray, t: np.ndarray) -> np.ndarray:
@@ -150,7 +152,7 @@ class GSTrainer:
     # ------------------------------------------------------------------ surface used by DiffusionGS
     def reset_optimizers(self):
         g, o = self.gaussians, self.opt
-        self.optimizer = torch.optim.Adam([
+        self.optimizer = FusedAdam([
             {"params": [g._xyz], "lr": o.position_lr}, {"params": [g._features], "lr": o.feature_lr},
             {"params": [g._opacity], "lr": o.opacity_lr}, {"params": [g._scaling], "lr": o.scaling_lr},
             {"params": [g._rotation], "lr": o.rotation_lr}], eps=1e-15)
@@ -190,7 +192,7 @@ class GSTrainer:
     def train_step(self, cam: Optional[Camera] = None) -> float:
         cam = cam or self._pick_camera()
         out = self.render_view(cam)
-        loss = cam.cam_confidence * (out["render"] - cam.original_image).abs().mean()
+        loss = l1_loss(out["render"], cam.original_image, weight=float(cam.cam_confidence))
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.optimizer.step()

@@ -1,0 +1,79 @@
+"""Fused trainer-loop operators (L1 loss, Adam) vs torch on the CPU (the published 3DGS step)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(3, 37, 53), (3, 270, 480), (1, 5), (3, 1080, 1920)])
+def test_l1_loss_forward_backward(shape, gpu):
+    from syn3r_amd.gs.train_ops import l1_loss
+    g = torch.Generator().manual_seed(sum(shape))
+    a = torch.rand(shape, generator=g)
+    b = torch.rand(shape, generator=g)
+    b.view(-1)[::7] = a.view(-1)[::7]                 # exact ties: sign(0) = 0 as torch.sign
+    ad = a.double().requires_grad_(True)
+    ref = 0.3 * (ad - b.double()).abs().mean()
+    (ref * 2.5).backward()
+    x = a.to(gpu).requires_grad_(True)
+    loss = l1_loss(x, b.to(gpu), weight=0.3)
+    (loss * 2.5).backward()
+    assert loss.shape == () and loss.dtype == torch.float32
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 2e-6 * abs(float(ref.detach()))
+    torch.testing.assert_close(x.grad.cpu(), ad.grad.float(), rtol=1e-6, atol=0)
+    # fixed-order reduction: bitwise reproducible
+    again = l1_loss(x.detach(), b.to(gpu), weight=0.3)
+    assert float(again) == float(loss.detach())
+
+
+def test_l1_loss_rejects_bad_input(gpu):
+    from syn3r_amd import _lib
+    from syn3r_amd.gs.train_ops import l1_loss
+    a = torch.rand(3, 8, 8)
+    with pytest.raises(_lib.Syn3rError):
+        l1_loss(a, a.to(gpu))
+    with pytest.raises(ValueError):
+        l1_loss(a.to(gpu), a[:, :4].to(gpu))
+    with pytest.raises(ValueError):
+        l1_loss(a.to(gpu).half(), a.to(gpu).half())
+
+
+def test_fused_adam_matches_torch_adam(gpu):
+    from syn3r_amd.gs.train_ops import FusedAdam
+    g = torch.Generator().manual_seed(5)
+    shapes = [(1000, 3), (1000, 16, 3), (1000, 1), (777,)]
+    lrs = [1.6e-4, 2.5e-3, 5e-2, 1e-3]
+    ref_p = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    hip_p = [p.detach().clone().to(gpu).requires_grad_(True) for p in ref_p]
+    ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(ref_p, lrs)], eps=1e-15)
+    hip = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(hip_p, lrs)], eps=1e-15)
+    for it in range(25):
+        for rp, hp in zip(ref_p, hip_p):
+            gr = torch.randn(rp.shape, generator=g) * (10.0 ** (-(it % 4)))
+            if it == 3:
+                gr[::5] = 0.0                         # zero gradients with eps = 1e-15 (0/eps path)
+            rp.grad = gr
+            hp.grad = gr.to(gpu)
+        ref.step()
+        hip.step()
+    for rp, hp in zip(ref_p, hip_p):
+        torch.testing.assert_close(hp.detach().cpu(), rp.detach(), rtol=2e-6, atol=1e-7)
+        st = hip.state[hp]
+        # moments: one fp32 rounding of the O(1) gradient terms survives cancellation -> absolute floor ~1 ulp(1)
+        torch.testing.assert_close(st["exp_avg"].cpu(), ref.state[rp]["exp_avg"], rtol=1e-5, atol=2e-7)
+        torch.testing.assert_close(st["exp_avg_sq"].cpu(), ref.state[rp]["exp_avg_sq"], rtol=1e-5, atol=2e-7)
+    hip.zero_grad()
+    assert all(p.grad is None for p in hip_p)
+
+
+def test_fused_adam_skips_params_without_grad_and_rejects_cpu(gpu):
+    from syn3r_amd import _lib
+    from syn3r_amd.gs.train_ops import FusedAdam
+    p = torch.ones(10, device=gpu, requires_grad=True)
+    opt = FusedAdam([{"params": [p]}], lr=0.1)
+    opt.step()                                        # no grad: untouched, no state
+    assert bool((p == 1).all()) and p not in opt.state
+    q = torch.ones(10, requires_grad=True)
+    q.grad = torch.ones(10)
+    with pytest.raises(_lib.Syn3rError):
+        FusedAdam([{"params": [q]}]).step()
