@@ -46,8 +46,14 @@ struct GeomState {
     float* rgb;              // [N,3]
     unsigned* clamped;       // [N] bit c set if colour channel c was clamped at 0
     unsigned* tiles_touched; // [N]
-    unsigned* point_offsets; // [N] exclusive scan of tiles_touched
+    unsigned* point_offsets; // [N] exclusive scan of tiles_touched IN DEPTH ORDER (entry i belongs to order[i])
     Splat* splats;           // [N]
+    unsigned* dkeys_a;       // [N] depth bits of the visible Gaussians (0xFFFFFFFF otherwise), sort ping
+    unsigned* dkeys_b;       // [N] sort pong
+    unsigned* order_a;       // [N] Gaussian ids by ascending depth (stable), sort ping
+    unsigned* order_b;       // [N] sort pong
+    unsigned* order;         // whichever of order_a / order_b holds the result (4 passes: order_a)
+    void* sort_scratch;      // argsort histograms
     void* scan_scratch;
 };
 
@@ -58,7 +64,7 @@ struct ImageState {
 };
 
 struct BinningState {
-    unsigned long long* keys_a;
+    unsigned long long* keys_a;   // the rasteriser stores u32 tile ids here (half of each array is used)
     unsigned long long* keys_b;
     unsigned* vals_a;
     unsigned* vals_b;
@@ -70,7 +76,13 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t scan_scratch_bytes(size_t n);
 size_t sort_scratch_bytes(size_t n);
 int exclusive_scan_u32(const unsigned* in, unsigned* out, size_t n, unsigned* total_out, void* scratch,
-                       hipStream_t stream);
+                       hipStream_t stream, const unsigned* perm = nullptr);   // perm: scan in[perm[i]]
+// stable argsort of n u32 keys (vals_a is NOT read: element i carries i); 4 passes of 8 bits
+int argsort_depth_u32(unsigned* keys_a, unsigned* vals_a, unsigned* keys_b, unsigned* vals_b, size_t n, void* scratch,
+                      hipStream_t stream, int* result_in_b);
+// stable sort of (u32 tile id, u32 Gaussian id) pairs on the low nbits of the key; 7-bit digits
+int sort_pairs_by_tile_u32(unsigned* keys_a, unsigned* vals_a, unsigned* keys_b, unsigned* vals_b, size_t n, int nbits,
+                           void* scratch, hipStream_t stream, int* result_in_b, const unsigned* n_dev);
 int radix_sort_pairs(unsigned long long* keys_a, unsigned* vals_a, unsigned long long* keys_b, unsigned* vals_b,
                      size_t n, int nbits, void* scratch, hipStream_t stream, int* result_in_b,
                      const unsigned* n_dev = nullptr);

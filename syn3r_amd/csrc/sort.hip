@@ -6,13 +6,18 @@
 // cub::DeviceRadixSort::SortPairs; a stable LSD radix sort gives the identical
 // order (ties keep duplication order = Gaussian index order).
 //
-// Structure per 8-bit pass:
+// Structure per BITS-wide pass (templated on the key type, u32 or u64, and on the digit width):
 //   k_hist    per-block digit histogram (LDS atomics)        -> hist[digit][block]
-//   scan      3-kernel exclusive scan over hist (digit-major) -> global bases
+//   scan      exclusive scan over hist (digit-major)          -> global bases  (ONE single-block kernel up to
+//             16 k counters, the 3-kernel hierarchy above that)
 //   k_scatter keys stay in registers; per-wave digit histograms, cross-wave
-//             prefix, then per-round wave-level match (8 ballots) gives each key
+//             prefix, then per-round wave-level match (BITS ballots) gives each key
 //             its stable rank; scatter to base + rank.
-// HBM-bound: (8+4) B read + (8+4) B written per pair per pass, + one key read in k_hist.
+// HBM-bound: (key+4) B read + (key+4) B written per pair per pass, + one key read in k_hist.
+//
+// The rasteriser uses two instantiations (raster_fwd.hip): Gaussians by depth bits (u32 keys, 8-bit digits,
+// 4 passes over N elements) and (tile, Gaussian) pairs by tile id (u32 keys, 7-bit digits, 2 passes over P
+// pairs, emitted in depth order) - together the same order as one 45-bit sort of (tile << 32 | depth) keys.
 #include "common.h"
 #include "raster_common.h"
 
@@ -54,13 +59,14 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* s
 }
 
 // phase 1: per-chunk sums
-__global__ void __launch_bounds__(kScanThreads) k_scan_sums(const unsigned* __restrict__ in, size_t n,
+__global__ void __launch_bounds__(kScanThreads) k_scan_sums(const unsigned* __restrict__ in,
+                                                           const unsigned* __restrict__ perm, size_t n,
                                                            unsigned* __restrict__ sums) {
     __shared__ unsigned smem[17];
     size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * kScanItems;
     unsigned s = 0;
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) s += (base + k < n) ? in[base + k] : 0;
+    for (int k = 0; k < kScanItems; ++k) s += (base + k < n) ? (perm ? in[perm[base + k]] : in[base + k]) : 0;
     unsigned total;
     block_exclusive_scan(s, smem, total);
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
@@ -83,7 +89,8 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_top(unsigned* __restrict_
 }
 
 // phase 3: per-chunk exclusive scan + chunk offset
-__global__ void __launch_bounds__(kScanThreads) k_scan_final(const unsigned* __restrict__ in, size_t n,
+__global__ void __launch_bounds__(kScanThreads) k_scan_final(const unsigned* __restrict__ in,
+                                                            const unsigned* __restrict__ perm, size_t n,
                                                             const unsigned* __restrict__ sums,
                                                             unsigned* __restrict__ out) {
     __shared__ unsigned smem[17];
@@ -92,7 +99,7 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_final(const unsigned* __r
     unsigned s = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
-        v[k] = (base + k < n) ? in[base + k] : 0;
+        v[k] = (base + k < n) ? (perm ? in[perm[base + k]] : in[base + k]) : 0;
         s += v[k];
     }
     unsigned total;
@@ -104,6 +111,51 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_final(const unsigned* __r
     }
 }
 
+// n <= kScanSmallMax (one sort pass's digit table when it is small): a single 1024-thread block, 16 consecutive
+// elements per thread with 16-byte loads and stores - one launch instead of three.
+constexpr int kSmallItems = 16;
+constexpr size_t kScanSmallMax = (size_t)kScanThreads * kSmallItems;
+__global__ void __launch_bounds__(kScanThreads) k_scan_small(const unsigned* __restrict__ in, size_t n,
+                                                            unsigned* __restrict__ out,
+                                                            unsigned* __restrict__ total_out) {
+    __shared__ unsigned smem[17];
+    const size_t base = (size_t)threadIdx.x * kSmallItems;
+    unsigned v[kSmallItems];
+    unsigned s = 0;
+    const bool full = base + kSmallItems <= n;
+    if (full) {
+        const uint4* src = (const uint4*)(in + base);
+#pragma unroll
+        for (int k = 0; k < kSmallItems / 4; ++k) {
+            uint4 q = src[k];
+            v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kSmallItems; ++k) v[k] = (base + k < n) ? in[base + k] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kSmallItems; ++k) s += v[k];
+    unsigned total;
+    unsigned ex = block_exclusive_scan(s, smem, total);
+#pragma unroll
+    for (int k = 0; k < kSmallItems; ++k) {
+        unsigned t = v[k];
+        v[k] = ex;
+        ex += t;
+    }
+    if (full) {
+        uint4* dst = (uint4*)(out + base);
+#pragma unroll
+        for (int k = 0; k < kSmallItems / 4; ++k) dst[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < kSmallItems; ++k)
+            if (base + k < n) out[base + k] = v[k];
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = total;
+}
+
 size_t scan_scratch_bytes(size_t n) {
     size_t chunks = (n + kScanChunk - 1) / kScanChunk;
     return ((chunks * 4 + 255) / 256) * 256 + 256;
@@ -111,17 +163,21 @@ size_t scan_scratch_bytes(size_t n) {
 
 // out[i] = sum(in[0..i-1]); *total_out = sum of all (device pointer, may be null). in may alias out.
 int exclusive_scan_u32(const unsigned* in, unsigned* out, size_t n, unsigned* total_out, void* scratch,
-                       hipStream_t stream) {
+                       hipStream_t stream, const unsigned* perm) {
     if (n == 0) {
         if (total_out) return check_hip(hipMemsetAsync(total_out, 0, 4, stream), "memset");
+        return SYN3R_OK;
+    }
+    if (!perm && n <= kScanSmallMax && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0) {
+        SYN3R_LAUNCH(k_scan_small, dim3(1), dim3(kScanThreads), 0, stream, in, n, out, total_out);
         return SYN3R_OK;
     }
     size_t chunks = (n + kScanChunk - 1) / kScanChunk;
     if (chunks > (1u << 30)) { set_error("scan: too many elements"); return SYN3R_E_INVALID; }
     unsigned* sums = (unsigned*)scratch;
-    SYN3R_LAUNCH(k_scan_sums, dim3((unsigned)chunks), dim3(kScanThreads), 0, stream, in, n, sums);
+    SYN3R_LAUNCH(k_scan_sums, dim3((unsigned)chunks), dim3(kScanThreads), 0, stream, in, perm, n, sums);
     SYN3R_LAUNCH(k_scan_top, dim3(1), dim3(kScanThreads), 0, stream, sums, (int)chunks, total_out);
-    SYN3R_LAUNCH(k_scan_final, dim3((unsigned)chunks), dim3(kScanThreads), 0, stream, in, n, sums, out);
+    SYN3R_LAUNCH(k_scan_final, dim3((unsigned)chunks), dim3(kScanThreads), 0, stream, in, perm, n, sums, out);
     return SYN3R_OK;
 }
 
@@ -139,51 +195,54 @@ __device__ __forceinline__ size_t live_count(size_t n, const unsigned* __restric
     return d < n ? d : n;
 }
 
-__global__ void __launch_bounds__(kSortThreads) k_hist(const unsigned long long* __restrict__ keys, size_t n_cap,
+template <typename K, int BITS>
+__global__ void __launch_bounds__(kSortThreads) k_hist(const K* __restrict__ keys, size_t n_cap,
                                                       const unsigned* __restrict__ n_dev, int shift,
                                                       unsigned* __restrict__ hist, unsigned nblocks) {
+    constexpr int BINS = 1 << BITS;
     const size_t n = live_count(n_cap, n_dev);
-    __shared__ unsigned h[256];
-    h[threadIdx.x] = 0;
+    __shared__ unsigned h[BINS];
+    for (int d = threadIdx.x; d < BINS; d += kSortThreads) h[d] = 0;
     __syncthreads();
     size_t base = (size_t)blockIdx.x * kSortChunk;
 #pragma unroll 4
     for (int r = 0; r < kSortRounds; ++r) {
         size_t i = base + (size_t)r * kSortThreads + threadIdx.x;
-        if (i < n) atomicAdd(&h[(unsigned)(keys[i] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&h[(unsigned)(keys[i] >> shift) & (BINS - 1)], 1u);
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    for (int d = threadIdx.x; d < BINS; d += kSortThreads) hist[(size_t)d * nblocks + blockIdx.x] = h[d];
 }
 
-__global__ void __launch_bounds__(kSortThreads) k_scatter(const unsigned long long* __restrict__ keys_in,
+// vals_in == nullptr: the value of element i is i (first pass of an argsort)
+template <typename K, int BITS>
+__global__ void __launch_bounds__(kSortThreads) k_scatter(const K* __restrict__ keys_in,
                                                          const unsigned* __restrict__ vals_in,
-                                                         unsigned long long* __restrict__ keys_out,
-                                                         unsigned* __restrict__ vals_out, size_t n_cap,
-                                                         const unsigned* __restrict__ n_dev, int shift,
+                                                         K* __restrict__ keys_out, unsigned* __restrict__ vals_out,
+                                                         size_t n_cap, const unsigned* __restrict__ n_dev, int shift,
                                                          const unsigned* __restrict__ bases, unsigned nblocks) {
+    constexpr int BINS = 1 << BITS;
     const size_t n = live_count(n_cap, n_dev);
-    __shared__ unsigned wh[kSortWaves][256];   // per-wave digit counts, then running offsets
+    __shared__ unsigned wh[kSortWaves][BINS];   // per-wave digit counts, then running offsets
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < kSortWaves * 256; i += kSortThreads) (&wh[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < kSortWaves * BINS; i += kSortThreads) (&wh[0][0])[i] = 0;
     __syncthreads();
 
     // wave w owns keys [w*1024, (w+1)*1024) of the block's chunk; round r covers 64 consecutive keys
     const size_t wbase = (size_t)blockIdx.x * kSortChunk + (size_t)wv * kWaveChunk;
-    unsigned long long key[kSortRounds];
+    K key[kSortRounds];
     unsigned val[kSortRounds];
 #pragma unroll
     for (int r = 0; r < kSortRounds; ++r) {
         size_t i = wbase + (size_t)r * 64 + lane;
         bool ok = i < n;
-        key[r] = ok ? keys_in[i] : ~0ull;
-        val[r] = ok ? vals_in[i] : 0u;
-        if (ok) atomicAdd(&wh[wv][(unsigned)(key[r] >> shift) & 255u], 1u);
+        key[r] = ok ? keys_in[i] : (K)~(K)0;
+        val[r] = ok ? (vals_in ? vals_in[i] : (unsigned)i) : 0u;
+        if (ok) atomicAdd(&wh[wv][(unsigned)(key[r] >> shift) & (BINS - 1)], 1u);
     }
     __syncthreads();
-    // digit d (= threadIdx.x): turn per-wave counts into per-wave starting offsets in the output
-    {
-        unsigned d = threadIdx.x;
+    // digit d: turn per-wave counts into per-wave starting offsets in the output
+    for (unsigned d = threadIdx.x; d < (unsigned)BINS; d += kSortThreads) {
         unsigned run = bases[(size_t)d * nblocks + blockIdx.x];
 #pragma unroll
         for (int w = 0; w < kSortWaves; ++w) {
@@ -198,12 +257,12 @@ __global__ void __launch_bounds__(kSortThreads) k_scatter(const unsigned long lo
     for (int r = 0; r < kSortRounds; ++r) {
         size_t i = wbase + (size_t)r * 64 + lane;
         bool ok = i < n;
-        unsigned d = (unsigned)(key[r] >> shift) & 255u;
+        unsigned d = (unsigned)(key[r] >> shift) & (BINS - 1);
         // lanes of this wave with the same digit (invalid lanes form their own group)
         unsigned long long peers = __ballot(ok);
         if (!ok) peers = ~peers;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             unsigned long long m = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
@@ -220,46 +279,70 @@ __global__ void __launch_bounds__(kSortThreads) k_scatter(const unsigned long lo
             keys_out[base + rank] = key[r];
             vals_out[base + rank] = val[r];
         }
-        __syncthreads();  // orders this round's LDS update before the next round's read (all waves run 16 rounds)
+        // a wave only ever touches its own wh[wv][*] row from here on: wave-level ordering is enough
+        __builtin_amdgcn_wave_barrier();
     }
 }
+
+constexpr int kMaxBins = 256;   // widest digit instantiated below
 
 size_t sort_scratch_bytes(size_t n) {
     size_t nblocks = (n + kSortChunk - 1) / kSortChunk;
     if (nblocks == 0) nblocks = 1;
-    size_t hist = ((256 * nblocks * 4 + 255) / 256) * 256;
-    return hist + scan_scratch_bytes(256 * nblocks);
+    size_t hist = (((size_t)kMaxBins * nblocks * 4 + 255) / 256) * 256;
+    return hist + scan_scratch_bytes((size_t)kMaxBins * nblocks);
 }
 
-// Sorts bits [0, nbits) of the keys; nbits is rounded up to a multiple of 8.
+// Sorts bits [0, nbits) of the keys, BITS at a time (nbits is rounded up to a multiple of BITS).
 // Ping-pongs between (keys_a, vals_a) and (keys_b, vals_b); returns which buffer holds the result.
-int radix_sort_pairs(unsigned long long* keys_a, unsigned* vals_a, unsigned long long* keys_b, unsigned* vals_b,
-                     size_t n, int nbits, void* scratch, hipStream_t stream, int* result_in_b, const unsigned* n_dev) {
+// iota_vals: vals_a is not read, element i carries the value i (argsort).
+template <typename K, int BITS>
+int radix_sort_t(K* keys_a, unsigned* vals_a, K* keys_b, unsigned* vals_b, size_t n, int nbits, void* scratch,
+                 hipStream_t stream, int* result_in_b, const unsigned* n_dev, bool iota_vals) {
+    constexpr int BINS = 1 << BITS;
     *result_in_b = 0;
     if (n == 0) return SYN3R_OK;
     size_t nblocks = (n + kSortChunk - 1) / kSortChunk;
     if (nblocks > (1u << 22)) { set_error("sort: too many pairs (%zu)", n); return SYN3R_E_INVALID; }
     unsigned* hist = (unsigned*)scratch;
-    size_t hist_bytes = ((256 * nblocks * 4 + 255) / 256) * 256;
+    size_t hist_bytes = (((size_t)kMaxBins * nblocks * 4 + 255) / 256) * 256;
     void* scan_scratch = (char*)scratch + hist_bytes;
-    int passes = (nbits + 7) / 8;
-    unsigned long long* kin = keys_a; unsigned* vin = vals_a;
-    unsigned long long* kout = keys_b; unsigned* vout = vals_b;
+    int passes = (nbits + BITS - 1) / BITS;
+    K* kin = keys_a; unsigned* vin = vals_a;
+    K* kout = keys_b; unsigned* vout = vals_b;
     for (int p = 0; p < passes; ++p) {
-        int shift = 8 * p;
-        SYN3R_LAUNCH(k_hist, dim3((unsigned)nblocks), dim3(kSortThreads), 0, stream, kin, n, n_dev, shift, hist,
-                           (unsigned)nblocks);
-        int rc = exclusive_scan_u32(hist, hist, 256 * nblocks, nullptr, scan_scratch, stream);
-        if (rc) return rc;
-        SYN3R_LAUNCH(k_scatter, dim3((unsigned)nblocks), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n,
+        int shift = BITS * p;
+        SYN3R_LAUNCH_NAMED("k_hist", (k_hist<K, BITS>), dim3((unsigned)nblocks), dim3(kSortThreads), 0, stream, kin, n,
                            n_dev, shift, hist, (unsigned)nblocks);
-        unsigned long long* tk = kin; kin = kout; kout = tk;
+        int rc = exclusive_scan_u32(hist, hist, (size_t)BINS * nblocks, nullptr, scan_scratch, stream);
+        if (rc) return rc;
+        SYN3R_LAUNCH_NAMED("k_scatter", (k_scatter<K, BITS>), dim3((unsigned)nblocks), dim3(kSortThreads), 0, stream,
+                           (const K*)kin, (const unsigned*)((p == 0 && iota_vals) ? nullptr : vin), kout, vout, n,
+                           n_dev, shift, (const unsigned*)hist, (unsigned)nblocks);
+        K* tk = kin; kin = kout; kout = tk;
         unsigned* tv = vin; vin = vout; vout = tv;
     }
     *result_in_b = (passes & 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return check_hip(e, "radix sort launch");
     return SYN3R_OK;
+}
+
+int radix_sort_pairs(unsigned long long* keys_a, unsigned* vals_a, unsigned long long* keys_b, unsigned* vals_b,
+                     size_t n, int nbits, void* scratch, hipStream_t stream, int* result_in_b, const unsigned* n_dev) {
+    return radix_sort_t<unsigned long long, 8>(keys_a, vals_a, keys_b, vals_b, n, nbits, scratch, stream, result_in_b,
+                                               n_dev, false);
+}
+
+int argsort_depth_u32(unsigned* keys_a, unsigned* vals_a, unsigned* keys_b, unsigned* vals_b, size_t n, void* scratch,
+                      hipStream_t stream, int* result_in_b) {
+    return radix_sort_t<unsigned, 8>(keys_a, vals_a, keys_b, vals_b, n, 32, scratch, stream, result_in_b, nullptr, true);
+}
+
+int sort_pairs_by_tile_u32(unsigned* keys_a, unsigned* vals_a, unsigned* keys_b, unsigned* vals_b, size_t n, int nbits,
+                           void* scratch, hipStream_t stream, int* result_in_b, const unsigned* n_dev) {
+    return radix_sort_t<unsigned, 7>(keys_a, vals_a, keys_b, vals_b, n, nbits, scratch, stream, result_in_b, n_dev,
+                                     false);
 }
 
 }  // namespace syn3r
