@@ -6,8 +6,8 @@
 // reference CUDA source absent).  Gradients are validated against autograd
 // through oracle/raster_oracle.py.
 //
-// MI355X mapping: each wavefront owns a 16 x 4 pixel strip of the tile and walks only the splats that can
-// reach alpha >= 1/255 on that strip (splat_reaches_rect, raster_common.h).  Per visited splat the up to 64
+// MI355X mapping: each wavefront owns an 8 x 8 pixel quadrant of the tile and walks only the splats that can
+// reach alpha >= 1/255 on that quadrant (splat_reaches_rect, raster_common.h).  Per visited splat the up to 64
 // pixel contributions to 10 quantities are summed by reduce12 (two half/row swap levels + DPP row rotates,
 // 30 VALU instructions), accumulated per (tile, splat) in LDS across the four wavefronts, and flushed with
 // ONE atomic per record slot onto a contiguous 64-byte gradient record (MI355X float atomics want
@@ -75,7 +75,10 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
     __shared__ float sacc[kTilePix * kGradSlots];   // per-round gradient records: the 4 wavefronts meet here first
     const unsigned tile = xcd_remap(blockIdx.x, (unsigned)(gx * gy));
     const int tx = tile % gx, ty = tile / gx;
-    const int lx = threadIdx.x % kTileX, ly = threadIdx.x / kTileX;
+    // wavefront w owns the 8 x 8 quadrant (w & 1, w >> 1) of the tile: squarer than a 16 x 4 strip, so fewer
+    // (wavefront, splat) visits for the same covered pixels
+    const int wq = threadIdx.x >> 6, lq = threadIdx.x & 63;
+    const int lx = (wq & 1) * 8 + (lq & 7), ly = (wq >> 1) * 8 + (lq >> 3);
     const int px = tx * kTileX + lx, py = ty * kTileY + ly;
     const bool inside = px < W && py < H;
     const float fx = (float)px, fy = (float)py;
@@ -88,8 +91,8 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
     const float T_final = inside ? final_T[pix] : 0.0f;
     float T = T_final;
     const int last_contributor = inside ? (int)n_contrib[pix] : 0;
-    const float sx0 = (float)(tx * kTileX), sx1 = sx0 + (float)(kTileX - 1);
-    const float sy0 = (float)(ty * kTileY + (threadIdx.x >> 6) * 4), sy1 = sy0 + 3.0f;
+    const float sx0 = (float)(tx * kTileX + (wq & 1) * 8), sx1 = sx0 + 7.0f;
+    const float sy0 = (float)(ty * kTileY + (wq >> 1) * 8), sy1 = sy0 + 7.0f;
     float gr = 0.f, gg = 0.f, gb = 0.f, gD = 0.f, gA = 0.f;
     if (inside) {
         gr = dL_dcolor[pix]; gg = dL_dcolor[hw + pix]; gb = dL_dcolor[2 * hw + pix];
@@ -118,8 +121,8 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
             ((float4*)sacc)[threadIdx.x * (kGradSlots / 4) + k] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
         const int cnt = min(kTilePix, todo);
-        // visit list of this wavefront's 16 x 4 strip (see k_render): one lane-test per staged splat, then a
-        // scalar walk over the ballot; splats that cannot reach alpha >= 1/255 on the strip are never evaluated
+        // visit list of this wavefront's quadrant (see k_render): one lane-test per staged splat, then a
+        // scalar walk over the ballot; splats that cannot reach alpha >= 1/255 on the quadrant are never evaluated
         for (int c0 = 0; c0 < cnt; c0 += 64) {
           bool hit = false;
           if (c0 + lane < cnt) {

@@ -8,7 +8,7 @@
 // oracle/raster_oracle.py.
 //
 // MI355X mapping: one 16x16 tile = one 256-thread workgroup = 4 wavefronts, a
-// wavefront covers 4 rows x 16 pixels.  Sorted splats are staged through LDS in
+// wavefront covers an 8 x 8 quadrant.  Sorted splats are staged through LDS in
 // batches of 256 as 48-byte records (3 x 16-byte loads per lane, broadcast reads
 // in the blend loop).  Tiles are dealt to XCDs in contiguous chunks so that
 // neighbouring tiles (which share splats) hit the same L2.
@@ -344,7 +344,10 @@ __global__ void __launch_bounds__(kTilePix) k_render(int H, int W, int gx, int g
     __shared__ float4 sm[kTilePix * 3];
     const unsigned tile = xcd_remap(blockIdx.x, (unsigned)(gx * gy));
     const int tx = tile % gx, ty = tile / gx;
-    const int lx = threadIdx.x % kTileX, ly = threadIdx.x / kTileX;
+    // wavefront w owns the 8 x 8 quadrant (w & 1, w >> 1) of the tile: squarer than a 16 x 4 strip, so fewer
+    // (wavefront, splat) visits for the same covered pixels
+    const int wq = threadIdx.x >> 6, lq = threadIdx.x & 63;
+    const int lx = (wq & 1) * 8 + (lq & 7), ly = (wq >> 1) * 8 + (lq >> 3);
     const int px = tx * kTileX + lx, py = ty * kTileY + ly;
     const bool inside = px < W && py < H;
     const float fx = (float)px, fy = (float)py;
@@ -356,10 +359,9 @@ __global__ void __launch_bounds__(kTilePix) k_render(int H, int W, int gx, int g
     float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dp = 0.f;
     unsigned last = 0;
     int todo = total;
-    // this wavefront's pixels: a 16 x 4 strip of the tile
     const int lane = threadIdx.x & 63;
-    const float sx0 = (float)(tx * kTileX), sx1 = sx0 + (float)(kTileX - 1);
-    const float sy0 = (float)(ty * kTileY + (threadIdx.x >> 6) * 4), sy1 = sy0 + 3.0f;
+    const float sx0 = (float)(tx * kTileX + (wq & 1) * 8), sx1 = sx0 + 7.0f;
+    const float sy0 = (float)(ty * kTileY + (wq >> 1) * 8), sy1 = sy0 + 7.0f;
     for (int rd = 0; rd < rounds; ++rd, todo -= kTilePix) {
         if (__syncthreads_count(done) == kTilePix) break;
         int idx = rd * kTilePix + threadIdx.x;
@@ -372,9 +374,9 @@ __global__ void __launch_bounds__(kTilePix) k_render(int H, int W, int gx, int g
         }
         __syncthreads();
         const int cnt = min(kTilePix, todo);
-        // Visit list: each lane tests ONE staged splat against the wavefront's strip (splat_reaches_rect); the
+        // Visit list: each lane tests ONE staged splat against the wavefront's 8 x 8 quadrant (splat_reaches_rect); the
         // ballot is the list, walked in order with scalar bit operations.  Two thirds of the (wavefront, splat)
-        // visits of the 3-sigma tile lists never reach alpha >= 1/255 on the strip and are skipped for the price
+        // visits of the 3-sigma tile lists never reach alpha >= 1/255 on the quadrant and are skipped for the price
         // of one lane-test instead of a 64-lane evaluation.
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             if (__ballot(!done) == 0ull) break;
