@@ -66,6 +66,14 @@ struct Mat3d { double m[9]; };
         if (e__ != hipSuccess) return syn3r::check_hip(e__, name);      \
     } while (0)
 
+// Workgroups are dealt to the 8 XCDs round-robin by blockIdx; this bijection hands every XCD one CONTIGUOUS
+// chunk of logical ids, so neighbouring tiles (which share operands) meet in the same 4 MB L2.
+__device__ __forceinline__ unsigned xcd_chunk_remap(unsigned bid, unsigned nblk) {
+    unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8, k = bid / 8;
+    unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}
+
 // Wave-level reductions (64 lanes).
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
