@@ -622,6 +622,63 @@ extern "C" int syn3r_gemm_set_tile(int bm) {
     return SYN3R_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Skinny contraction, M <= 16 rows (time-embedding projections [B,1280], the folded Sk = 1 cross-attention
+// context k/v [B,1024], the frame-position MLP [F,C]): ~100 launches per UNet forward whose whole cost is
+// streaming the weight matrix once.  The tile kernels would put all of it on N/160 CUs; here a wavefront owns
+// 2 output columns and splits K across its lanes (16-byte weight loads, x rows from L1/L2), so the weight
+// stream is spread over N/8 workgroups.  HBM-bound: N*K*2 bytes.
+constexpr int SKINNY_MAX_M = 16;
+template <int MR>
+__global__ void __launch_bounds__(256) k_gemm_skinny(GemmParams p) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 4 + wv) * 2;
+    if (n0 >= p.N) return;
+    const bool two = n0 + 1 < p.N;
+    const __half* w0 = p.W + (long long)n0 * p.K;
+    const __half* w1 = p.W + (long long)(two ? n0 + 1 : n0) * p.K;
+    float acc0[MR], acc1[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) { acc0[m] = 0.f; acc1[m] = 0.f; }
+    for (int k = lane * 8; k < p.K; k += 512) {
+        const half8 a = *(const half8*)(w0 + k), b = *(const half8*)(w1 + k);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m < p.M) {
+                const half8 x = *(const half8*)(p.A + (long long)m * p.lda + k);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    acc0[m] += (float)x[e] * (float)a[e];
+                    acc1[m] += (float)x[e] * (float)b[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        if (m < p.M) {
+            float s0 = wave_sum(acc0[m]), s1 = wave_sum(acc1[m]);
+            if (lane == 0) {
+                float b0 = p.bias ? __half2float(p.bias[n0]) : 0.f;
+                p.out[(long long)m * p.ldc + n0] = __float2half((s0 + b0) * p.s_acc);
+                if (two) {
+                    float b1 = p.bias ? __half2float(p.bias[n0 + 1]) : 0.f;
+                    p.out[(long long)m * p.ldc + n0 + 1] = __float2half((s1 + b1) * p.s_acc);
+                }
+            }
+        }
+    }
+}
+
+int launch_skinny(const GemmParams& p, hipStream_t stream) {
+    const int blocks = (p.N + 7) / 8;
+    if (p.M <= 2) SYN3R_LAUNCH_NAMED("k_gemm_skinny<2>", k_gemm_skinny<2>, dim3(blocks), dim3(256), 0, stream, p);
+    else if (p.M <= 8) SYN3R_LAUNCH_NAMED("k_gemm_skinny<8>", k_gemm_skinny<8>, dim3(blocks), dim3(256), 0, stream, p);
+    else SYN3R_LAUNCH_NAMED("k_gemm_skinny<16>", k_gemm_skinny<16>, dim3(blocks), dim3(256), 0, stream, p);
+    SYN3R_LAUNCH_CHECK("gemm_skinny launch");
+    return SYN3R_OK;
+}
+
 extern "C" int syn3r_gemm_f16(const void* A, long long lda, const void* W, void* out, long long ldc, const void* bias,
                               const void* rowvec, long long ldrv, int rows_per_vec, const void* residual,
                               long long ldr, const void* aux, long long ldaux, float s_acc, float s_res, float s_aux,
@@ -634,6 +691,8 @@ extern "C" int syn3r_gemm_f16(const void* A, long long lda, const void* W, void*
     int rc = check_common(p, "gemm_f16");
     if (rc) return rc;
     SYN3R_REQUIRE(lda % 8 == 0 && lda >= K, "gemm_f16: lda=%lld must be >= K and a multiple of 8", lda);
+    if (M <= SKINNY_MAX_M && !p.rowvec && !p.residual && !p.aux && g_tile_bm == 0 && g_dma_bm == 0)
+        return launch_skinny(p, (hipStream_t)stream);
     return launch<MODE_DENSE>(p, (hipStream_t)stream);
 }
 

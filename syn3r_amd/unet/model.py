@@ -268,6 +268,7 @@ class UNetSpatioTemporalConditionModel:
 
     def _pack(self):
         """Kernel-side layouts: OHWI conv weights, fused QKV, (3,1,1) convs as [Cout,3,Cin]."""
+        self._pos_cache = {}        # frame-position embeddings: functions of the weights, F and B only
         p, pk = self.p, {}
         for k, t in p.t.items():
             if k.endswith(".weight") and t.dim() == 4 and t.shape[-1] == 3:          # Conv2d 3x3
@@ -349,12 +350,15 @@ class UNetSpatioTemporalConditionModel:
         hs = ops.groupnorm(x, W(pre + ".norm.weight"), W(pre + ".norm.bias"), B * F, 1e-6, False)
         hs = ops.linear(hs, W(pre + ".proj_in.weight"), W(pre + ".proj_in.bias"))
         # frame-position embedding (transformer_temporal.py:326-337), one row per (b, f)
-        key = ("pos", ch, F)
-        if key not in st:
-            st[key] = timestep_embedding(torch.arange(F, device=x.device), ch).to(H)
-        e = ops.linear(st[key], W(pre + ".time_pos_embed.linear_1.weight"), W(pre + ".time_pos_embed.linear_1.bias"))
-        e = ops.linear(Fn.silu(e), W(pre + ".time_pos_embed.linear_2.weight"), W(pre + ".time_pos_embed.linear_2.bias"))
-        emb = e.repeat(B, 1).contiguous()                                  # [B*F, C]
+        # (its input is the frame index alone, so the MLP output is a constant of the loaded weights: kept per
+        # (block, F, B) instead of being recomputed by every forward as the reference does)
+        ck = (pre, F, B, str(x.device))
+        emb = self._pos_cache.get(ck)
+        if emb is None:
+            pos = timestep_embedding(torch.arange(F, device=x.device), ch).to(H)
+            e = ops.linear(pos, W(pre + ".time_pos_embed.linear_1.weight"), W(pre + ".time_pos_embed.linear_1.bias"))
+            e = ops.linear(Fn.silu(e), W(pre + ".time_pos_embed.linear_2.weight"), W(pre + ".time_pos_embed.linear_2.bias"))
+            emb = self._pos_cache[ck] = e.repeat(B, 1).contiguous()        # [B*F, C]
         # BasicTransformerBlock (attention.py:283-403)
         b = pre + ".transformer_blocks.0"
         n1 = ops.layernorm(hs, W(b + ".norm1.weight"), W(b + ".norm1.bias"))
