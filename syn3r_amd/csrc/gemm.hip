@@ -435,14 +435,18 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
     }
     const int cpb = (MODE == MODE_DENSE) ? 1 : p.Cin / BK;
 
-    auto issue_stage = [&](int kt, int buf) {
-        char* st = smem_raw + buf * DMA_STAGE_BYTES;
-        if constexpr (MODE == MODE_DENSE) {
+    // Source addresses advance incrementally: stages are issued in k order, a k-tile inside one filter tap is
+    // +128 bytes on every live row, and the full im2col arithmetic (64-bit multiplies, bounds tests) runs only
+    // when the tap changes (every Cin/64 k-tiles).  Padded rows point at the zero page and do not advance.
+    const __half* a_cur[4];
+    int a_inc[4];                         // halfs per k-tile: BK for live rows, 0 for zero-page rows
+    const __half* b_cur[NB_MAX];
+    int b_inc[NB_MAX];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_base[i] + kt * BK), (lds_void_t*)(st + (wv * 4 + i) * 1024), 16, 0, 0);
-        } else if constexpr (MODE == MODE_CONV2D) {
-            const int tap = kt / cpb, c0 = (kt - tap * cpb) * BK;
+    for (int j = 0; j < NB_MAX; ++j) { b_cur[j] = b_base[j] ? b_base[j] : zero; b_inc[j] = b_base[j] ? BK : 0; }
+    int tap_next = 0, c_left = 0;         // wave-uniform: next tap to set up, k-tiles left in the current tap
+    auto setup_tap = [&](int tap) {
+        if constexpr (MODE == MODE_CONV2D) {
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
             const int Hg = p.ups ? p.Hi * 2 : p.Hi, Wg = p.ups ? p.Wi * 2 : p.Wi;
 #pragma unroll
@@ -450,26 +454,42 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
                 int yy = a_y[i] * p.stride + dy, xx = a_x[i] * p.stride + dx;
                 bool ok = yy >= 0 && yy < Hg && xx >= 0 && xx < Wg;
                 if (p.ups) { yy >>= 1; xx >>= 1; }
-                long long off = (((long long)a_n[i] * p.Hi + yy) * p.Wi + xx) * p.Cin + c0;
-                const __half* src = ok ? a_base[i] + off : zero;
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wv * 4 + i) * 1024), 16, 0, 0);
+                long long off = (((long long)a_n[i] * p.Hi + yy) * p.Wi + xx) * p.Cin;
+                a_cur[i] = ok ? a_base[i] + off : zero;
+                a_inc[i] = ok ? BK : 0;
             }
-        } else {
-            const int tap = kt / cpb, c0 = (kt - tap * cpb) * BK;
+        } else if constexpr (MODE == MODE_TCONV) {
             const int df = tap - 1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int ff = a_y[i] + df;
                 bool ok = ff >= 0 && ff < p.F;
-                const __half* src = ok ? a_base[i] + (long long)df * p.HW * p.Cin + c0 : zero;
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wv * 4 + i) * 1024), 16, 0, 0);
+                a_cur[i] = ok ? a_base[i] + (long long)df * p.HW * p.Cin : zero;
+                a_inc[i] = ok ? BK : 0;
             }
+        }
+    };
+    if constexpr (MODE == MODE_DENSE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a_cur[i] = a_base[i]; a_inc[i] = BK; }
+    }
+
+    auto issue_stage = [&](int kt, int buf) {     // must be called with kt = 0, 1, 2, ... in order
+        char* st = smem_raw + buf * DMA_STAGE_BYTES;
+        if constexpr (MODE != MODE_DENSE) {
+            if (c_left == 0) { setup_tap(tap_next); ++tap_next; c_left = cpb; }
+            --c_left;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)a_cur[i], (lds_void_t*)(st + (wv * 4 + i) * 1024), 16, 0, 0);
+            a_cur[i] += a_inc[i];
         }
 #pragma unroll
         for (int j = 0; j < NB_MAX; ++j) {
             if (j < nb) {
-                const __half* src = b_base[j] ? b_base[j] + kt * BK : zero;
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + DMA_A_BYTES + (b_first + j) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)b_cur[j], (lds_void_t*)(st + DMA_A_BYTES + (b_first + j) * 1024), 16, 0, 0);
+                b_cur[j] += b_inc[j];
             }
         }
     };
