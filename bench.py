@@ -119,13 +119,13 @@ def raster_algorithmic_bytes(N, P, H, W):
 
 def cpu_baseline_raster(args):
     """Oracle (CPU restatement, kind='port') on a bounded sample: same 200k-Gaussian scene rendered
-    fwd+bwd at 1/4 resolution per axis; pixel work is scaled by 16 to the full frame."""
+    fwd+bwd at 1/2 resolution per axis (about 15 s of CPU work); pixel work is scaled by 4 to the full frame."""
     from oracle import raster_oracle as RO
     # the GPU box exposes many host cores but grants ~16 to a 1-GPU job: oversubscribing them stalls for minutes
     ncores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(ncores)
     N = args.gaussians
-    H, W = args.height // 4, args.width // 4
+    H, W = args.height // 2, args.width // 2
     m, s, q, o, sh = RO.synthetic_gaussians(N, seed=args.seed)
     # keep the footprint in pixels comparable: scales shrink with the image
     view, proj, campos, tfx, tfy = RO.look_at_camera(H, W)
@@ -135,10 +135,10 @@ def cpu_baseline_raster(args):
                                                    H, W, torch.zeros(3), 3)
     color.abs().mean().backward()
     dt = time.time() - t0
-    full = dt * 16.0
+    full = dt * 4.0
     return dict(value=1.0 / full, unit="iters/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle/raster_oracle.py fwd+bwd, {N} Gaussians at {W}x{H} (1/16 of the pixels) took "
-                       f"{dt:.1f} s; scaled x16 to 1920x1080; raster iterations only (no CPU UNet: see DESIGN.md)")
+                sample=f"oracle/raster_oracle.py fwd+bwd, {N} Gaussians at {W}x{H} (1/4 of the pixels) took "
+                       f"{dt:.1f} s; scaled x4 to {args.width}x{args.height}; raster iterations only (no CPU UNet: see DESIGN.md)")
 
 
 def main():

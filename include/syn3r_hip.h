@@ -276,15 +276,17 @@ int syn3r_gemm_geglu_f16(const void* A, long long lda, const void* Wpacked, cons
                          long long ldc, int M, int D, int K, void* stream);
 
 /*
- * 3x3 Conv2d, padding 1, on NHWC fp16 (resnet.py:274,290; downsampling.py:116-148 with stride 2;
+ * 3x3 Conv2d on NHWC fp16 (resnet.py:274,290; downsampling.py:116-148 with stride 2;
  * upsampling.py:172-183 with upsample != 0: nearest-2x of the input fused into the gather).
+ * pad_lo = 1: padding 1 on every side.  pad_lo = 0: the VAE encoder's Downsample2D(padding=0), which pads
+ * (0,1,0,1) — nothing before the first row/column, one zero row/column after the last (downsampling.py:140-143).
  * X [NB,Hi,Wi,Cin], W [Cout, 3, 3, Cin] (= the Conv2d weight permuted to OHWI), Cin % 64 == 0.
- * out [NB*Ho*Wo, Cout] with the gemm epilogue (aux excluded).
+ * out [NB*Ho*Wo, Cout] with the gemm epilogue (aux excluded); Ho = (Hg + pad_lo - 2) / stride + 1.
  */
 int syn3r_conv2d3x3_f16(const void* X, const void* W, void* out, long long ldc, const void* bias,
                         const void* rowvec, long long ldrv, int rows_per_vec, const void* residual, long long ldr,
                         float s_acc, float s_res, int NB, int Hi, int Wi, int Cin, int Cout, int stride, int upsample,
-                        void* stream);
+                        int pad_lo, void* stream);
 
 /*
  * (3,1,1) Conv3d over frames, padding (1,0,0) (resnet.py:571-597) on [B,F,HW,Cin] fp16.
@@ -329,6 +331,17 @@ int syn3r_layernorm_f16(const void* x, void* y, void* xsum, const void* addvec, 
 
 /* GEGLU gate (activations.py GEGLU.forward): y[M,D] = x[:, :D] * gelu_erf(x[:, D:]) for x [M, 2D]. */
 int syn3r_geglu_f16(const void* x, void* y, long long M, int D, void* stream);
+
+/* Row softmax of an fp16 matrix in fp32 arithmetic: y[m,:] = softmax(scale * x[m,:]); x may equal y.
+ * The single-head, 512-wide attention of the VAE mid blocks (attention_processor.py:1222-1299 through
+ * vae.py:119-129 and unet_3d_blocks.py:1794-1805) is two syn3r_gemm_f16 calls around this kernel. */
+int syn3r_softmax_rows_f16(const void* x, void* y, long long M, int N, long long ld, float scale, void* stream);
+
+/* TemporalDecoder.time_conv_out (autoencoder_kl_temporal_decoder.py:78-84,156-160): Conv3d(3,3,(3,1,1)) over
+ * frames.  x [B*F*HW, ldx] fp16 channels-last (first 3 columns used), w [3,3,3] = weight[co][ci][dt] and bias [3]: fp32 HOST
+ * pointers (30 floats, passed as kernel arguments) -> out [B*F, 3, HW] fp32 (the NCHW frames the decoder returns). */
+int syn3r_time_conv_out(const void* x, long long ldx, const float* w, const float* bias, float* out, int B, int F,
+                        long long HW, void* stream);
 
 /* ------------------------------------------------------------------------
  * Trainer-loop pieces adjacent to the rasteriser.  The reference runs them inside FSGS'

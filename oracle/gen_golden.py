@@ -149,6 +149,28 @@ def gen_unet():
     np.savez_compressed(GOLD / "unet_small.npz", **out)
 
 
+def gen_vae():
+    """Reference AutoencoderKLTemporalDecoder (reduced config, CPU fp32): encode moments and decoded frames."""
+    from diffusers.models import AutoencoderKLTemporalDecoder
+    from oracle import unet_weights as UW
+    from oracle import vae_weights as VW
+    torch.manual_seed(0)
+    model = AutoencoderKLTemporalDecoder(**VW.SMALL_VAE_CONFIG)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(UW.make_state_dict(shapes, seed=7))
+    model.eval()
+    out = {"names": np.array(sorted(shapes)), "shapes": np.array([str(shapes[k]) for k in sorted(shapes)])}
+    with torch.no_grad():
+        x = VW.make_images()
+        out["moments"] = model.encode(x).latent_dist.parameters.numpy()
+        z = VW.make_latents()
+        out["decoded_f3"] = model.decode(z, num_frames=3).sample.numpy()
+        out["decoded_f1"] = model.decode(z[:2], num_frames=1).sample.numpy()
+    for k in ("moments", "decoded_f3", "decoded_f1"):
+        print("vae", k, out[k].shape, float(np.abs(out[k]).mean()), float(out[k].std()))
+    np.savez_compressed(GOLD / "vae_small.npz", **out)
+
+
 def gen_pipeline():
     """Run the REFERENCE pipeline classes' own __call__ (both variants) on the CPU with mock CLIP / VAE /
     UNet (oracle/pipeline_mocks.py), 3 denoise steps, output_type='latent'."""
@@ -237,13 +259,15 @@ def gen_orchestrator():
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     Sch, consistency, forward_warp, inverse_warp = _import_reference()
-    which = sys.argv[1:] or ["warp", "sched", "unet", "pipeline", "orch"]
+    which = sys.argv[1:] or ["warp", "sched", "unet", "vae", "pipeline", "orch"]
     if "pipeline" in which:
         gen_pipeline()
     if "orch" in which:
         gen_orchestrator()
     if "unet" in which:
         gen_unet()
+    if "vae" in which:
+        gen_vae()
     if "warp" in which:
         gen_warp(consistency, forward_warp, inverse_warp)
     if "sched" in which:

@@ -1,0 +1,19 @@
+"""Reduced temporal-decoder VAE configuration and seeded inputs shared by oracle/gen_golden.py (which runs the
+REFERENCE AutoencoderKLTemporalDecoder on the CPU in fp32) and tests/ (which run the HIP mirror).  Test
+infrastructure: weights come from oracle.unet_weights.make_state_dict on the same name->shape table."""
+from __future__ import annotations
+
+import torch
+
+SMALL_VAE_CONFIG = dict(in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D", "DownEncoderBlock2D"),
+                        block_out_channels=(64, 128), layers_per_block=2, latent_channels=4, sample_size=32)
+
+
+def make_images(n=2, h=32, w=48, seed=0):
+    g = torch.Generator().manual_seed(4000 + seed)
+    return (torch.rand(n, 3, h, w, generator=g) * 2.0 - 1.0).to(torch.float16).float()
+
+
+def make_latents(b=2, f=3, h=16, w=24, seed=0):
+    g = torch.Generator().manual_seed(5000 + seed)
+    return torch.randn(b * f, 4, h, w, generator=g).to(torch.float16).float()

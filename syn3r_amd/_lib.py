@@ -58,7 +58,7 @@ SIGNATURES = {
     "syn3r_gemm_set_tile": (c_i, [c_i]),
     "syn3r_gemm_geglu_f16": (c_i, [c_p, c_ll, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
     "syn3r_conv2d3x3_f16": (c_i, [c_p, c_p, c_p, c_ll, c_p, c_p, c_ll, c_i, c_p, c_ll, c_f, c_f,
-                                  c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+                                  c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "syn3r_tconv3_f16": (c_i, [c_p, c_p, c_p, c_ll, c_p, c_p, c_ll, c_i, c_p, c_ll, c_f, c_f,
                                c_i, c_i, c_i, c_i, c_i, c_p]),
     "syn3r_attention_f16": (c_i, [c_p, c_p, c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, c_p]),
@@ -67,6 +67,8 @@ SIGNATURES = {
     "syn3r_groupnorm_f16": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_p, c_sz, c_p]),
     "syn3r_layernorm_f16": (c_i, [c_p, c_p, c_p, c_p, c_i, c_ll, c_i, c_p, c_p, c_f, c_p]),
     "syn3r_geglu_f16": (c_i, [c_p, c_p, c_ll, c_i, c_p]),
+    "syn3r_softmax_rows_f16": (c_i, [c_p, c_p, c_ll, c_i, c_ll, c_f, c_p]),
+    "syn3r_time_conv_out": (c_i, [c_p, c_ll, c_p, c_p, c_p, c_i, c_i, c_ll, c_p]),
     "syn3r_l1_loss_workspace_bytes": (c_sz, [c_ll]),
     "syn3r_l1_loss": (c_i, [c_p, c_p, c_ll, c_f, c_p, c_p, c_sz, c_p]),
     "syn3r_l1_loss_backward": (c_i, [c_p, c_p, c_ll, c_f, c_p, c_p, c_p]),

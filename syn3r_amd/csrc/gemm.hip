@@ -50,7 +50,7 @@ struct GemmParams {
     float s_acc, s_res, s_aux;
     int M, N, K;
     // conv geometry (NHWC): output Ho x Wo, input Hi x Wi, Cin channels (K = taps * Cin)
-    int Ho, Wo, Hi, Wi, Cin, stride, ups;
+    int Ho, Wo, Hi, Wi, Cin, stride, ups, pad;   // pad: zero rows/cols before the first pixel (1, or 0 for the (0,1,0,1) pad)
     // temporal conv: F frames of HW rows each (row = (b*F + f)*HW + p)
     int F, HW;
     // GEGLU epilogue: W rows are packed per 160-row tile as [80 hidden | 80 gate]; out has geglu_D columns
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm(GemmParams p) {
             for (int i = 0; i < 4; ++i) ra[i] = *(const u32x4*)(p.A + a_off[i] + k0);
         } else if constexpr (MODE == MODE_CONV2D) {
             const int tap = kt / cpb, c0 = (kt - tap * cpb) * BK + a_chunk * 8;
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const int dy = tap / 3 - p.pad, dx = tap % 3 - p.pad;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int yy = a_y[i] * p.stride + dy, xx = a_x[i] * p.stride + dx;
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
     int tap_next = 0, c_left = 0;         // wave-uniform: next tap to set up, k-tiles left in the current tap
     auto setup_tap = [&](int tap) {
         if constexpr (MODE == MODE_CONV2D) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const int dy = tap / 3 - p.pad, dx = tap % 3 - p.pad;
             const int Hg = p.ups ? p.Hi * 2 : p.Hi, Wg = p.ups ? p.Wi * 2 : p.Wi;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -736,8 +736,9 @@ extern "C" int syn3r_gemm_geglu_f16(const void* A, long long lda, const void* Wp
 extern "C" int syn3r_conv2d3x3_f16(const void* X, const void* W, void* out, long long ldc, const void* bias,
                                    const void* rowvec, long long ldrv, int rows_per_vec, const void* residual,
                                    long long ldr, float s_acc, float s_res, int NB, int Hi, int Wi, int Cin, int Cout,
-                                   int stride, int upsample, void* stream) {
+                                   int stride, int upsample, int pad_lo, void* stream) {
     SYN3R_REQUIRE(NB > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv2d3x3: bad sizes");
+    SYN3R_REQUIRE(pad_lo == 0 || pad_lo == 1, "conv2d3x3: pad_lo must be 0 or 1");
     SYN3R_REQUIRE(stride == 1 || stride == 2, "conv2d3x3: stride must be 1 or 2");
     SYN3R_REQUIRE(!(upsample && stride != 1), "conv2d3x3: upsample requires stride 1");
     SYN3R_REQUIRE(Cin % BK == 0, "conv2d3x3: Cin=%d must be a multiple of %d (pad the input channels)", Cin, BK);
@@ -745,10 +746,11 @@ extern "C" int syn3r_conv2d3x3_f16(const void* X, const void* W, void* out, long
     p.A = (const __half*)X; p.W = (const __half*)W; p.out = (__half*)out; p.ldc = ldc; p.bias = (const __half*)bias;
     p.rowvec = (const __half*)rowvec; p.ldrv = ldrv; p.rows_per_vec = rows_per_vec;
     p.residual = (const __half*)residual; p.ldr = ldr; p.s_acc = s_acc; p.s_res = s_res; p.s_aux = 0.f;
-    p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.stride = stride; p.ups = upsample ? 1 : 0;
+    p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.stride = stride; p.ups = upsample ? 1 : 0; p.pad = pad_lo;
     int Hg = upsample ? 2 * Hi : Hi, Wg = upsample ? 2 * Wi : Wi;
-    p.Ho = (Hg + 2 - 3) / stride + 1;
-    p.Wo = (Wg + 2 - 3) / stride + 1;
+    p.Ho = (Hg + pad_lo + 1 - 3) / stride + 1;      // one zero row/col always follows the last pixel
+    p.Wo = (Wg + pad_lo + 1 - 3) / stride + 1;
+    SYN3R_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d3x3: input too small");
     long long M = (long long)NB * p.Ho * p.Wo;
     SYN3R_REQUIRE(M < (1ll << 31), "conv2d3x3: too many output pixels");
     p.M = (int)M; p.N = Cout; p.K = 9 * Cin;

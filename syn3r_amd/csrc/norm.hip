@@ -301,3 +301,104 @@ extern "C" int syn3r_geglu_f16(const void* x, void* y, long long M, int D, void*
     SYN3R_LAUNCH_CHECK("geglu launch");
     return SYN3R_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax (fp16 storage, fp32 arithmetic) and the temporal decoder's 3-channel output convolution:
+// the two element-wise pieces of the temporal-decoder VAE that the UNet kernels lack.
+namespace {
+
+__global__ void __launch_bounds__(256) k_softmax_rows(const __half* __restrict__ x, __half* __restrict__ y, int N,
+                                                      long long ld, float scale) {
+    const long long row = blockIdx.x;
+    const __half* src = x + row * ld;
+    __half* dst = y + row * ld;
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float mx = -3.0e38f;
+    for (int i = threadIdx.x * 8; i < N; i += 256 * 8) {
+        if (i + 8 <= N) {
+            half8 v = *(const half8*)(src + i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[e]);
+        } else {
+            for (int e = 0; i + e < N; ++e) mx = fmaxf(mx, __half2float(src[i + e]));
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale;   // scale > 0
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = threadIdx.x * 8; i < N; i += 256 * 8) {
+        const int n = min(8, N - i);
+        for (int e = 0; e < n; ++e) sum += __expf(__half2float(src[i + e]) * scale - mx);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int i = threadIdx.x * 8; i < N; i += 256 * 8) {
+        if (i + 8 <= N) {
+            half8 v = *(const half8*)(src + i), o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)(__expf((float)v[e] * scale - mx) * inv);
+            *(half8*)(dst + i) = o;
+        } else {
+            for (int e = 0; i + e < N; ++e) dst[i + e] = __float2half(__expf(__half2float(src[i + e]) * scale - mx) * inv);
+        }
+    }
+}
+
+struct TimeConvW { float w[27]; float b[3]; };
+
+__global__ void __launch_bounds__(256) k_time_conv_out(const __half* __restrict__ x, long long ldx, TimeConvW tw,
+                                                       float* __restrict__ out, int F, long long HW, long long total) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // (b*F + f)*HW + p
+    if (i >= total) return;
+    const long long bf = i / HW, pix = i - bf * HW;
+    const int f = (int)(bf % F);
+    float acc[3] = {tw.b[0], tw.b[1], tw.b[2]};
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+        const int ff = f + dt - 1;
+        if (ff < 0 || ff >= F) continue;
+        const __half* src = x + (i + (long long)(dt - 1) * HW) * ldx;
+        const float c0 = __half2float(src[0]), c1 = __half2float(src[1]), c2 = __half2float(src[2]);
+#pragma unroll
+        for (int co = 0; co < 3; ++co)
+            acc[co] += tw.w[(co * 3 + 0) * 3 + dt] * c0 + tw.w[(co * 3 + 1) * 3 + dt] * c1 + tw.w[(co * 3 + 2) * 3 + dt] * c2;
+    }
+#pragma unroll
+    for (int co = 0; co < 3; ++co) out[(bf * 3 + co) * HW + pix] = acc[co];
+}
+
+}  // namespace
+
+extern "C" int syn3r_softmax_rows_f16(const void* x, void* y, long long M, int N, long long ld, float scale, void* stream) {
+    SYN3R_REQUIRE(M > 0 && N > 0 && ld >= N, "softmax_rows: bad sizes M=%lld N=%d ld=%lld", M, N, ld);
+    SYN3R_REQUIRE(x && y, "softmax_rows: null pointer");
+    SYN3R_REQUIRE(scale > 0.0f, "softmax_rows: scale must be positive");
+    SYN3R_REQUIRE(ld % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "softmax_rows: rows must be 16-byte aligned");
+    SYN3R_REQUIRE(M < (1ll << 31), "softmax_rows: too many rows");
+    SYN3R_LAUNCH(k_softmax_rows, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, (const __half*)x, (__half*)y, N, ld,
+                 scale);
+    SYN3R_LAUNCH_CHECK("softmax_rows launch");
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_time_conv_out(const void* x, long long ldx, const float* w, const float* bias, float* out, int B,
+                                   int F, long long HW, void* stream) {
+    SYN3R_REQUIRE(B > 0 && F > 0 && HW > 0 && ldx >= 3, "time_conv_out: bad sizes");
+    SYN3R_REQUIRE(x && w && bias && out, "time_conv_out: null pointer");
+    TimeConvW tw;
+    for (int i = 0; i < 27; ++i) tw.w[i] = w[i];     // host pointers: 30 floats travel as kernel arguments
+    for (int i = 0; i < 3; ++i) tw.b[i] = bias[i];
+    const long long total = (long long)B * F * HW;
+    SYN3R_REQUIRE((total + 255) / 256 < (1ll << 31), "time_conv_out: too many pixels");
+    SYN3R_LAUNCH(k_time_conv_out, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                 (const __half*)x, ldx, tw, out, F, HW, total);
+    SYN3R_LAUNCH_CHECK("time_conv_out launch");
+    return SYN3R_OK;
+}

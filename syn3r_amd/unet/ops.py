@@ -89,21 +89,24 @@ def linear_geglu(x: torch.Tensor, wpacked: torch.Tensor, bpacked: torch.Tensor, 
 
 def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride: int = 1,
             upsample: bool = False, rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0,
-            residual: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0) -> torch.Tensor:
-    """x [NB,Hi,Wi,Cin] NHWC, weight [Cout,3,3,Cin] -> [NB,Ho,Wo,Cout]."""
+            residual: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0,
+            pad_lo: int = 1) -> torch.Tensor:
+    """x [NB,Hi,Wi,Cin] NHWC, weight [Cout,3,3,Cin] -> [NB,Ho,Wo,Cout].  pad_lo = 0: the (0,1,0,1) padding of the
+    VAE encoder's stride-2 Downsample2D(padding=0)."""
     dev = _chk(x, weight, bias, rowvec, residual)
     NB, Hi, Wi, Cin = x.shape
     Cout = weight.shape[0]
     if tuple(weight.shape[1:]) != (3, 3, Cin):
         raise ValueError(f"conv3x3: weight {tuple(weight.shape)} does not match Cin={Cin}")
     Hg, Wg = (2 * Hi, 2 * Wi) if upsample else (Hi, Wi)
-    Ho, Wo = (Hg - 1) // stride + 1, (Wg - 1) // stride + 1
+    Ho, Wo = (Hg + pad_lo - 2) // stride + 1, (Wg + pad_lo - 2) // stride + 1
     out = torch.empty((NB, Ho, Wo, Cout), dtype=H, device=dev)
     lib = L.load()
     rc = lib.syn3r_conv2d3x3_f16(L.ptr(x), L.ptr(weight), L.ptr(out), Cout, L.ptr(bias), L.ptr(rowvec),
                                  rowvec.stride(0) if rowvec is not None else 0, int(rows_per_vec),
                                  L.ptr(residual), Cout if residual is not None else 0, float(s_acc), float(s_res),
-                                 NB, Hi, Wi, Cin, Cout, int(stride), 1 if upsample else 0, L.stream_ptr(dev))
+                                 NB, Hi, Wi, Cin, Cout, int(stride), 1 if upsample else 0, int(pad_lo),
+                                 L.stream_ptr(dev))
     L.check(rc, "syn3r_conv2d3x3_f16")
     _count("gemm", 2.0 * NB * Ho * Wo * Cout * 9 * Cin)
     return out
@@ -195,3 +198,38 @@ def geglu(x: torch.Tensor) -> torch.Tensor:
     rc = L.load().syn3r_geglu_f16(L.ptr(x), L.ptr(y), M, D2 // 2, L.stream_ptr(dev))
     L.check(rc, "syn3r_geglu_f16")
     return y
+
+
+def softmax_rows(x: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(scale * x, dim=1) of an fp16 [M,N] matrix in fp32 arithmetic (in place when out is x)."""
+    dev = _chk(x)
+    M, N = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    rc = L.load().syn3r_softmax_rows_f16(L.ptr(x), L.ptr(out), M, N, x.stride(0), float(scale), L.stream_ptr(dev))
+    L.check(rc, "syn3r_softmax_rows_f16")
+    return out
+
+
+def attention_wide(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """Single-head attention of ONE sequence with an arbitrary head width D (the VAE mid blocks: D = 512):
+    q, k, v [S,D] -> [S,D] as two contractions around a row softmax (the S x S score matrix is materialised
+    in fp16: 170 MB at S = 9216)."""
+    S, D = q.shape
+    scores = linear(q, k, s_acc=1.0 / (D ** 0.5))                 # [S,S] = q . k^T / sqrt(D)
+    softmax_rows(scores, 1.0, out=scores)
+    return linear(scores, v.t().contiguous())                     # [S,D] = P . v
+
+
+def time_conv_out(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, B: int, F: int, HW: int) -> torch.Tensor:
+    """TemporalDecoder.time_conv_out: x [B*F*HW, >=3] fp16 channels-last, weight [3,3,3,1,1], bias [3]
+    -> [B*F, 3, HW] fp32."""
+    dev = _chk(x)
+    if x.shape[0] != B * F * HW or x.shape[1] < 3 or weight.numel() != 27 or bias.numel() != 3:
+        raise ValueError("time_conv_out: shape mismatch")
+    out = torch.empty((B * F, 3, HW), dtype=torch.float32, device=dev)
+    w = L.host_f32(weight.detach().float().cpu().reshape(-1).tolist())
+    b = L.host_f32(bias.detach().float().cpu().reshape(-1).tolist())
+    rc = L.load().syn3r_time_conv_out(L.ptr(x), x.stride(0), w, b, L.ptr(out), B, F, HW, L.stream_ptr(dev))
+    L.check(rc, "syn3r_time_conv_out")
+    return out
