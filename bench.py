@@ -141,6 +141,56 @@ def cpu_baseline_raster(args):
                        f"{dt:.1f} s; scaled x4 to {args.width}x{args.height}; raster iterations only (no CPU UNet: see DESIGN.md)")
 
 
+def cpu_baseline_unet(args):
+    """Oracle (oracle/unet_oracle.py, torch fp32 on the host cores, kind='port') on a bounded sample of HOT LOOP B:
+    the FULL SVD-XT UNet configuration (1.52 B seeded weights) on a CFG batch of 2 frames at 24x32 latents; the
+    time is scaled to the benchmark unit by the token ratio (every contraction is linear in B*F*h*w; the
+    attention's quadratic term is under-counted at the small size, so this over-states the CPU's throughput)."""
+    from oracle.unet_oracle import UNetOracle
+    from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel      # parameter table only
+    shapes = UNetSpatioTemporalConditionModel().parameter_shapes()
+    g = torch.Generator().manual_seed(args.seed)
+    pool = torch.randn(1 << 22, generator=g)      # timing only: the 1.5 B weights are tiled from 4 M normals
+    sd = {}
+    for k, shape in shapes.items():
+        if k.endswith("mix_factor"):
+            sd[k] = torch.full(shape, 0.5)
+        elif (".norm" in k and k.endswith(".weight")) or k == "conv_norm_out.weight":
+            sd[k] = torch.ones(shape)
+        elif k.endswith(".bias"):
+            sd[k] = torch.zeros(shape)
+        else:
+            n = math.prod(shape)
+            sd[k] = (pool.repeat((n + pool.numel() - 1) // pool.numel())[:n].view(shape)
+                     * min(0.02, math.prod(shape[1:]) ** -0.5))
+    orc = UNetOracle(sd, {})
+    B, F, h, w = 2, 2, 24, 32
+    x = torch.randn(B, F, 8, h, w, generator=g)
+    ehs = torch.randn(B, 1, 1024, generator=g)
+    added = torch.tensor([[6.0, 127.0, 0.02]] * B)
+    t0 = time.time()
+    y = orc.forward(x, 1.6378, ehs, added)
+    dt = time.time() - t0
+    assert bool(torch.isfinite(y).all())
+    scale = (2 * args.frames * 72 * 128) / float(B * F * h * w)
+    return dt * scale, f"oracle/unet_oracle.py CFG forward [2,{F},8,{h},{w}] (full 1.52 B-parameter configuration) took {dt:.1f} s; x{scale:.0f} by tokens to [2,{args.frames},8,72,128]"
+
+
+def cpu_baseline(args, with_unet: bool):
+    """Composite CPU figure in the headline's unit: raster iterations per second of the same block
+    (raster_iters raster iterations + one SVD unit), from the two bounded oracle samples."""
+    ras = cpu_baseline_raster(args)
+    t_iter = 1.0 / ras["value"]
+    if not with_unet:
+        return ras
+    t_unit, note = cpu_baseline_unet(args)
+    value = args.raster_iters / (args.raster_iters * t_iter + t_unit)
+    return dict(value=value, unit="iters/s", cores=ras["cores"], kind="port",
+                sample=ras["sample"].replace("; raster iterations only (no CPU UNet: see DESIGN.md)", "")
+                       + f" -> {t_iter:.1f} s per raster iteration; {note} -> {t_unit:.0f} s per SVD unit; "
+                         f"value = {args.raster_iters} / ({args.raster_iters} x raster + unit)")
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -271,7 +321,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             log("cpu baseline (oracle on the host cores, bounded sample) ...")
-            out["cpu_baseline"] = cpu_baseline_raster(args)
+            out["cpu_baseline"] = cpu_baseline(args, loop_b is not None)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

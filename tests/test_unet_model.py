@@ -49,6 +49,35 @@ def test_forward_matches_reference_golden(tag, B, F, h, w, gpu, golden_dir):
     assert err.mean().item() < 3e-3 * scale, (err.mean().item(), scale)
 
 
+def test_unet_oracle_matches_reference_golden(golden_dir):
+    """oracle/unet_oracle.py (torch fp32 CPU restatement) is pinned by the reference module's own outputs."""
+    from oracle.unet_oracle import UNetOracle
+    g = np.load(golden_dir / "unet_small.npz")
+    shapes = {str(n): ast.literal_eval(str(s)) for n, s in zip(g["names"], g["shapes"])}
+    orc = UNetOracle(UW.make_state_dict(shapes), UW.SMALL_CONFIG)
+    for tag, (B, F, h, w) in {"b2f5": (2, 5, 16, 24), "b1f14": (1, 14, 8, 16)}.items():
+        y = orc.forward(*UW.make_inputs(B, F, h, w, seed=F))
+        torch.testing.assert_close(y, torch.from_numpy(g[f"{tag}_out"]), atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,F,h,w", [(2, 7, 16, 40), (1, 25, 8, 8), (2, 3, 48, 16)])
+def test_forward_matches_oracle_on_other_shapes(B, F, h, w, gpu):
+    """Shapes the golden file does not hold (the reference's 25 frames, non-square and odd frame counts), against
+    the pinned CPU oracle; same tolerance as the golden comparison."""
+    from oracle.unet_oracle import UNetOracle
+    from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel
+    model = UNetSpatioTemporalConditionModel(**UW.SMALL_CONFIG)
+    sd = UW.make_state_dict(model.parameter_shapes())
+    model.load_state_dict(sd, gpu)
+    sample, t, ehs, added = UW.make_inputs(B, F, h, w, seed=100 + F)
+    ref = UNetOracle(sd, UW.SMALL_CONFIG).forward(sample, t, ehs, added)
+    y = model.forward(sample.to(gpu).half(), t, ehs.to(gpu).half(), added.to(gpu))[0].float().cpu()
+    scale = float(ref.abs().max())
+    err = (y - ref).abs()
+    assert float(err.max()) < 3e-2 * scale and float(err.mean()) < 3e-3 * scale, (float(err.max()), float(err.mean()), scale)
+
+
 @pytest.mark.gpu
 def test_forward_is_deterministic_and_context_interleave(gpu):
     """Same input -> bit-identical output.  Batch items only interact through the reference's
