@@ -157,6 +157,22 @@ class AutoencoderKLTemporalDecoder:
         self._pack()
         return self
 
+    def init_random(self, device, seed: int = 0) -> "AutoencoderKLTemporalDecoder":
+        """Seeded fan-in-scaled weights (benchmarks / smoke: no checkpoint is reachable offline)."""
+        dev = torch.device(device)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        sd = {}
+        for k, shape in self.p.shapes.items():
+            if k.endswith("mix_factor"):
+                sd[k] = torch.zeros(shape, device=dev)
+            elif "norm" in k.split(".")[-2] and k.endswith(".weight"):
+                sd[k] = torch.ones(shape, device=dev)
+            elif k.endswith(".bias"):
+                sd[k] = torch.zeros(shape, device=dev)
+            else:
+                sd[k] = torch.randn(shape, generator=g, device=dev) * math.prod(shape[1:]) ** -0.5
+        return self.load_state_dict(sd, dev)
+
     @classmethod
     def from_pretrained(cls, path: str, device) -> "AutoencoderKLTemporalDecoder":
         """`path`: a local diffusers `vae/` directory (config.json + *.safetensors)."""

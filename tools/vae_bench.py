@@ -7,12 +7,11 @@ import torch
 from syn3r_amd import _lib as L
 from syn3r_amd.unet import ops
 from syn3r_amd.vae import AutoencoderKLTemporalDecoder
-from oracle import unet_weights as UW      # developer tool: seeded weights only
 
 dev = torch.device("cuda", 0)
 m = AutoencoderKLTemporalDecoder(block_out_channels=(128, 256, 512, 512), down_block_types=("DownEncoderBlock2D",) * 4,
                                  layers_per_block=2, sample_size=768)
-m.load_state_dict(UW.make_state_dict(m.parameter_shapes(), seed=7), dev)
+m.init_random(dev, seed=7)
 Hh, Ww = 576, 1024
 g = torch.Generator().manual_seed(0)
 img = (torch.rand(1, 3, Hh, Ww, generator=g) * 2 - 1).to(dev)
