@@ -319,7 +319,7 @@ def main():
             "kernels_ms": {k: [v[0], round(v[1], 3)] for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])[:12]},
             "per_rank": [[round(float(x), 3) for x in r.tolist()] for r in allrec],
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported on rank 0 of the single-GPU run only
             log("cpu baseline (oracle on the host cores, bounded sample) ...")
             out["cpu_baseline"] = cpu_baseline(args, loop_b is not None)
         print(json.dumps(out))
