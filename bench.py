@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--raster-iters", type=int, default=50, help="raster fwd+bwd iterations per step")
     ap.add_argument("--frames", type=int, default=14, help="SVD frames (14 = BASELINE configs[1], 25 = reference)")
     ap.add_argument("--svd", choices=["on", "off"], default="on")
+    ap.add_argument("--loss", choices=["l1", "l1+ssim"], default="l1",
+                    help="photometric loss of the raster iteration (SURVEY 8d defines the composite with L1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
@@ -70,13 +72,14 @@ class RasterLoop:
         g = torch.Generator().manual_seed(args.seed)
         self.target = torch.rand(3, args.height, args.width, generator=g).to(dev)
         self.N, self.H, self.W = args.gaussians, args.height, args.width
+        self.loss_kind = args.loss
         self.P = 0
 
     def iteration(self):
-        from syn3r_amd.gs.train_ops import l1_loss
+        from syn3r_amd.gs.train_ops import l1_loss, photometric_loss
         p = self.p
         color, radii, depth, alpha = self.rast(p["m"], self.m2, p["o"], shs=p["sh"], scales=p["s"], rotations=p["q"])
-        loss = l1_loss(color, self.target)
+        loss = l1_loss(color, self.target) if self.loss_kind == "l1" else photometric_loss(color, self.target, 0.2)
         loss.backward()
         for t in list(p.values()) + [self.m2]:
             t.grad = None
@@ -306,7 +309,7 @@ def main():
             "dtype": "f32 raster / f16 UNet (f32 accumulate)",
             "data": "synthetic",
             "config": {
-                "workload": f"LLFF fern-like 3-view block: {args.raster_iters} raster fwd+bwd iters "
+                "workload": f"LLFF fern-like 3-view block: {args.raster_iters} raster fwd+bwd iters ({args.loss} loss) "
                             f"({args.gaussians} Gaussians, {args.width}x{args.height}, SH3, P={P} pairs) + "
                             + (f"1 SVD (step,pass): CFG UNet fwd [2,{args.frames},8,72,128] f16 + fused Euler step"
                                if loop_b is not None else "SVD pass NOT included (UNet not built yet)"),

@@ -360,6 +360,18 @@ int syn3r_l1_loss(const float* image, const float* target, long long n, float we
 int syn3r_l1_loss_backward(const float* image, const float* target, long long n, float weight,
                            const float* grad_loss, float* grad_image, void* stream);
 
+/* The published 3DGS photometric loss in one pass:
+ *   loss3[0] = weight * ((1 - lambda_dssim) * mean|I - G| + lambda_dssim * (1 - SSIM(I, G))), loss3[1] = L1, loss3[2] = SSIM
+ * I, G [C,H,W] fp32; SSIM with the 11x11 Gaussian window (sigma 1.5), zero padding 5, C1 = 0.01^2, C2 = 0.03^2, mean
+ * over all C*H*W.  ws (syn3r_photo_loss_workspace_bytes) also receives the three derivative maps the backward
+ * reads, so the SAME workspace must be passed to syn3r_photo_loss_backward, which writes
+ * grad_image = grad_loss[0] * d loss3[0] / d I  (grad_loss: device scalar, NULL = 1). */
+size_t syn3r_photo_loss_workspace_bytes(int C, int H, int W);
+int syn3r_photo_loss(const float* image, const float* target, int C, int H, int W, float lambda_dssim, float weight,
+                     float* loss3, void* ws, size_t ws_bytes, void* stream);
+int syn3r_photo_loss_backward(const float* image, const float* target, int C, int H, int W, float lambda_dssim,
+                              float weight, const float* grad_loss, const void* ws, float* grad_image, void* stream);
+
 /* One torch.optim.Adam update (no weight decay, no amsgrad) of n fp32 parameters in place, in torch's
  * operation order: exp_avg.lerp_(g, 1-beta1); exp_avg_sq = beta2*exp_avg_sq + (1-beta2)*g*g;
  * param -= lr/(1-beta1^step) * exp_avg / (sqrt(exp_avg_sq)/sqrt(1-beta2^step) + eps).  step is 1-based. */

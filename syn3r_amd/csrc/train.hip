@@ -89,6 +89,153 @@ __global__ void __launch_bounds__(kThreads) k_adam(float* __restrict__ p, const 
     v[i] = vi;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Photometric loss of the published 3DGS trainer, fused:  L = w * [(1 - lambda) * mean|I - G| + lambda * (1 - SSIM(I, G))]
+// with SSIM as published (11x11 Gaussian window, sigma 1.5, zero padding 5, C1 = 0.01^2, C2 = 0.03^2, mean over
+// all channels and pixels).  Forward: one pass over 16x16 tiles with a 5-pixel halo staged in LDS, separable
+// window (horizontal then vertical) on the five moments; it also stores the three per-pixel derivative maps
+// (d ssim / d mu1 [total], / d sigma1^2, / d sigma12) the backward needs.  Backward: the same separable window
+// on those three maps, combined with the L1 sign term, one write of the image gradient.
+constexpr int kWin = 11, kHalo = 5, kTile = 16, kReg = kTile + 2 * kHalo;   // 26
+struct SsimWindow { float g[kWin]; };
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return t;
+}
+
+__global__ void __launch_bounds__(256) k_photo_fwd(const float* __restrict__ img, const float* __restrict__ gt, int H,
+                                                   int W, SsimWindow win, float* __restrict__ maps,
+                                                   float* __restrict__ partial) {
+    __shared__ float s1[kReg][kReg + 1], s2[kReg][kReg + 1];
+    __shared__ float hor[5][kReg][kTile];
+    __shared__ float red[4];
+    const int c = blockIdx.z, x0 = blockIdx.x * kTile, y0 = blockIdx.y * kTile;
+    const size_t plane = (size_t)H * W;
+    const float* a = img + c * plane;
+    const float* b = gt + c * plane;
+    for (int i = threadIdx.x; i < kReg * kReg; i += 256) {
+        int ry = i / kReg, rx = i - ry * kReg;
+        int y = y0 + ry - kHalo, x = x0 + rx - kHalo;
+        bool in = y >= 0 && y < H && x >= 0 && x < W;
+        s1[ry][rx] = in ? a[(size_t)y * W + x] : 0.0f;
+        s2[ry][rx] = in ? b[(size_t)y * W + x] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kReg * kTile; i += 256) {
+        int ry = i / kTile, tx = i - ry * kTile;
+        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < kWin; ++k) {
+            float p = s1[ry][tx + k], q = s2[ry][tx + k], w = win.g[k];
+            m1 += w * p; m2 += w * q; e11 += w * p * p; e22 += w * q * q; e12 += w * p * q;
+        }
+        hor[0][ry][tx] = m1; hor[1][ry][tx] = m2; hor[2][ry][tx] = e11; hor[3][ry][tx] = e22; hor[4][ry][tx] = e12;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x = x0 + tx, y = y0 + ty;
+    float ssim = 0.f, l1 = 0.f;
+    if (x < W && y < H) {
+        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < kWin; ++k) {
+            float w = win.g[k];
+            mu1 += w * hor[0][ty + k][tx]; mu2 += w * hor[1][ty + k][tx]; e11 += w * hor[2][ty + k][tx];
+            e22 += w * hor[3][ty + k][tx]; e12 += w * hor[4][ty + k][tx];
+        }
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+        const float sg1 = e11 - mu1s, sg2 = e22 - mu2s, sg12 = e12 - mu12;
+        const float A = 2.f * mu12 + C1, B = 2.f * sg12 + C2, Cc = mu1s + mu2s + C1, D = sg1 + sg2 + C2;
+        const float inv = 1.0f / (Cc * D);
+        ssim = A * B * inv;
+        // partial derivatives of the map value (gt is constant)
+        const float d_sg1 = -ssim / D;                 // d/d sigma1^2
+        const float d_sg12 = 2.f * A * inv;            // d/d sigma12
+        const float d_mu1 = (2.f * mu2 * B * Cc - 2.f * mu1 * A * B) * inv / Cc    // explicit
+                            - 2.f * mu1 * d_sg1 - mu2 * d_sg12;                      // through sigma1^2, sigma12
+        const size_t o = (size_t)c * plane + (size_t)y * W + x;
+        const size_t n = (size_t)gridDim.z * plane;
+        maps[o] = d_mu1; maps[n + o] = d_sg1; maps[2 * n + o] = d_sg12;
+        l1 = fabsf(s1[ty + kHalo][tx + kHalo] - s2[ty + kHalo][tx + kHalo]);
+    }
+    const float ts = block_sum_256(ssim, red);
+    const float tl = block_sum_256(l1, red);
+    if (threadIdx.x == 0) {
+        const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[2 * bid] = tl;
+        partial[2 * bid + 1] = ts;
+    }
+}
+
+// loss[0] = w*((1-lam)*L1 + lam*(1-SSIM)), loss[1] = L1, loss[2] = SSIM  (fixed-order double sums)
+__global__ void __launch_bounds__(256) k_photo_final(const float* __restrict__ partial, long long nblocks, double inv_n,
+                                                     float lam, float weight, float* __restrict__ loss) {
+    double sl = 0.0, ss = 0.0;
+    for (long long i = threadIdx.x; i < nblocks; i += 256) { sl += (double)partial[2 * i]; ss += (double)partial[2 * i + 1]; }
+    sl = wave_sum_d(sl); ss = wave_sum_d(ss);
+    __shared__ double w1[4], w2[4];
+    if ((threadIdx.x & 63) == 0) { w1[threadIdx.x >> 6] = sl; w2[threadIdx.x >> 6] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double l1 = ((w1[0] + w1[1]) + (w1[2] + w1[3])) * inv_n, ssim = ((w2[0] + w2[1]) + (w2[2] + w2[3])) * inv_n;
+        loss[0] = (float)((double)weight * ((1.0 - (double)lam) * l1 + (double)lam * (1.0 - ssim)));
+        loss[1] = (float)l1;
+        loss[2] = (float)ssim;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_photo_bwd(const float* __restrict__ img, const float* __restrict__ gt, int H,
+                                                   int W, SsimWindow win, const float* __restrict__ maps, float c_l1,
+                                                   float c_ssim, const float* __restrict__ go,
+                                                   float* __restrict__ grad) {
+    __shared__ float sm[3][kReg][kReg + 1];
+    __shared__ float hor[3][kReg][kTile];
+    const int c = blockIdx.z, x0 = blockIdx.x * kTile, y0 = blockIdx.y * kTile;
+    const size_t plane = (size_t)H * W, n = (size_t)gridDim.z * plane;
+    const float* m0 = maps + c * plane;
+    for (int i = threadIdx.x; i < kReg * kReg; i += 256) {
+        int ry = i / kReg, rx = i - ry * kReg;
+        int y = y0 + ry - kHalo, x = x0 + rx - kHalo;
+        bool in = y >= 0 && y < H && x >= 0 && x < W;
+        size_t o = (size_t)y * W + x;
+        sm[0][ry][rx] = in ? m0[o] : 0.0f;
+        sm[1][ry][rx] = in ? m0[n + o] : 0.0f;
+        sm[2][ry][rx] = in ? m0[2 * n + o] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kReg * kTile; i += 256) {
+        int ry = i / kTile, tx = i - ry * kTile;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < kWin; ++k) {
+            float w = win.g[k];
+            a0 += w * sm[0][ry][tx + k]; a1 += w * sm[1][ry][tx + k]; a2 += w * sm[2][ry][tx + k];
+        }
+        hor[0][ry][tx] = a0; hor[1][ry][tx] = a1; hor[2][ry][tx] = a2;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= W || y >= H) return;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < kWin; ++k) {
+        float w = win.g[k];
+        g0 += w * hor[0][ty + k][tx]; g1 += w * hor[1][ty + k][tx]; g2 += w * hor[2][ty + k][tx];
+    }
+    const size_t o = (size_t)c * plane + (size_t)y * W + x;
+    const float p = img[o], q = gt[o], d = p - q;
+    const float up = go ? *go : 1.0f;
+    const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+    grad[o] = up * (c_l1 * sgn - c_ssim * (g0 + 2.0f * p * g1 + q * g2));
+}
+
 int l1_blocks(long long n) {
     long long b = (n / 4 + kThreads * 8 - 1) / (kThreads * 8);
     if (b < 1) b = 1;
@@ -147,5 +294,53 @@ extern "C" int syn3r_adam_step(float* param, const float* grad, float* exp_avg, 
     SYN3R_LAUNCH(k_adam, dim3((unsigned)b), dim3(kThreads), 0, stream, param, grad, exp_avg, exp_avg_sq, n,
                  (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), bc2_sqrt, eps, neg_step);
     SYN3R_LAUNCH_CHECK("adam_step launch");
+    return SYN3R_OK;
+}
+
+static SsimWindow make_window() {
+    SsimWindow w;
+    double g[kWin], sum = 0.0;
+    for (int i = 0; i < kWin; ++i) { g[i] = exp(-(double)((i - kWin / 2) * (i - kWin / 2)) / (2.0 * 1.5 * 1.5)); sum += g[i]; }
+    for (int i = 0; i < kWin; ++i) w.g[i] = (float)(g[i] / sum);
+    return w;
+}
+
+extern "C" size_t syn3r_photo_loss_workspace_bytes(int C, int H, int W) {
+    if (C <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t n = (size_t)C * H * W;
+    const size_t blocks = (size_t)C * ((H + kTile - 1) / kTile) * ((W + kTile - 1) / kTile);
+    return 3 * n * sizeof(float) + ((2 * blocks * sizeof(float) + 255) / 256) * 256;
+}
+
+extern "C" int syn3r_photo_loss(const float* image, const float* target, int C, int H, int W, float lambda_dssim,
+                                float weight, float* loss3, void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SYN3R_REQUIRE(C > 0 && C <= 65535 && H > 0 && W > 0, "photo_loss: bad sizes C=%d H=%d W=%d", C, H, W);
+    SYN3R_REQUIRE(image && target && loss3 && ws, "photo_loss: null pointer");
+    SYN3R_REQUIRE(lambda_dssim >= 0.0f && lambda_dssim <= 1.0f, "photo_loss: lambda_dssim must be in [0, 1]");
+    SYN3R_REQUIRE(ws_bytes >= syn3r_photo_loss_workspace_bytes(C, H, W), "photo_loss: workspace too small");
+    const size_t n = (size_t)C * H * W;
+    float* maps = (float*)ws;
+    float* partial = maps + 3 * n;
+    const dim3 grid((W + kTile - 1) / kTile, (H + kTile - 1) / kTile, C);
+    SYN3R_LAUNCH(k_photo_fwd, grid, dim3(256), 0, stream, image, target, H, W, make_window(), maps, partial);
+    SYN3R_LAUNCH(k_photo_final, dim3(1), dim3(256), 0, stream, (const float*)partial,
+                 (long long)grid.x * grid.y * grid.z, 1.0 / (double)n, lambda_dssim, weight, loss3);
+    SYN3R_LAUNCH_CHECK("photo_loss launch");
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_photo_loss_backward(const float* image, const float* target, int C, int H, int W,
+                                         float lambda_dssim, float weight, const float* grad_loss, const void* ws,
+                                         float* grad_image, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SYN3R_REQUIRE(C > 0 && C <= 65535 && H > 0 && W > 0, "photo_loss_backward: bad sizes");
+    SYN3R_REQUIRE(image && target && ws && grad_image, "photo_loss_backward: null pointer");
+    const double n = (double)C * H * W;
+    const dim3 grid((W + kTile - 1) / kTile, (H + kTile - 1) / kTile, C);
+    SYN3R_LAUNCH(k_photo_bwd, grid, dim3(256), 0, stream, image, target, H, W, make_window(), (const float*)ws,
+                 (float)((double)weight * (1.0 - (double)lambda_dssim) / n), (float)((double)weight * (double)lambda_dssim / n),
+                 grad_loss, grad_image);
+    SYN3R_LAUNCH_CHECK("photo_loss_backward launch");
     return SYN3R_OK;
 }

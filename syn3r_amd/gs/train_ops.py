@@ -44,6 +44,48 @@ def l1_loss(image: torch.Tensor, target: torch.Tensor, weight: float = 1.0) -> t
     return _L1Loss.apply(image, target, weight)
 
 
+class _PhotoLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image: torch.Tensor, target: torch.Tensor, lambda_dssim: float, weight: float):
+        L.require_gpu(image, target)
+        if image.shape != target.shape or image.dim() != 3 or image.dtype != torch.float32 or target.dtype != torch.float32:
+            raise ValueError("photometric_loss: image and target must be float32 [C,H,W] tensors of the same shape")
+        image, target = image.contiguous(), target.contiguous()
+        lib = L.load()
+        C_, H_, W_ = image.shape
+        # own buffer, not the shared workspace cache: the derivative maps must survive until backward
+        ws = torch.empty(lib.syn3r_photo_loss_workspace_bytes(C_, H_, W_), dtype=torch.uint8, device=image.device)
+        out = torch.empty(3, dtype=torch.float32, device=image.device)
+        L.check(lib.syn3r_photo_loss(L.ptr(image), L.ptr(target), C_, H_, W_, float(lambda_dssim), float(weight),
+                                     L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr(image.device)), "photo_loss")
+        ctx.save_for_backward(image, target, ws)
+        ctx.args = (float(lambda_dssim), float(weight))
+        ctx.mark_non_differentiable(out)
+        ctx.parts = out
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, grad_loss: torch.Tensor, _grad_parts):
+        image, target, ws = ctx.saved_tensors
+        lam, weight = ctx.args
+        C_, H_, W_ = image.shape
+        go = grad_loss.to(torch.float32).contiguous()
+        grad = torch.empty_like(image)
+        L.check(L.load().syn3r_photo_loss_backward(L.ptr(image), L.ptr(target), C_, H_, W_, lam, weight, L.ptr(go),
+                                                   L.ptr(ws), L.ptr(grad), L.stream_ptr(image.device)),
+                "photo_loss_backward")
+        return grad, None, None, None
+
+
+def photometric_loss(image: torch.Tensor, target: torch.Tensor, lambda_dssim: float = 0.2, weight: float = 1.0,
+                     return_parts: bool = False):
+    """The published 3DGS loss `weight * ((1 - lambda) * L1 + lambda * (1 - SSIM))` on [C,H,W] images, fused: one
+    tile pass forward (also storing the SSIM derivative maps), one tile pass backward.  `return_parts`: also the
+    device tensor [loss, L1, SSIM]."""
+    loss, parts = _PhotoLoss.apply(image, target, lambda_dssim, weight)
+    return (loss, parts) if return_parts else loss
+
+
 class FusedAdam:
     """`torch.optim.Adam(param_groups, eps=...)` (no weight decay / amsgrad) with one kernel per parameter tensor.
     Keeps torch's `param_groups` / `state` layout so checkpoints and lr schedules written for the torch optimiser

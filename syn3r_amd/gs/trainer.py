@@ -3,8 +3,8 @@
 
 The reference delegates all of this to `FSGS.utils.trainer_v4.GSTrainer` (un-vendored submodule): only the
 call surface is visible.  This module provides that surface with the published 3DGS training step
-(render -> L1 photometric loss weighted by the camera confidence -> backward -> Adam; the loss and the
-Adam update are the fused HIP operators of `train_ops.py`), no densification
+(render -> (1-lambda) L1 + lambda (1-SSIM) photometric loss weighted by the camera confidence -> backward ->
+Adam; the loss and the Adam update are the fused HIP operators of `train_ops.py`), no densification
 heuristics (out of scope).  Camera conventions follow the published 3DGS/FSGS code:
 `world_view_transform` and `full_proj_transform` are the TRANSPOSED matrices.
 """
@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from ..raster import GaussianRasterizationSettings, GaussianRasterizer
-from .train_ops import FusedAdam, l1_loss
+from .train_ops import FusedAdam, l1_loss, photometric_loss
 
 
 def _world2view(R: np.ndarray, t: np.ndarray) -> np.ndarray:
@@ -128,6 +128,7 @@ class OptimizationParams:
     opacity_lr: float = 5e-2
     scaling_lr: float = 5e-3
     rotation_lr: float = 1e-3
+    lambda_dssim: float = 0.2          # published 3DGS: L = (1 - lambda) L1 + lambda (1 - SSIM)
     pseudo_cam_sampling_rate: float = 0.02
     seed: int = 0
 
@@ -192,7 +193,10 @@ class GSTrainer:
     def train_step(self, cam: Optional[Camera] = None) -> float:
         cam = cam or self._pick_camera()
         out = self.render_view(cam)
-        loss = l1_loss(out["render"], cam.original_image, weight=float(cam.cam_confidence))
+        if self.opt.lambda_dssim > 0.0:
+            loss = photometric_loss(out["render"], cam.original_image, self.opt.lambda_dssim, float(cam.cam_confidence))
+        else:
+            loss = l1_loss(out["render"], cam.original_image, weight=float(cam.cam_confidence))
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.optimizer.step()

@@ -77,3 +77,50 @@ def test_fused_adam_skips_params_without_grad_and_rejects_cpu(gpu):
     q.grad = torch.ones(10)
     with pytest.raises(_lib.Syn3rError):
         FusedAdam([{"params": [q]}]).step()
+
+
+def _published_ssim(img1, img2):
+    """The published 3DGS `ssim()` (utils/loss_utils.py of the 3DGS code base the FSGS trainer builds on):
+    11x11 Gaussian window, sigma 1.5, conv2d padding 5, groups = channels, mean of the map."""
+    import math
+    import torch.nn.functional as Fn
+    g = torch.tensor([math.exp(-(x - 5) ** 2 / (2 * 1.5 ** 2)) for x in range(11)], dtype=img1.dtype)
+    g = (g / g.sum())[:, None]
+    C = img1.shape[0]
+    win = (g @ g.t())[None, None].expand(C, 1, 11, 11).contiguous()
+    conv = lambda t: Fn.conv2d(t[None], win, padding=5, groups=C)[0]
+    mu1, mu2 = conv(img1), conv(img2)
+    s1, s2, s12 = conv(img1 * img1) - mu1 * mu1, conv(img2 * img2) - mu2 * mu2, conv(img1 * img2) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s1 + s2 + C2))).mean()
+
+
+@pytest.mark.parametrize("shape,lam", [((3, 37, 53), 0.2), ((3, 64, 48), 0.2), ((1, 16, 16), 1.0), ((3, 20, 70), 0.0)])
+def test_photometric_loss_vs_published_formula(shape, lam, gpu):
+    from syn3r_amd.gs.train_ops import photometric_loss
+    g = torch.Generator().manual_seed(11 + shape[1])
+    a = torch.rand(shape, generator=g)
+    b = (a + 0.2 * torch.randn(shape, generator=g)).clamp(0, 1)      # correlated target: SSIM well away from 0
+    ad = a.double().requires_grad_(True)
+    l1 = (ad - b.double()).abs().mean()
+    ssim = _published_ssim(ad, b.double())
+    ref = 0.7 * ((1 - lam) * l1 + lam * (1 - ssim))
+    (ref * 1.5).backward()
+    x = a.to(gpu).requires_grad_(True)
+    loss, parts = photometric_loss(x, b.to(gpu), lambda_dssim=lam, weight=0.7, return_parts=True)
+    (loss * 1.5).backward()
+    assert abs(float(parts[1]) - float(l1.detach())) < 2e-6 and abs(float(parts[2]) - float(ssim.detach())) < 2e-5
+    assert abs(float(loss.detach()) - float(ref.detach())) < 2e-5
+    torch.testing.assert_close(x.grad.cpu(), ad.grad.float(), rtol=2e-3, atol=2e-7 + 2e-4 * float(ad.grad.abs().max()))
+
+
+def test_photometric_loss_full_frame_and_errors(gpu):
+    from syn3r_amd.gs.train_ops import photometric_loss
+    g = torch.Generator().manual_seed(2)
+    a = torch.rand(3, 1080, 1920, generator=g).to(gpu).requires_grad_(True)
+    loss, parts = photometric_loss(a, a.detach().clone(), return_parts=True)       # identical images: SSIM = 1, L1 = 0
+    loss.backward()
+    assert abs(float(parts[2]) - 1.0) < 1e-5 and float(parts[1]) == 0.0 and abs(float(loss.detach())) < 1e-5
+    assert float(a.grad.abs().max()) < 1e-6
+    with pytest.raises(ValueError):
+        photometric_loss(a.detach()[0], a.detach()[0])

@@ -39,7 +39,8 @@ def test_render_view_and_one_adam_step_match_oracle(gpu):
                                   cam.full_proj_transform.cpu().double(), cam.camera_center.cpu().double(),
                                   math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), H, W, torch.zeros(3, dtype=torch.float64), 3)
     np.testing.assert_allclose(out["render"].detach().cpu().numpy(), oc.detach().numpy(), atol=3e-4)
-    loss_o = 0.5 * (oc - target.double()).abs().mean()
+    from tests.test_train_ops_gpu import _published_ssim
+    loss_o = 0.5 * (0.8 * (oc - target.double()).abs().mean() + 0.2 * (1.0 - _published_ssim(oc, target.double())))
     opt = torch.optim.Adam([{"params": [P[0]], "lr": 1.6e-4}, {"params": [P[1]], "lr": 2.5e-3}, {"params": [P[2]], "lr": 5e-2},
                             {"params": [P[3]], "lr": 5e-3}, {"params": [P[4]], "lr": 1e-3}], eps=1e-15)
     loss_o.backward()
