@@ -295,16 +295,21 @@ class UNetSpatioTemporalConditionModel:
                 wp, bp, D = ops.pack_geglu(p.t[k], p.t[pre + "bias"])
                 pk[pre + "geglu_w"], pk[pre + "geglu_b"] = wp, bp
         self.packed = pk
-        self.alpha = {k: torch.sigmoid(t.float()).to(H) for k, t in p.t.items() if k.endswith("mix_factor")}
+        # AlphaBlender scales as host floats, computed ONCE (reading a device scalar per block would drain the
+        # launch queue 60 times per forward): alpha in fp16 as `alpha.to(x_spatial.dtype)` (resnet.py:797), and
+        # 1 - alpha in fp16 arithmetic, as the reference
+        self.alpha = {}
+        for k, t in p.t.items():
+            if k.endswith("mix_factor"):
+                a = torch.sigmoid(t.float()).to(H)
+                self.alpha[k] = (float(a), float((1.0 - a).to(H)))
 
     def w(self, name: str) -> torch.Tensor:
         return self.packed.get(name, self.p.t.get(name))
 
     # ------------------------------------------------------------------ blocks
     def _blend_scales(self, name: str):
-        a = self.alpha[name]                       # fp16, as `alpha.to(x_spatial.dtype)` (resnet.py:797)
-        one_minus = (1.0 - a).to(H)                # fp16 arithmetic, as the reference
-        return float(a), float(one_minus)
+        return self.alpha[name]
 
     def _resblock(self, pre: str, x: torch.Tensor, st: dict, cin: int, cout: int) -> torch.Tensor:
         B, F, h, w_ = st["B"], st["F"], st["h"], st["w"]

@@ -208,6 +208,10 @@ class AutoencoderKLTemporalDecoder:
             elif t.dim() == 5:
                 pk[k] = t[..., 0, 0].permute(0, 2, 1).contiguous()
         self.packed = pk
+        # host-side constants, read back ONCE (a device-scalar read per block would drain the launch queue)
+        self.one_minus_alpha = {k: float(torch.sigmoid(t.float())) for k, t in self.p.t.items() if k.endswith("mix_factor")}
+        self.time_conv_host = (self.p.t["decoder.time_conv_out.weight"].float().cpu(),
+                               self.p.t["decoder.time_conv_out.bias"].float().cpu())
 
     def w(self, name: str) -> torch.Tensor:
         return self.packed.get(name, self.p.t.get(name))
@@ -233,7 +237,7 @@ class AutoencoderKLTemporalDecoder:
         hcur = ops.tconv3(hcur, W(t + ".conv1.weight"), W(t + ".conv1.bias"), B, F, HW)
         hcur = ops.groupnorm(hcur, W(t + ".norm2.weight"), W(t + ".norm2.bias"), B, 1e-5, True)
         # AlphaBlender with the switch: a = 1 - sigmoid(mix); out = a*xs + (1-a)*(xs + conv2) = xs + (1-a)*conv2
-        one_minus_a = float(torch.sigmoid(self.p.t[pre + ".time_mixer.mix_factor"].float()))
+        one_minus_a = self.one_minus_alpha[pre + ".time_mixer.mix_factor"]
         return ops.tconv3(hcur, W(t + ".conv2.weight"), W(t + ".conv2.bias"), B, F, HW, residual=xs,
                           s_acc=one_minus_a, s_res=1.0)
 
@@ -317,6 +321,6 @@ class AutoencoderKLTemporalDecoder:
             prev = co
         x = ops.groupnorm(x, W("decoder.conv_norm_out.weight"), W("decoder.conv_norm_out.bias"), N, 1e-6, True)
         y = ops.conv3x3(x.view(N, h, w_, boc[0]), W("decoder.conv_out.weight"), W("decoder.conv_out.bias"))   # [N,H,W,8]
-        frames = ops.time_conv_out(y.view(-1, y.shape[-1]), self.p.t["decoder.time_conv_out.weight"],
-                                   self.p.t["decoder.time_conv_out.bias"], B, F, h * w_).view(N, 3, h, w_)
+        frames = ops.time_conv_out(y.view(-1, y.shape[-1]), self.time_conv_host[0], self.time_conv_host[1], B, F,
+                                   h * w_).view(N, 3, h, w_)
         return SimpleNamespace(sample=frames) if return_dict else (frames,)
