@@ -250,8 +250,9 @@ def main():
     if loop_b is not None:
         loop_b.count_flops()
     barrier()
-    # HIP-event brackets only on the kernels that can be the dominant one (an event pair costs microseconds)
-    with L.kernel_trace(only="k_gemm,k_attn_spatial,k_render") as tr:
+    # start/stop events only on the kernels that can be the dominant one (a timed launch costs microseconds):
+    # the contraction family and the spatial attention when the SVD unit is part of the step, else the blend kernels
+    with L.kernel_trace(only="k_gemm,k_attn_spatial" if loop_b is not None else "k_render") as tr:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()

@@ -52,20 +52,14 @@ static bool wanted(const char* name) {
     }
     return false;
 }
-static thread_local bool t_open = false;
-
-void trace_begin(const char* name, hipStream_t stream) {
+bool trace_open(const char* name, hipEvent_t* start, hipEvent_t* stop) {
     std::lock_guard<std::mutex> lk(g_mu);
-    t_open = wanted(name);
-    if (!t_open) return;
+    if (!wanted(name)) return false;
     Span s{name, get_event(), get_event()};
-    hipEventRecord(s.a, stream);
+    *start = s.a;
+    *stop = s.b;
     g_spans.push_back(s);
-}
-void trace_end(hipStream_t stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (t_open && !g_spans.empty()) hipEventRecord(g_spans.back().b, stream);
-    t_open = false;
+    return true;
 }
 }  // namespace syn3r
 

@@ -1,6 +1,7 @@
 // Shared host-side helpers for libsyn3r_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -25,8 +26,7 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 // Optional per-kernel timing with HIP events on the launch stream (syn3r_trace_* in the ABI).
 bool trace_on();
 bool trace_detail();   // syn3r_trace_enable(2): contraction launches carry their shape in the name
-void trace_begin(const char* name, hipStream_t stream);
-void trace_end(hipStream_t stream);
+bool trace_open(const char* name, hipEvent_t* start, hipEvent_t* stop);   // false: this kernel is filtered out
 
 // 4x4 / 3x3 matrices travel to kernels by value.
 struct Mat4f { float m[16]; };
@@ -44,21 +44,19 @@ struct Mat3d { double m[9]; };
         }                                        \
     } while (0)
 
-// Kernel launch that the tracer can bracket with events on the same stream.
-#define SYN3R_LAUNCH(kernel, grid, block, shmem, stream, ...)                        \
-    do {                                                                             \
-        if (syn3r::trace_on()) syn3r::trace_begin(#kernel, stream);                  \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);         \
-        if (syn3r::trace_on()) syn3r::trace_end(stream);                             \
+// Kernel launch the tracer can time.  A traced launch goes through hipExtLaunchKernelGGL, which attaches the
+// start / stop events to the dispatch packet itself (the kernel's own begin / end timestamps): no marker
+// packets before and after the kernel, so tracing costs a fraction of two hipEventRecord calls per launch.
+#define SYN3R_LAUNCH_NAMED(name, kernel, grid, block, shmem, stream, ...)                                  \
+    do {                                                                                                   \
+        hipEvent_t ea__ = nullptr, eb__ = nullptr;                                                         \
+        if (syn3r::trace_on() && syn3r::trace_open(name, &ea__, &eb__))                                    \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, ea__, eb__, 0, __VA_ARGS__);          \
+        else                                                                                               \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                           \
     } while (0)
-
-// same, with an explicit trace name (template instantiations, per-shape detail)
-#define SYN3R_LAUNCH_NAMED(name, kernel, grid, block, shmem, stream, ...)            \
-    do {                                                                             \
-        if (syn3r::trace_on()) syn3r::trace_begin(name, stream);                     \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);         \
-        if (syn3r::trace_on()) syn3r::trace_end(stream);                             \
-    } while (0)
+#define SYN3R_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    SYN3R_LAUNCH_NAMED(#kernel, kernel, grid, block, shmem, stream, __VA_ARGS__)
 
 #define SYN3R_LAUNCH_CHECK(name)                                        \
     do {                                                                \
