@@ -262,7 +262,8 @@ int syn3r_gemm_f16(const void* A, long long lda, const void* W, void* out, long 
                    const void* aux, long long ldaux, float s_acc, float s_res, float s_aux, int M, int N, int K,
                    void* stream);
 
-/* Tuning hook: force the GEMM block height (128 or 256 rows; 0 = library default). */
+/* Tuning / test hook: 0 = library default (kernel chosen per shape); 128 / 256 = register-staged kernel of that
+ * block height; -128 / -256 = LDS-DMA kernel of that block height; -320 = the 256 x 320 wide-tile LDS-DMA kernel. */
 int syn3r_gemm_set_tile(int bm);
 
 /*

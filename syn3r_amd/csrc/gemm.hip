@@ -20,6 +20,7 @@
 // Blocks are dealt to XCDs in contiguous chunks (neighbouring M-tiles share the weight panel,
 // the N-tiles of one M-tile share the activation panel in L2).
 #include "common.h"
+#include <cstdlib>
 
 using namespace syn3r;
 
@@ -67,6 +68,9 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chu
 
 // Shared epilogue: acc (+bias +rowvec) -> fp16 through LDS -> row-contiguous 16-byte stores (+residual, +aux),
 // or the GEGLU gate.  Must be entered by every wavefront of the block after the last LDS tile read.
+// PREFETCH_RES: 1 = residual rows requested before the accumulators are staged (most latency hidden);
+// 2 = requested after the staging writes, when the accumulators are dead (wide tile: registers are short)
+template <int PREFETCH_RES = 1>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc)[TM][TN], char* smem_raw, int lane,
                                               int wv, int wm, int wn, int m0, int n0, int tile_n) {
     const int fr = lane & 15, fq = lane >> 4;
@@ -80,7 +84,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
     // behind the accumulator -> LDS staging and the block barrier (10 x 16 B per lane; the MFMA fragments
     // are dead here, so the registers are free).
     half8 res[WM * (WN / 8) / 64];
-    if (p.residual && p.geglu_D <= 0) {
+    auto prefetch_residual = [&]() {
 #pragma unroll
         for (int it = 0; it < WM * (WN / 8) / 64; ++it) {
             const int q = lane + it * 64;
@@ -92,7 +96,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
                 for (int e = 0; e < 8; ++e) res[it][e] = (m < p.M && n + e < p.N) ? ((const _Float16*)p.residual)[(long long)m * p.ldr + n + e] : (_Float16)0.f;
             }
         }
-    }
+    };
+    if (PREFETCH_RES == 1 && p.residual && p.geglu_D <= 0) prefetch_residual();
     float bias4[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -141,6 +146,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
             *(half4e*)(st + row * EPI_LD + col) = o;
         }
     }
+    if (PREFETCH_RES == 2 && p.residual && p.geglu_D <= 0) prefetch_residual();
     __builtin_amdgcn_wave_barrier();
     __syncthreads();
     if (p.geglu_D > 0) {
@@ -185,8 +191,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
             if (p.residual) {
+                half8 rr;
+                if constexpr (PREFETCH_RES != 0) rr = res[it];
+                else rr = *(const half8*)(p.residual + (long long)m * p.ldr + n);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] += p.s_res * (float)res[it][e];
+                for (int e = 0; e < 8; ++e) f[e] += p.s_res * (float)rr[e];
             }
             if (p.aux) {
                 half8 av = *(const half8*)(p.aux + (long long)m * p.ldaux + n);
@@ -564,6 +573,207 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
     gemm_epilogue(p, acc, smem_raw, lane, wv, wm, wn, m0, n0, tile_n);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide-tile variant: 256 x 320 output tile, 512 threads, ONE block per CU, wavefront tile 64 x 160
+// (4 x 10 MFMA tiles = 160 accumulator registers).  Against the 128 x 160 blocks it halves the L2->LDS bytes
+// per FLOP (N = 320 is one tile: A is read exactly once) and issues 0.35 instead of 0.45 fragment reads per
+// MFMA; the price is one wave-pair per SIMD and no second block to hide a tile's prologue and epilogue, so it
+// is selected per shape (launch_dma).  2-stage LDS ring of 73,728-byte stages, one barrier per k-tile, the
+// fragments of a k-half are read into the SAME registers after the 40 MFMAs of the previous half have issued
+// (the partner wavefront on the SIMD covers the read latency).  The GEGLU pair [80 hidden | 80 gate] of a
+// 160-column group lives in one wavefront, so the gate is applied in registers.
+constexpr int WBM = 256, WBN = 320, WTN = 10;
+constexpr int W_A_BYTES = WBM * BK * 2;                      // 32,768
+constexpr int W_B_BYTES = WBN * BK * 2;                      // 40,960
+constexpr int W_STAGE = W_A_BYTES + W_B_BYTES;               // 73,728
+
+template <int MODE>
+__global__ void __launch_bounds__(512, 2) k_gemm_wide(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int Ncols = p.geglu_D > 0 ? p.N : p.N;
+    const int tiles_n = (Ncols + WBN - 1) / WBN;
+    const int tiles_m = (p.M + WBM - 1) / WBM;
+    const unsigned bid = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * WBM, n0 = tile_n * WBN;
+
+    // Addressing state is kept small (160 of the 256 registers are accumulators): per A piece the clamped row
+    // index and the running source pointer, per B piece the running pointer, and ONE bit mask of the pieces that
+    // advance (rows in range); the im2col decomposition of a row is redone at every tap change.
+    const int prow = lane >> 3;
+    const int csrc = (lane & 7) ^ prow;
+    const __half* zero = g_zero_page;
+    int a_m[4];
+    unsigned live = 0;                    // bit i: A piece i advances; bit 4 + j: B piece j advances
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + wv * 32 + i * 8 + prow;
+        a_m[i] = m < p.M ? m : p.M - 1;
+    }
+    const __half* b_cur[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        int n = n0 + (wv * 5 + j) * 8 + prow;
+        bool ok = n < p.N;
+        b_cur[j] = ok ? p.W + (long long)n * p.K + csrc * 8 : zero;
+        if (ok) live |= 16u << j;
+    }
+    const int cpb = (MODE == MODE_DENSE) ? 1 : p.Cin / BK;
+    const __half* a_cur[4];
+    int tap_next = 0, c_left = 0;
+    auto setup_tap = [&](int tap) {
+        live &= ~15u;
+        if constexpr (MODE == MODE_CONV2D) {
+            const int dy = tap / 3 - p.pad, dx = tap % 3 - p.pad;
+            const int Hg = p.ups ? p.Hi * 2 : p.Hi, Wg = p.ups ? p.Wi * 2 : p.Wi;
+            const int hw = p.Ho * p.Wo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int an = a_m[i] / hw, r = a_m[i] - an * hw;
+                const int ay = r / p.Wo, ax = r - ay * p.Wo;
+                int yy = ay * p.stride + dy, xx = ax * p.stride + dx;
+                bool ok = yy >= 0 && yy < Hg && xx >= 0 && xx < Wg;
+                if (p.ups) { yy >>= 1; xx >>= 1; }
+                long long off = (((long long)an * p.Hi + yy) * p.Wi + xx) * p.Cin + csrc * 8;
+                a_cur[i] = ok ? p.A + off : zero;
+                if (ok) live |= 1u << i;
+            }
+        } else if constexpr (MODE == MODE_TCONV) {
+            const int df = tap - 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int ff = (a_m[i] / p.HW) % p.F + df;
+                bool ok = ff >= 0 && ff < p.F;
+                a_cur[i] = ok ? p.A + ((long long)a_m[i] + (long long)df * p.HW) * p.Cin + csrc * 8 : zero;
+                if (ok) live |= 1u << i;
+            }
+        }
+    };
+    if constexpr (MODE == MODE_DENSE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_cur[i] = p.A + (long long)a_m[i] * p.lda + csrc * 8;
+        live |= 15u;
+    }
+    auto issue_stage = [&](int buf) {     // stages are issued in k order
+        char* st = smem_raw + buf * W_STAGE;
+        if constexpr (MODE != MODE_DENSE) {
+            if (c_left == 0) { setup_tap(tap_next); ++tap_next; c_left = cpb; }
+            --c_left;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)a_cur[i], (lds_void_t*)(st + (wv * 4 + i) * 1024), 16, 0, 0);
+            a_cur[i] += ((live >> i) & 1u) * BK;
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)b_cur[j], (lds_void_t*)(st + W_A_BYTES + (wv * 5 + j) * 1024), 16, 0, 0);
+            b_cur[j] += ((live >> (4 + j)) & 1u) * BK;
+        }
+    };
+
+    float4v acc[2][TM][TN];               // [column half][row tile][column tile]: halves are 80 columns each
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[hh][i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = p.K / BK;
+    const int fr = lane & 15, fq = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const unsigned a_row = (unsigned)((wm * WM + fr) * 128);
+    const unsigned b_row = (unsigned)(W_A_BYTES + (wn * 160 + fr) * 128);
+    const unsigned swz[2] = {(unsigned)(((0 + fq) ^ (fr & 7)) << 4), (unsigned)(((4 + fq) ^ (fr & 7)) << 4)};
+
+    issue_stage(0);
+    int buf = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage kt (the only one in flight) has landed
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nkt) issue_stage(buf ^ 1);              // the slot every wavefront finished reading in iteration kt-1
+        const unsigned sb = lds0 + (unsigned)buf * W_STAGE;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            half8 af[TM], bf[WTN];
+            const unsigned aa = sb + a_row + swz[kh], ba = sb + b_row + swz[kh];
+            DS_READ128(af[0], aa, 0); DS_READ128(af[1], aa, 2048); DS_READ128(af[2], aa, 4096); DS_READ128(af[3], aa, 6144);
+            DS_READ128(bf[0], ba, 0); DS_READ128(bf[1], ba, 2048); DS_READ128(bf[2], ba, 4096); DS_READ128(bf[3], ba, 6144);
+            DS_READ128(bf[4], ba, 8192); DS_READ128(bf[5], ba, 10240); DS_READ128(bf[6], ba, 12288); DS_READ128(bf[7], ba, 14336);
+            DS_READ128(bf[8], ba, 16384); DS_READ128(bf[9], ba, 18432);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]),
+                           "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7]), "+v"(bf[8]), "+v"(bf[9]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < WTN; ++j)
+                    acc[j / TN][i][j % TN] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[j / TN][i][j % TN], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // the next half's reads reuse af / bf: keep them behind these MFMAs
+        }
+        buf ^= 1;
+    }
+    __syncthreads();   // every wavefront is done reading the ring before the epilogue reuses it
+
+    if (p.geglu_D > 0) {
+        // GEGLU.forward: hidden * gelu(gate) on the fp16-rounded projection output (activations.py); the wavefront's
+        // 160 columns are one packed group [80 hidden | 80 gate]
+        const int gn = n0 + wn * 160;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = gn + j * 16 + fq * 4;
+            float bh[4], bg[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bh[r] = (p.bias && n + r < p.N) ? __half2float(p.bias[n + r]) : 0.f;
+                bg[r] = (p.bias && n + 80 + r < p.N) ? __half2float(p.bias[n + 80 + r]) : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float hv = (float)(_Float16)(acc[0][i][j][r] + bh[r]);
+                    float gv = (float)(_Float16)(acc[1][i][j][r] + bg[r]);
+                    acc[0][i][j][r] = hv * gelu_erf(gv);
+                }
+        }
+        GemmParams q = p;
+        q.bias = nullptr; q.rowvec = nullptr; q.residual = nullptr; q.aux = nullptr; q.s_acc = 1.0f;
+        q.N = p.geglu_D; q.geglu_D = 0;
+        gemm_epilogue<0>(q, acc[0], smem_raw, lane, wv, wm, wn, m0, tile_n * 160, tile_n);
+        return;
+    }
+    // (no residual prefetch here: with the other half's 80 accumulators live it would spill)
+    gemm_epilogue<0>(p, acc[0], smem_raw, lane, wv, wm, wn * 2, m0, n0, tile_n);
+    __builtin_amdgcn_wave_barrier();     // a wavefront's staging area is its own: program order is enough
+    gemm_epilogue<0>(p, acc[1], smem_raw, lane, wv, wm, wn * 2 + 1, m0, n0, tile_n);
+}
+
+template <int MODE>
+int launch_wide(const GemmParams& p, hipStream_t stream) {
+    constexpr size_t lds = (size_t)2 * W_STAGE;   // 147,456 B
+    static_assert(8 * WM * EPI_LD * sizeof(__half) <= lds, "epilogue staging must fit in the ring");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_wide<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_wide)");
+        attr_set = true;
+    }
+    int tiles = ((p.M + WBM - 1) / WBM) * ((p.N + WBN - 1) / WBN);
+    char name[96];
+    if (trace_on()) {
+        if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_wide<%d>[M%d,N%d,K%d,e%d]", MODE, p.M, p.N, p.K, p.geglu_D > 0 ? 2 : (p.residual != nullptr));
+        else snprintf(name, sizeof(name), "k_gemm_wide<%d>", MODE);
+    }
+    SYN3R_LAUNCH_NAMED(name, (k_gemm_wide<MODE>), dim3(tiles), dim3(512), lds, stream, p);
+    SYN3R_LAUNCH_CHECK("gemm_wide launch");
+    return SYN3R_OK;
+}
+
 int g_dma_bm = 0;   // 0 = by shape; 128 / 256 forced (syn3r_gemm_set_tile(-128 / -256), tuning only)
 
 template <int MODE, int BM>
@@ -589,9 +799,23 @@ int launch_dma_bm(const GemmParams& p, hipStream_t stream) {
 
 template <int MODE>
 int launch_dma(const GemmParams& p, hipStream_t stream) {
+    static int wide_env = -2;       // SYN3R_GEMM_WIDE: unset = by shape, 0 = never, 1 = always (tuning)
+    if (wide_env == -2) { const char* e = getenv("SYN3R_GEMM_WIDE"); wide_env = e ? atoi(e) : -1; }
+    if (g_dma_bm == -320) return launch_wide<MODE>(p, stream);       // forced by syn3r_gemm_set_tile(-320)
+    if (g_dma_bm == 0 && wide_env != 0) {
+        // measured on MI355X inside the UNet (tools/gemm_ab.py, same box): the 256 x 320 tile is 7..14 % faster on
+        // the dense contractions whenever its tiles fill the 256 CUs (last round >= 80 % full), except the
+        // residual-add projections with K <= 1280, whose epilogue misses the early residual prefetch (+2..19 %);
+        // the implicit-GEMM convolutions are within 3 % either way and keep the two-blocks-per-CU kernel
+        const long long tiles = (long long)((p.M + WBM - 1) / WBM) * ((p.N + WBN - 1) / WBN);
+        const long long rounds = (tiles + 255) / 256;
+        const bool fills = tiles * 10 >= rounds * 256 * 8;
+        const bool short_residual = p.residual != nullptr && p.K <= 1280;
+        if (wide_env == 1 || (MODE == MODE_DENSE && fills && !short_residual)) return launch_wide<MODE>(p, stream);
+    }
     // measured on MI355X (tools/gemm_bench.py): two 128-row blocks per CU win on every UNet shape except the
     // wide feed-forward expansions at C = 1280, where re-reading the 160-column B tile per 128 rows costs more
-    int bm = g_dma_bm ? g_dma_bm : ((p.N >= 5120 && p.K >= 1280) ? 256 : 128);
+    int bm = g_dma_bm > 0 ? g_dma_bm : ((p.N >= 5120 && p.K >= 1280) ? 256 : 128);
     return bm == 128 ? launch_dma_bm<MODE, 128>(p, stream) : launch_dma_bm<MODE, 256>(p, stream);
 }
 
@@ -636,8 +860,10 @@ int check_common(const GemmParams& p, const char* who) {
 }  // namespace
 
 extern "C" int syn3r_gemm_set_tile(int bm) {
-    SYN3R_REQUIRE(bm == 0 || bm == 128 || bm == 256 || bm == -128 || bm == -256, "gemm_set_tile: bm must be 0, +-128 or +-256");
-    if (bm < 0) { g_tile_bm = 0; g_dma_bm = -bm; }          // LDS-DMA kernel with a forced block height
+    SYN3R_REQUIRE(bm == 0 || bm == 128 || bm == 256 || bm == -128 || bm == -256 || bm == -320,
+                  "gemm_set_tile: bm must be 0, +-128, +-256 or -320");
+    if (bm == -320) { g_tile_bm = 0; g_dma_bm = -320; }     // the 256 x 320 wide-tile LDS-DMA kernel
+    else if (bm < 0) { g_tile_bm = 0; g_dma_bm = -bm; }     // LDS-DMA kernel with a forced block height
     else { g_tile_bm = bm; g_dma_bm = 0; }                  // 0: LDS-DMA by shape; > 0: register-staged kernel
     return SYN3R_OK;
 }

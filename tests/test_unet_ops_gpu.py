@@ -201,3 +201,51 @@ def test_ops_reject_bad_input(gpu):
         ops.linear(torch.zeros(8, 64, dtype=H), torch.zeros(16, 64, dtype=H))   # CPU tensors
     with pytest.raises(_lib.Syn3rError):
         ops.attention_temporal(torch.zeros(40 * 2, 192, dtype=H, device=gpu), 1, 40, 2, 1)   # F > 32
+
+
+@pytest.fixture
+def every_contraction_kernel():
+    """Run a test body once per contraction kernel: the per-shape default and every forced variant of
+    `syn3r_gemm_set_tile` (register-staged 128/256, LDS-DMA 128/256, 256x320 wide tile)."""
+    from syn3r_amd import _lib
+    lib = _lib.load()
+
+    def run(body):
+        try:
+            for tile in (0, 128, 256, -128, -256, -320):
+                _lib.check(lib.syn3r_gemm_set_tile(tile), "set_tile")
+                body(tile)
+        finally:
+            lib.syn3r_gemm_set_tile(0)
+    return run
+
+
+def test_every_contraction_kernel_agrees(gpu, every_contraction_kernel):
+    """Dense / conv3x3 / tconv3 / fused GEGLU with the full epilogue on ragged sizes (M, N not multiples of the
+    tiles, N crossing the 320-column wide tile), through every kernel variant."""
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(77)
+    M, N, K, rpv = 700, 400, 192, 100
+    x, w, b = rnd(g, M, K, dev=gpu), rnd(g, N, K, scale=K ** -0.5, dev=gpu), rnd(g, N, dev=gpu)
+    rv, res, aux = rnd(g, M // rpv, N, dev=gpu), rnd(g, M, N, dev=gpu), rnd(g, M, N, dev=gpu)
+    ref_lin = 0.3 * (x.float() @ w.float().T + b.float() + rv.float().repeat_interleave(rpv, 0)) + res.float() + 0.7 * aux.float()
+    xc = rnd(g, 2, 9, 11, 64, dev=gpu)
+    wc, bc = rnd(g, 328, 3, 3, 64, scale=(9 * 64) ** -0.5, dev=gpu), rnd(g, 328, dev=gpu)
+    ref_conv = Fn.conv2d(xc.float().permute(0, 3, 1, 2), wc.float().permute(0, 3, 1, 2), bc.float(), padding=1).permute(0, 2, 3, 1)
+    B, F, HW = 2, 5, 13
+    xt = rnd(g, B * F * HW, 64, dev=gpu)
+    wt, bt = rnd(g, 336, 3, 64, scale=(3 * 64) ** -0.5, dev=gpu), rnd(g, 336, dev=gpu)
+    ref_t = Fn.conv3d(xt.float().view(B, F, HW, 64).permute(0, 3, 1, 2)[..., None], wt.float().permute(0, 2, 1)[..., None, None],
+                      bt.float(), padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(-1, 336)
+    D = 200
+    wg, bg = rnd(g, 2 * D, K, scale=K ** -0.5, dev=gpu), rnd(g, 2 * D, dev=gpu)
+    wp, bp, _ = ops.pack_geglu(wg, bg)
+    y = (x.float() @ wg.float().T + bg.float()).half().float()
+    ref_g = y[:, :D] * Fn.gelu(y[:, D:])
+
+    def body(tile):
+        close(ops.linear(x, w, b, rowvec=rv, rows_per_vec=rpv, residual=res, aux=aux, s_acc=0.3, s_res=1.0, s_aux=0.7), ref_lin)
+        close(ops.conv3x3(xc, wc, bc), ref_conv)
+        close(ops.tconv3(xt, wt, bt, B, F, HW), ref_t)
+        close(ops.linear_geglu(x, wp, bp, D), ref_g, tol=4e-3)
+    every_contraction_kernel(body)
