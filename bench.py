@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--loss", choices=["l1", "l1+ssim"], default="l1",
                     help="photometric loss of the raster iteration (SURVEY 8d defines the composite with L1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-trace", action="store_true",
+                    help="skip the HIP-event kernel timing (rocprofv3 --pmc passes: the counters serialise every launch)")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
 
@@ -252,7 +254,8 @@ def main():
     barrier()
     # start/stop events only on the kernels that can be the dominant one (a timed launch costs microseconds):
     # the contraction family and the spatial attention when the SVD unit is part of the step, else the blend kernels
-    with L.kernel_trace(only="k_gemm,k_attn_spatial" if loop_b is not None else "k_render") as tr:
+    only = "k_gemm,k_attn_spatial" if loop_b is not None else "k_render"
+    with L.kernel_trace(only="(none)" if args.no_kernel_trace else only) as tr:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
