@@ -88,14 +88,16 @@ class SvdStepBench:
         calls, ms = agg[best]
         flops = self.flops_per_unit[cand[best]] * units
         ach = flops / (ms / 1e3) / 1e12
+        traffic, source = _pmc_traffic(best)
         return dict(bound="mfma", kernel=best, achieved=round(ach, 1), peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / MFMA_F16_PEAK_TFLOPS, 4), traffic=_pmc_traffic(best), avg_ms=round(ms / calls, 4),
-                    calls=calls, algorithmic_flops_per_unit=self.flops_per_unit)
+                    frac=round(ach / MFMA_F16_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=source,
+                    avg_ms=round(ms / calls, 4), calls=calls, algorithmic_flops_per_unit=self.flops_per_unit)
 
 
 def _pmc_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*/traffic.json;
-    bench.py cannot run the profiler on itself).  None if no profile of this kernel is committed."""
+    """(HBM bytes per launch of `kernel`, where the number comes from) out of the committed rocprofv3 PMC passes
+    (profiles/*/traffic.json; bench.py cannot run the profiler on itself).  (None, None) if no profile of this
+    kernel is committed."""
     import json
     from pathlib import Path
     root = Path(__file__).resolve().parents[2] / "profiles"
@@ -105,6 +107,6 @@ def _pmc_traffic(kernel: str):
         except (OSError, ValueError):
             continue
         if rec:
-            return dict(hbm_bytes_per_launch=rec["hbm_bytes_per_launch"], source=str(f.relative_to(root.parent)),
-                        note="PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, averaged over the launches of the profiled run")
-    return None
+            return rec["hbm_bytes_per_launch"], (f"{f.relative_to(root.parent)}: PMC FETCH_SIZE x2 (gfx950 correction) + "
+                                                 "WRITE_SIZE, averaged over the launches of the profiled run")
+    return None, None
