@@ -412,7 +412,9 @@ extern "C" int syn3r_inverse_warp(const float* img, const float* depth, const fl
         p.bandwidth = bandwidth; p.H = H; p.W = W;
         const float* dp = depth_pseudo + b * n;
         int g = grid_for((int)n);
-        SYN3R_LAUNCH(k_iw_minmax, dim3(g), dim3(kBlock), 0, stream, p, depth, dp, mm + 4 * b);
+        // one same-address atomic pair per block serialises in L2 (~20 ns each): keep the reduction grid small
+        int g_mm = g > 128 ? 128 : g;
+        SYN3R_LAUNCH(k_iw_minmax, dim3(g_mm), dim3(kBlock), 0, stream, p, depth, dp, mm + 4 * b);
         SYN3R_LAUNCH(k_iw_main, dim3(g), dim3(kBlock), 0, stream, p, img, depth, dp, mm + 4 * b,
                            warped_img + 3 * b * n, warped_depth + b * n, mask_warp + b * n, mask_depth + b * n,
                            mask + b * n, warped_masked_img + 3 * b * n, mask_inv + b * n,
