@@ -152,18 +152,34 @@ __global__ void __launch_bounds__(ATHREADS, 2) k_attn_spatial(AttnParams p) {
         constexpr int cur = decltype(CUR)::value;
         if (t + 1 < ntiles) load_kv((t + 1) * BKV);
         // S^T = K . Q^T : two 32-key groups
+        // Fragment reads are issued in batches AHEAD of the MFMAs that consume them (hipcc otherwise emits
+        // read / wait / MFMA triples, exposing one LDS round trip per MFMA: ~1300 cycles per phase against 256 of
+        // matrix work): all eight K fragments before QK^T, and all eight V fragments before the softmax, whose
+        // VALU work then covers their latency.
         float16v st[2];
+        half8 kf[2][4];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[g][ks] = *(const half8*)(&Ks[cur][k_off(g * 32 + lq, ks * 2 + h)]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[g][r] = 0.f;
-            int key = g * 32 + lq;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                half8 kf = *(const half8*)(&Ks[cur][k_off(key, ks * 2 + h)]);
-                st[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st[g], 0, 0, 0);
-            }
-        }
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) st[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[g][ks], qf[ks], st[g], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        half8 vf[2][2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) vf[g][s][dt] = v_frag_tr(Vs[cur], g * 32 + s * 16 + 4 * h, dt * 32, lane);
+        __builtin_amdgcn_sched_barrier(0);
         const int kv0 = t * BKV;
         if (kv0 + BKV > p.S) {   // wave-uniform: mask keys beyond the sequence
 #pragma unroll
@@ -174,11 +190,16 @@ __global__ void __launch_bounds__(ATHREADS, 2) k_attn_spatial(AttnParams p) {
                     if (key >= p.S) st[g][r] = kNegBig;
                 }
         }
-        float mx = st[0][0];
+        // four independent max chains (then a 2-level combine) instead of one 32-long dependent chain: with three
+        // waves per SIMD the softmax phase is bound by VALU latency, not issue
+        float mq[4];
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int c = 0; c < 4; ++c) mq[c] = st[c >> 1][(c & 1) * 8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[g][r]);
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 1; r < 8; ++r) mq[c] = fmaxf(mq[c], st[c >> 1][(c & 1) * 8 + r]);
+        float mx = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
         {
             auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(mx), __float_as_int(mx), false, false);
             mx = fmaxf(__int_as_float(sw[0]), __int_as_float(sw[1]));
@@ -194,7 +215,7 @@ __global__ void __launch_bounds__(ATHREADS, 2) k_attn_spatial(AttnParams p) {
         }
         const float2v l2 = {kLog2e, kLog2e};
         const float2v mn = {-m_new * kLog2e, -m_new * kLog2e};
-        float2v ls2 = {0.f, 0.f};
+        float2v ls2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};      // independent partial sums
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -204,9 +225,12 @@ __global__ void __launch_bounds__(ATHREADS, 2) k_attn_spatial(AttnParams p) {
                 float2v e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
                 st[g][r] = e[0];
                 st[g][r + 1] = e[1];
-                ls2 += e;
+                ls2[(r >> 1) & 3] += e;
             }
-        l_run += ls2[0] + ls2[1];
+        {
+            const float2v t = (ls2[0] + ls2[1]) + (ls2[2] + ls2[3]);
+            l_run += t[0] + t[1];
+        }
         // O^T += V^T . P
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -214,10 +238,7 @@ __global__ void __launch_bounds__(ATHREADS, 2) k_attn_spatial(AttnParams p) {
             for (int s = 0; s < 2; ++s) {
                 half8 pf = pack8(st[g], s);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    half8 vf = v_frag_tr(Vs[cur], g * 32 + s * 16 + 4 * h, dt * 32, lane);
-                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[dt], 0, 0, 0);
-                }
+                for (int dt = 0; dt < 2; ++dt) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[g][s][dt], pf, ot[dt], 0, 0, 0);
             }
         if (t + 1 < ntiles) store_kv(cur ^ 1);
         __syncthreads();
