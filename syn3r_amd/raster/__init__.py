@@ -173,6 +173,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.save_for_backward(m3, sc, ro, op, sh, cf if cf is not None else torch.empty(0, device=dev), radii, geom,
                               binning, image)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)     # unused outputs (depth / alpha) arrive as None, not as zero tensors
         ctx.opacity_shape = opacities.shape
         return color, radii, depth, alpha
 
