@@ -141,13 +141,17 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
             float alpha = fminf(kAlphaMax, b.y * G);
             bool active = (contributor < last_contributor) && (power <= 0.0f) && (alpha >= kAlphaMin);
             if (__ballot(active) == 0ull) continue;   // wave-uniform
+            // Branch-free: a lane that does not take this splat blends it with alpha = 0 and G = 0, which is an exact
+            // no-op on its running state (T * rcp(1) = T, the colour recursion absorbs a zero-weight layer exactly)
+            // and makes every gradient term an exact zero - no EXEC-masked region, no zero-fill of v[].
+            const float a_eff = active ? alpha : 0.0f;
+            const float G_eff = active ? G : 0.0f;
             float v[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) v[k] = 0.0f;
-            if (active) {
-                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);   // 1 ulp reciprocal: one instruction, not a 10-op IEEE divide
+            v[10] = 0.0f; v[11] = 0.0f;
+            {
+                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - a_eff);   // 1 ulp reciprocal: one instruction, not a 10-op IEEE divide
                 T = T * inv1ma;
-                float wgt = alpha * T;
+                float wgt = a_eff * T;
                 // colour / depth recursion of the contribution behind this splat
                 acc_r = last_alpha * last_r + (1.0f - last_alpha) * acc_r;
                 acc_g = last_alpha * last_g + (1.0f - last_alpha) * acc_g;
@@ -156,11 +160,11 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
                 last_r = b.z; last_g = b.w; last_b = c.x; last_d = c.y;
                 float dL_da = (b.z - acc_r) * gr + (b.w - acc_g) * gg + (c.x - acc_b) * gb + (c.y - acc_d) * gD;
                 dL_da *= T;
-                last_alpha = alpha;
+                last_alpha = a_eff;
                 dL_da += (-T_final * inv1ma) * bg_dot;   // background term of the colour output
                 dL_da += (T_final * inv1ma) * gA;        // alpha output  A = 1 - T_final
                 float dL_dG = b.y * dL_da;
-                float gdx = G * dx, gdy = G * dy;
+                float gdx = G_eff * dx, gdy = G_eff * dy;
                 float dG_ddelx = -gdx * a.z - gdy * a.w;
                 float dG_ddely = -gdy * b.x - gdx * a.w;
                 v[G_R] = wgt * gr; v[G_G] = wgt * gg; v[G_B] = wgt * gb; v[G_DEPTH] = wgt * gD;
@@ -169,7 +173,7 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
                 v[G_CXX] = -0.5f * gdx * dx * dL_dG;
                 v[G_CXY] = -gdx * dy * dL_dG;
                 v[G_CYY] = -0.5f * gdy * dy * dL_dG;
-                v[G_OP] = G * dL_da;
+                v[G_OP] = G_eff * dL_da;
             }
             float s = reduce12(v, lane);
             const int slot = 3 * (lane >> 4) + (lane & 15);
