@@ -167,10 +167,14 @@ __global__ void __launch_bounds__(ATHREADS, 2) k_attn_spatial(AttnParams p) {
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[g][r] = 0.f;
+        // The QK^T MFMAs issue at raised priority: VALU arbitration between the waves of a SIMD is by priority, then
+        // age, and at equal priority the other waves' softmax VALU starves this wave's matrix issue (+5 %).
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int g = 0; g < 2; ++g) st[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[g][ks], qf[ks], st[g], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         half8 vf[2][2][2];
 #pragma unroll
@@ -240,6 +244,7 @@ __global__ void __launch_bounds__(ATHREADS, 2) k_attn_spatial(AttnParams p) {
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[g][s][dt], pf, ot[dt], 0, 0, 0);
             }
+        __builtin_amdgcn_s_setprio(0);
         if (t + 1 < ntiles) store_kv(cur ^ 1);
         __syncthreads();
     };
