@@ -84,13 +84,27 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
     const float fx = (float)px, fy = (float)py;
     const int lane = threadIdx.x & 63;
     const uint2 range = ranges[tile];
-    const int total = (int)(range.y - range.x);
-    const int rounds = (total + kTilePix - 1) / kTilePix;
     const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
 
     const float T_final = inside ? final_T[pix] : 0.0f;
     float T = T_final;
     const int last_contributor = inside ? (int)n_contrib[pix] : 0;
+    // The forward pass stops a tile once every pixel is saturated; the backward walks back from the LAST splat
+    // any pixel of the tile took (max of n_contrib), not from the end of the tile's list.
+    __shared__ int s_live;
+    int wave_live;                        // the same bound for this wavefront's quadrant alone
+    if (threadIdx.x == 0) s_live = 0;
+    __syncthreads();
+    {
+        int mc = last_contributor;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mc = max(mc, __shfl_xor(mc, o, 64));
+        if (lane == 0) atomicMax(&s_live, mc);
+        wave_live = mc;
+    }
+    __syncthreads();
+    const int total = min(s_live, (int)(range.y - range.x));
+    const int rounds = (total + kTilePix - 1) / kTilePix;
     const float sx0 = (float)(tx * kTileX + (wq & 1) * 8), sx1 = sx0 + 7.0f;
     const float sy0 = (float)(ty * kTileY + (wq >> 1) * 8), sy1 = sy0 + 7.0f;
     float gr = 0.f, gg = 0.f, gb = 0.f, gD = 0.f, gA = 0.f;
@@ -109,7 +123,7 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
         __syncthreads();
         int progress = rd * kTilePix + threadIdx.x;
         if (progress < total) {
-            unsigned gid = point_list[range.y - progress - 1];   // back to front
+            unsigned gid = point_list[range.x + total - 1 - progress];   // back to front
             const float4* src = (const float4*)(splats + gid);
             sm[threadIdx.x * 3 + 0] = src[0];
             sm[threadIdx.x * 3 + 1] = src[1];
@@ -127,7 +141,8 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
           bool hit = false;
           if (c0 + lane < cnt) {
               const float4 ta = sm[(c0 + lane) * 3], tb = sm[(c0 + lane) * 3 + 1];
-              hit = splat_reaches_rect(ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, sx0, sx1, sy0, sy1);
+              hit = splat_reaches_rect(ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, sx0, sx1, sy0, sy1) &&
+                    (total - 1 - (rd * kTilePix + c0 + lane)) < wave_live;
           }
           unsigned long long vm = __ballot(hit);
           while (vm) {
