@@ -172,6 +172,7 @@ __global__ void __launch_bounds__(256) k_preprocess(int N, int D, int M, const f
                                                     GeomState g) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
+    if (i < 4) g.header[i] = 0u;            // pair count (written by the scan that follows) and overflow flag
     radii[i] = 0;
     g.tiles_touched[i] = 0;
     g.dkeys_a[i] = 0xFFFFFFFFu;             // culled Gaussians sort behind every visible one
@@ -257,8 +258,10 @@ __global__ void __launch_bounds__(256) k_dup_tiles(int N, const unsigned* __rest
                                                    const float* __restrict__ means2D, const int* __restrict__ radii,
                                                    const unsigned* __restrict__ offsets, int gx, int gy,
                                                    unsigned* __restrict__ keys, unsigned* __restrict__ vals,
-                                                   unsigned cap, unsigned* __restrict__ header) {
+                                                   unsigned cap, unsigned* __restrict__ header,
+                                                   uint2* __restrict__ ranges, int tiles) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    for (int t = i; t < tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);   // k_tile_ranges fills the non-empty ones
     const int lane = threadIdx.x & 63;
     const bool valid = i < N;
     unsigned id = valid ? order[i] : 0u;
@@ -472,8 +475,7 @@ extern "C" int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, cons
     fill_camera(cam, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W);
     SYN3R_LAUNCH(k_preprocess, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
                        scales, rotations, opacities, shs, confidence, scale_modifier, cam, radii, g);
-    int rc = check_hip(hipMemsetAsync(g.header, 0, 16, stream), "memset header");
-    if (rc) return rc;
+    int rc = SYN3R_OK;
     // Gaussians by ascending depth (stable: equal depths keep index order), then the tile counts scanned in
     // that order: pairs emitted along it and stably sorted by tile id end up ordered exactly like the
     // published (tile << 32 | depth bits) key sort, for 8 B instead of 72 B of sort traffic per pair
@@ -514,8 +516,11 @@ extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const i
     BinningState bn = carve_binning(binning, P);
     const int gx = (W + kTileX - 1) / kTileX, gy = (H + kTileY - 1) / kTileY;
     const size_t tiles = (size_t)gx * gy;
-    int rc = check_hip(hipMemsetAsync(im.ranges, 0, tiles * 8, stream), "memset ranges");
-    if (rc) return rc;
+    int rc = SYN3R_OK;
+    if (P == 0) {
+        rc = check_hip(hipMemsetAsync(im.ranges, 0, tiles * 8, stream), "memset ranges");
+        if (rc) return rc;
+    }
     unsigned* point_list = bn.vals_a;
     if (P > 0) {
         // P is the pair CAPACITY of the binning buffer; the live count is read from the geometry header on
@@ -523,7 +528,7 @@ extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const i
         unsigned* tk_a = (unsigned*)bn.keys_a;
         unsigned* tk_b = (unsigned*)bn.keys_b;
         SYN3R_LAUNCH(k_dup_tiles, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, g.order, g.means2D, radii,
-                           g.point_offsets, gx, gy, tk_a, bn.vals_a, (unsigned)P, g.header);
+                           g.point_offsets, gx, gy, tk_a, bn.vals_a, (unsigned)P, g.header, im.ranges, (int)tiles);
         int in_b = 0;
         rc = sort_pairs_by_tile_u32(tk_a, bn.vals_a, tk_b, bn.vals_b, (size_t)P, bits_for((unsigned)tiles - 1),
                                     bn.sort_scratch, stream, &in_b, g.header);
