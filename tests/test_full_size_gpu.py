@@ -69,3 +69,29 @@ def test_unet_svd_xt_full_size_properties(gpu):
     for hh in (40, 48):
         yt = unet(x[:1, :, :, :hh, :72].contiguous(), torch.tensor(0.5), ehs[:1], added[:1])[0]
         assert yt.shape == (1, 14, 4, hh, 72) and torch.isfinite(yt).all()
+
+
+def test_vae_full_size_properties(gpu):
+    """The published SVD VAE configuration (97.7 M parameters, seeded weights) at the pipeline's 576x1024 size:
+    shapes, finiteness, bitwise repeatability of a repeated call (no atomics on this path), frame independence of
+    `decode` with num_frames = 1 and batch independence of the image encoder (to fp16 accuracy)."""
+    from syn3r_amd.vae import AutoencoderKLTemporalDecoder
+    vae = AutoencoderKLTemporalDecoder(block_out_channels=(128, 256, 512, 512), down_block_types=("DownEncoderBlock2D",) * 4,
+                                       layers_per_block=2, sample_size=768).init_random(gpu, seed=1)
+    g = torch.Generator(device=gpu).manual_seed(0)
+    img = torch.rand(2, 3, 576, 1024, generator=g, device=gpu) * 2 - 1
+    m = vae.encode(img).latent_dist.parameters
+    assert m.shape == (2, 8, 72, 128) and torch.isfinite(m).all()
+    assert torch.equal(m, vae.encode(img).latent_dist.parameters)
+    # images are encoded independently; a different batch size may select other contraction kernels (other
+    # fp32 summation order, then fp16 rounding through ~30 layers), so this is equality to fp16 accuracy
+    def near(a, b):
+        return float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())
+    assert near(m[1:], vae.encode(img[1:]).latent_dist.parameters)
+    z = torch.randn(3, 4, 72, 128, generator=g, device=gpu)
+    y = vae.decode(z, num_frames=3).sample
+    assert y.shape == (3, 3, 576, 1024) and torch.isfinite(y).all()
+    assert torch.equal(y, vae.decode(z, num_frames=3).sample)
+    y1 = vae.decode(z, num_frames=1).sample                                           # every latent its own 1-frame video
+    assert near(y1[:1], vae.decode(z[:1], num_frames=1).sample)
+    assert not near(y1, y)                                                            # the temporal layers do mix frames
