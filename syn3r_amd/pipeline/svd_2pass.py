@@ -154,13 +154,19 @@ class StableVideoDiffusionPipeline:
         x = torch.cat([x, image_latents], dim=2)
         h, w = latents.shape[-2:]
         tiles, ov_y, ov_x = post_tiles(h, w)
-        grads = []
-        for ys, xs in tiles:                                           # :726-774, B=1, no CFG
-            sl = (slice(0, 1), slice(None), slice(None), ys, xs)
-            noise_t = self._unet(x[sl].contiguous(), t, ehs[0:1], added[0:1])
-            out = sch.step_interp(noise_t, t, latents[sl].contiguous(), cond[(slice(0, 2),) + sl[1:]].contiguous(),
-                                  mask[sl].contiguous(), lam, step_i=i, lr=0.02, compute_grad=True)
-            grads.append(out.grad)
+        # :726-774 — four B = 1 forwards of the unconditional half in the reference.  Tiles 0/2 and 1/3 have equal
+        # shapes and share the same (unconditional) context and time ids, so each pair runs as ONE batch-of-2 forward:
+        # identical per-sample arithmetic (GroupNorm and attention are per sample; the reference's batch-interleaved
+        # temporal context is the same vector for both), larger contractions.
+        grads = [None] * 4
+        for pair in ((0, 2), (1, 3)):
+            sls = [(slice(0, 1), slice(None), slice(None)) + tiles[k] for k in pair]
+            xb = torch.cat([x[sl] for sl in sls], dim=0).contiguous()
+            noise = self._unet(xb, t, ehs[0:1].expand(2, -1, -1), added[0:1].expand(2, -1).contiguous())   # stride-0 context
+            for n, (k, sl) in enumerate(zip(pair, sls)):
+                out = sch.step_interp(noise[n:n + 1], t, latents[sl].contiguous(), cond[(slice(0, 2),) + sl[1:]].contiguous(),
+                                      mask[sl].contiguous(), lam, step_i=i, lr=0.02, compute_grad=True)
+                grads[k] = out.grad
         g1 = torch.cat((grads[0], grads[1][:, :, :, ov_y:, :]), -2)     # :776-778
         g2 = torch.cat((grads[2], grads[3][:, :, :, ov_y:, :]), -2)
         g3 = torch.cat((g1, g2[:, :, :, :, ov_x:]), -1)

@@ -369,7 +369,7 @@ class UNetSpatioTemporalConditionModel:
         n1 = ops.layernorm(hs, W(b + ".norm1.weight"), W(b + ".norm1.bias"))
         a1 = ops.attention(ops.linear(n1, W(b + ".attn1.qkv")), B * F, HW, heads)
         hs = ops.linear(a1, W(b + ".attn1.to_out.0.weight"), W(b + ".attn1.to_out.0.bias"), residual=hs,
-                        rowvec=self._cross_vec(b + ".attn2", ehs), rows_per_vec=F * HW)
+                        rowvec=self._cross_vec(b + ".attn2", ehs), rows_per_vec=(B if st["shared_ctx"] else 1) * F * HW)
         n3 = ops.layernorm(hs, W(b + ".norm3.weight"), W(b + ".norm3.bias"))
         hs = self._ff(b + ".ff", n3, residual=hs)
         # TemporalBasicTransformerBlock (attention.py:478-533) on hs + emb
@@ -382,10 +382,12 @@ class UNetSpatioTemporalConditionModel:
         # The reference lays the first-frame context out pixel-major / batch-minor
         # (transformer_temporal.py:310-317) while the temporal tokens are batch-major (attention.py:487-489):
         # token (b, pixel) reads the context of batch item (b*HW + pixel) mod B.  Reproduced, not fixed.
-        if HW % B:
-            raise NotImplementedError("temporal cross-attention context interleave needs h*w divisible by the batch size")
+        # With ONE context shared by every batch item (B = 1, or a stride-0 expanded context) the interleave is moot.
+        if HW % B and not st["shared_ctx"]:
+            raise NotImplementedError("temporal cross-attention context interleave needs h*w divisible by the batch "
+                                      "size (or one context shared by the batch: pass it expanded, stride 0)")
         tt = ops.linear(a1, W(t + ".attn1.to_out.0.weight"), W(t + ".attn1.to_out.0.bias"), residual=tt,
-                        rowvec=self._cross_vec(t + ".attn2", ehs), rows_per_vec=-B)
+                        rowvec=self._cross_vec(t + ".attn2", ehs), rows_per_vec=B * F * HW if st["shared_ctx"] else -B)
         n3 = ops.layernorm(tt, W(t + ".norm3.weight"), W(t + ".norm3.bias"))
         a, om = self._blend_scales(pre + ".time_mixer.mix_factor")
         # alpha*hs + (1-alpha)*(ff + tt)
@@ -418,8 +420,12 @@ class UNetSpatioTemporalConditionModel:
         aug = ops.linear(te, W("add_embedding.linear_1.weight"), W("add_embedding.linear_1.bias"))
         aug = ops.linear(Fn.silu(aug), W("add_embedding.linear_2.weight"), W("add_embedding.linear_2.bias"))
         emb = emb + aug
-        st = dict(B=B, F=F, h=h, w=w_, temb_act=Fn.silu(emb).contiguous(),
-                  ehs=encoder_hidden_states.reshape(B, -1).to(H).contiguous())
+        # one context for the whole batch (a stride-0 `expand` of a single embedding, as the guidance tiles pass it):
+        # the folded cross-attention vector is computed once and added to every row
+        shared_ctx = B == 1 or encoder_hidden_states.stride(0) == 0
+        ctx = encoder_hidden_states[:1] if shared_ctx else encoder_hidden_states
+        st = dict(B=B, F=F, h=h, w=w_, temb_act=Fn.silu(emb).contiguous(), shared_ctx=shared_ctx,
+                  ehs=ctx.reshape(ctx.shape[0], -1).to(H).contiguous())
         # 2. conv_in on NHWC with channels padded to 64 (:428)
         x = sample.to(H).flatten(0, 1).permute(0, 2, 3, 1)
         x = Fn.pad(x, (0, 64 - Cin % 64 if Cin % 64 else 0)).contiguous()

@@ -96,3 +96,25 @@ def test_forward_is_deterministic_and_context_interleave(gpu):
     e_same = e[1:].repeat(2, 1, 1)
     y_same = model(s, t, e_same, a)[0]
     assert torch.allclose(y_single.float(), y_same[1:].float(), atol=2e-3, rtol=1e-2)
+
+
+@pytest.mark.gpu
+def test_shared_context_batch_equals_single_items(gpu):
+    """The guidance tiles of the Post pipeline run as batch-of-2 forwards with ONE (stride-0 expanded) context:
+    every item must come out as its own B = 1 forward does — also where h*w is odd at the coarsest level (5x9),
+    which the batch-interleaved context path cannot serve."""
+    from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel
+    model = UNetSpatioTemporalConditionModel(**UW.SMALL_CONFIG)
+    model.load_state_dict(UW.make_state_dict(model.parameter_shapes()), gpu)
+    sample, t, ehs, added = UW.make_inputs(2, 5, 40, 72, seed=9)
+    x = sample.to(gpu).half()
+    e1 = ehs[:1].to(gpu).half()
+    a1 = added[:1].to(gpu)
+    both = model(x, t, e1.expand(2, -1, -1), a1.expand(2, -1).contiguous())[0]
+    for n in range(2):
+        one = model(x[n:n + 1].contiguous(), t, e1, a1)[0]
+        err = (both[n:n + 1].float() - one.float()).abs()
+        scale = float(one.float().abs().max())
+        assert float(err.max()) < 2e-2 * scale and float(err.mean()) < 2e-3 * scale, (float(err.max()), scale)
+    with pytest.raises(NotImplementedError):        # two DIFFERENT contexts need the interleave, which needs even h*w
+        model(x, t, ehs.to(gpu).half(), added.to(gpu))
