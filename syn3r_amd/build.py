@@ -56,10 +56,16 @@ def build(verbose: bool = False, force: bool = False) -> Path:
     if not sources:
         raise RuntimeError(f"no sources under {CSRC}")
 
+    extra = os.environ.get("SYN3R_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DSYN3R_TIMING (developer builds)
+    stamp = OBJ / "flags.txt"                                        # objects of another flag set are stale
+    if (stamp.read_text() if stamp.exists() else "") != " ".join(extra):
+        force = True
+    stamp.write_text(" ".join(extra))
+
     def compile_one(src: Path) -> Path:
         obj = OBJ / (src.stem + ".o")
         if force or _newer(src, obj, headers):
-            flags = list(COMMON_FLAGS)
+            flags = list(COMMON_FLAGS) + extra
             if src.name in STRICT_FP:
                 flags.append("-ffp-contract=off")
             cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]

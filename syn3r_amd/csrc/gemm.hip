@@ -587,6 +587,10 @@ constexpr int W_A_BYTES = WBM * BK * 2;                      // 32,768
 constexpr int W_B_BYTES = WBN * BK * 2;                      // 40,960
 constexpr int W_STAGE = W_A_BYTES + W_B_BYTES;               // 73,728
 
+#ifdef SYN3R_TIMING
+__device__ unsigned long long g_wide_timing[64];
+#endif
+
 template <int MODE>
 __global__ void __launch_bounds__(512, 2) k_gemm_wide(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -690,12 +694,22 @@ __global__ void __launch_bounds__(512, 2) k_gemm_wide(GemmParams p) {
     const unsigned b_row = (unsigned)(W_A_BYTES + (wn * 160 + fr) * 128);
     const unsigned swz[2] = {(unsigned)(((0 + fq) ^ (fr & 7)) << 4), (unsigned)(((4 + fq) ^ (fr & 7)) << 4)};
 
+    // -DSYN3R_TIMING (tools/wide_timing.py): per-wavefront s_memtime sums of the loop's segments for one block
+#ifdef SYN3R_TIMING
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define TMARK(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsum[i] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define TMARK(i)
+#endif
     issue_stage(0);
     int buf = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage kt (the only one in flight) has landed
+        TMARK(0);
         __builtin_amdgcn_s_barrier();
+        TMARK(1);
         if (kt + 1 < nkt) issue_stage(buf ^ 1);              // the slot every wavefront finished reading in iteration kt-1
+        TMARK(2);
         const unsigned sb = lds0 + (unsigned)buf * W_STAGE;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
@@ -708,15 +722,22 @@ __global__ void __launch_bounds__(512, 2) k_gemm_wide(GemmParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]),
                            "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7]), "+v"(bf[8]), "+v"(bf[9]));
+            TMARK(3 + 2 * kh);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < WTN; ++j)
                     acc[j / TN][i][j % TN] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[j / TN][i][j % TN], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);   // the next half's reads reuse af / bf: keep them behind these MFMAs
+            TMARK(4 + 2 * kh);
         }
         buf ^= 1;
     }
+#ifdef SYN3R_TIMING
+    if (blockIdx.x == gridDim.x / 2 && lane == 0)
+        for (int i = 0; i < 8; ++i) g_wide_timing[wv * 8 + i] = tsum[i];
+#endif
+#undef TMARK
     __syncthreads();   // every wavefront is done reading the ring before the epilogue reuses it
 
     if (p.geglu_D > 0) {
@@ -1003,3 +1024,10 @@ extern "C" int syn3r_tconv3_f16(const void* X, const void* W, void* out, long lo
     if (rc) return rc;
     return launch<MODE_TCONV>(p, (hipStream_t)stream);
 }
+
+#ifdef SYN3R_TIMING
+// developer hook (tools/wide_timing.py): the segment sums the last k_gemm_wide launch left behind
+extern "C" __attribute__((visibility("default"))) int syn3r_debug_wide_timing(unsigned long long* out64) {
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_wide_timing), sizeof(unsigned long long) * 64);
+}
+#endif

@@ -1,0 +1,43 @@
+"""Time single contraction shapes in isolation, cold (20 launches) and sustained (1 s of launches), optionally from
+another build of the library (developer tool):  python tools/gemm_iso.py [lib.so|-] [ENV=VAL ...]"""
+import os, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+for kv in sys.argv[2:]:
+    k, v = kv.split("=", 1)
+    os.environ[k] = v
+from syn3r_amd import _lib
+if len(sys.argv) > 1 and sys.argv[1] != "-":
+    _lib._LIB_PATH = Path(sys.argv[1]).resolve()
+import torch
+from syn3r_amd.unet import ops
+dev = torch.device("cuda", 0)
+H = torch.float16
+SHAPES = [(16128, 1280, 5120), (64512, 640, 2560), (64512, 5120, 640), (258048, 2560, 320), (258048, 960, 320), (16128, 10240, 1280)]
+
+
+def timed(f, n):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+for M, N, K in SHAPES:
+    x = torch.randn(M, K, device=dev).to(H)
+    w = (torch.randn(N, K, device=dev) * 0.02).to(H)
+    f = lambda: ops.linear(x, w)
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    cold = timed(f, 20)
+    n = max(20, int(1000 / cold))
+    timed(f, n)
+    hot = timed(f, n // 2)
+    fl = 2 * M * N * K / 1e9
+    print(f"M{M} N{N} K{K}: cold {cold * 1e3:7.1f} us {fl / cold:6.0f} TF | sustained {hot * 1e3:7.1f} us {fl / hot:6.0f} TF")
+    del x, w

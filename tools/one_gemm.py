@@ -15,6 +15,10 @@ elif kind == "lin":
     x = torch.randn(258048, 320, device=dev).to(H)
     w = (torch.randn(2560, 320, device=dev) * 0.05).to(H)
     f = lambda: ops.linear(x, w)
+elif kind == "big":      # long-K projection on the wide tile
+    x = torch.randn(16128, 5120, device=dev).to(H)
+    w = (torch.randn(1280, 5120, device=dev) * 0.02).to(H)
+    f = lambda: ops.linear(x, w)
 elif kind == "attn":
     qkv = torch.randn(28 * 2304, 1920, device=dev).to(H)
     f = lambda: ops.attention(qkv, 28, 2304, 10)
