@@ -103,6 +103,29 @@ int syn3r_reproj_error(const float* depth1, const float* depth2, const float* T1
                        void* stream);
 
 /*
+ * Orchestrator post-processing of a batch of inverse warps, on the device.
+ * Replaces the per-frame host code of `warp_images_bw` (model/diffusionGS.py:1447-1483): binary mask
+ * 1 - mask_reproj >= 0.5, cv2.dilate 5x5 (default border), cond = uint8(warped * (1 - ero)) / 255 (the uint8
+ * round trip of :1469,1475), the (h, H/h, w, W/w) block-mean pooling of the hard mask (threshold 0.2) and of
+ * the soft reprojection uncertainty 1 - soft_mask_reproj.
+ *   mask_reproj [n,H,W] u8, warped_img [n,3,H,W] f32 (0..255), soft_mask_reproj [n,H,W] f32 (outputs of
+ *   syn3r_inverse_warp) -> ero [n,H,W] u8 (0/1), cond_image, cond_ori [n,H,W,3] f32, soft [n,H,W] f32,
+ *   masks, soft_pool [n,h,w] f32.  H % h == 0, W % w == 0.
+ */
+int syn3r_warp_post(const uint8_t* mask_reproj, const float* warped_img, const float* soft_mask_reproj,
+                    int n, int H, int W, int h, int w, uint8_t* ero, float* cond_image, float* cond_ori,
+                    float* soft, float* masks, float* soft_pool, void* stream);
+
+/*
+ * Uncertainty fusion + condition-image selection (model/diffusionGS.py:821-862):
+ *   conf = exp(-(|cond_ori - gs|_2 / 0.5)^3) * (sum_c cond_ori > 0);  u = 1 - conf * (1 - soft);
+ *   cond_image = clip(u > 0.5 ? gs : cond_ori, 0, 1);  masks = block mean of u.
+ *   cond_ori, gs_images [n,H,W,3] f32, soft [n,H,W] f32 -> uncertainty [n,H,W], cond_image [n,H,W,3], masks [n,h,w].
+ */
+int syn3r_fuse_uncertainty(const float* cond_ori, const float* gs_images, const float* soft, int n, int H, int W,
+                           int h, int w, float* uncertainty, float* cond_image, float* masks, void* stream);
+
+/*
  * forward_warp: depth-weighted bilinear splat.
  * Replaces solver_utils/forward_warp.py:141-182 (forward_warp),
  * :7-38 (compute_transformed_points) and :42-127 (bilinear_splatting).

@@ -33,6 +33,8 @@ SIGNATURES = {
     "syn3r_inverse_warp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i,
                                  c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "syn3r_reproj_error": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "syn3r_warp_post": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "syn3r_fuse_uncertainty": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "syn3r_forward_warp_workspace_bytes": (c_sz, [c_i, c_i]),
     "syn3r_forward_warp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "syn3r_step_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),

@@ -370,6 +370,107 @@ inline int grid_for(int n) {
 void load3(Mat3f& d, const float* s) { for (int i = 0; i < 9; ++i) d.m[i] = s[i]; }
 void load4(Mat4f& d, const float* s) { for (int i = 0; i < 16; ++i) d.m[i] = s[i]; }
 
+
+// ------------------------------------------------------------------------------------------------
+// Orchestrator post-processing on the device (diffusionGS.py:1447-1483, 821-862): what
+// `warp_images_bw` and the uncertainty fusion do per frame with numpy / cv2 on the host, for all frames at once.
+
+// per pixel: hard mask = 5x5 dilate of (1 - mask_reproj >= 0.5) (cv2.dilate, default border: the window's
+// in-image part), cond = uint8(warped * (1 - ero)) / 255 (the reference's uint8 round trip), cond_ori = warped / 255,
+// soft = 1 - soft_mask_reproj
+__global__ void k_warp_post(const uint8_t* __restrict__ mask_reproj, const float* __restrict__ warped,
+                            const float* __restrict__ soft_in, int H, int W, uint8_t* __restrict__ ero,
+                            float* __restrict__ cond, float* __restrict__ cond_ori, float* __restrict__ soft) {
+    __shared__ uint8_t tile[20][20];
+    const int f = blockIdx.z, x0 = blockIdx.x * 16, y0 = blockIdx.y * 16;
+    const long long plane = (long long)H * W;
+    const uint8_t* mr = mask_reproj + f * plane;
+    for (int i = threadIdx.x; i < 400; i += 256) {
+        int ty = i / 20, tx = i - ty * 20, y = y0 + ty - 2, x = x0 + tx - 2;
+        tile[ty][tx] = (y >= 0 && y < H && x >= 0 && x < W) ? (uint8_t)(mr[(long long)y * W + x] == 0) : (uint8_t)0;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, x = x0 + tx, y = y0 + ty;
+    if (x >= W || y >= H) return;
+    unsigned m = 0;
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) m |= tile[ty + dy][tx + dx];
+    const long long pix = (long long)y * W + x;
+    ero[f * plane + pix] = (uint8_t)m;
+    const float keep = m ? 0.0f : 1.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = warped[((long long)f * 3 + c) * plane + pix];
+        cond_ori[(f * plane + pix) * 3 + c] = v / 255.0f;
+        float t = v * keep;                                   // np.uint8(): truncation (values are 0..255)
+        t = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);
+        cond[(f * plane + pix) * 3 + c] = (float)(unsigned)t / 255.0f;
+    }
+    soft[f * plane + pix] = 1.0f - soft_in[f * plane + pix];
+}
+
+// numpy's float32 mean over a contiguous run of fy*fx values (pairwise sum: 8 running sums below 128 elements)
+__device__ __forceinline__ float np_block_mean(const float* __restrict__ src, int W, int fy, int fx) {
+    const int n = fy * fx;
+    float r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float res;
+    if (n >= 8 && n <= 128) {
+        int i = 0;
+        for (int k = 0; k < 8; ++k) r[k] = src[(long long)(k / fx) * W + k % fx];
+        for (i = 8; i + 8 <= n; i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += src[(long long)((i + k) / fx) * W + (i + k) % fx];
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += src[(long long)(i / fx) * W + i % fx];
+    } else {
+        res = 0.f;
+        for (int i = 0; i < n; ++i) res += src[(long long)(i / fx) * W + i % fx];
+    }
+    return res / (float)n;
+}
+
+// per (h, w) cell of fy x fx pixels: mask = mean(ero) >= 0.2, soft_pool = mean(soft)
+__global__ void k_warp_pool(const uint8_t* __restrict__ ero, const float* __restrict__ soft, int H, int W, int h, int w,
+                            long long cells, float* __restrict__ masks, float* __restrict__ soft_pool) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    const int fy = H / h, fx = W / w;
+    const int cx = (int)(i % w), cy = (int)((i / w) % h);
+    const long long f = i / ((long long)w * h);
+    const long long base = f * H * W + (long long)cy * fy * W + (long long)cx * fx;
+    if (ero) {
+        int cnt = 0;
+        for (int dy = 0; dy < fy; ++dy)
+            for (int dx = 0; dx < fx; ++dx) cnt += ero[base + (long long)dy * W + dx];
+        masks[i] = (double)cnt / (double)(fy * fx) >= 0.2 ? 1.0f : 0.0f;
+    }
+    if (soft) soft_pool[i] = np_block_mean(soft + base, W, fy, fx);
+}
+
+// diffusionGS.py:821-862: intensity confidence exp(-(|warp - gs|_2 / 0.5)^3) * (warp != 0), uncertainty
+// u = 1 - conf * (1 - soft), cond = clip(u > 0.5 ? gs : warp, 0, 1)
+__global__ void k_fuse_uncertainty(const float* __restrict__ cond_ori, const float* __restrict__ gs,
+                                   const float* __restrict__ soft, long long npix, float* __restrict__ unc,
+                                   float* __restrict__ cond) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const float a0 = cond_ori[i * 3], a1 = cond_ori[i * 3 + 1], a2 = cond_ori[i * 3 + 2];
+    const float g0 = gs[i * 3], g1 = gs[i * 3 + 1], g2 = gs[i * 3 + 2];
+    const float known = (a0 + a1) + a2 > 0.0f ? 1.0f : 0.0f;
+    const float d0 = a0 - g0, d1 = a1 - g1, d2 = a2 - g2;
+    const float nrm = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+    const float q = nrm / 0.5f;
+    const float conf = expf(-(q * q * q)) * known;
+    const float u = 1.0f - conf * (1.0f - soft[i]);
+    unc[i] = u;
+    const bool use_gs = u > 0.5f;
+    const float c0 = use_gs ? g0 : a0, c1 = use_gs ? g1 : a1, c2 = use_gs ? g2 : a2;
+    cond[i * 3] = fminf(fmaxf(c0, 0.f), 1.f);
+    cond[i * 3 + 1] = fminf(fmaxf(c1, 0.f), 1.f);
+    cond[i * 3 + 2] = fminf(fmaxf(c2, 0.f), 1.f);
+}
+
 }  // namespace
 
 extern "C" size_t syn3r_inverse_warp_workspace_bytes(int nb) { return (size_t)(nb > 0 ? nb : 1) * 16; }
@@ -471,5 +572,40 @@ extern "C" int syn3r_forward_warp(const double* frame1, const uint8_t* mask1, co
     SYN3R_LAUNCH(k_fw_splat, dim3(g), dim3(kBlock), 0, stream, p, frame1, mask1, depth1, maxbits, acc, flow12);
     SYN3R_LAUNCH(k_fw_finish, dim3(g), dim3(kBlock), 0, stream, H, W, acc, warped, mask2);
     SYN3R_LAUNCH_CHECK("forward_warp launch");
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_warp_post(const uint8_t* mask_reproj, const float* warped_img, const float* soft_mask_reproj,
+                               int n, int H, int W, int h, int w, uint8_t* ero, float* cond_image, float* cond_ori,
+                               float* soft, float* masks, float* soft_pool, void* stream_) {
+    SYN3R_REQUIRE(mask_reproj && warped_img && soft_mask_reproj && ero && cond_image && cond_ori && soft && masks && soft_pool,
+                  "warp_post: null argument");
+    SYN3R_REQUIRE(n > 0 && H > 0 && W > 0 && h > 0 && w > 0 && H % h == 0 && W % w == 0,
+                  "warp_post: bad shape n=%d H=%d W=%d pooled %dx%d", n, H, W, h, w);
+    SYN3R_REQUIRE(n <= 65535, "warp_post: too many frames");
+    hipStream_t stream = (hipStream_t)stream_;
+    SYN3R_LAUNCH(k_warp_post, dim3((W + 15) / 16, (H + 15) / 16, n), dim3(256), 0, stream, mask_reproj, warped_img,
+                 soft_mask_reproj, H, W, ero, cond_image, cond_ori, soft);
+    const long long cells = (long long)n * h * w;
+    SYN3R_LAUNCH(k_warp_pool, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)ero,
+                 (const float*)soft, H, W, h, w, cells, masks, soft_pool);
+    SYN3R_LAUNCH_CHECK("warp_post launch");
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_fuse_uncertainty(const float* cond_ori, const float* gs_images, const float* soft, int n, int H,
+                                      int W, int h, int w, float* uncertainty, float* cond_image, float* masks,
+                                      void* stream_) {
+    SYN3R_REQUIRE(cond_ori && gs_images && soft && uncertainty && cond_image && masks, "fuse_uncertainty: null argument");
+    SYN3R_REQUIRE(n > 0 && H > 0 && W > 0 && h > 0 && w > 0 && H % h == 0 && W % w == 0,
+                  "fuse_uncertainty: bad shape n=%d H=%d W=%d pooled %dx%d", n, H, W, h, w);
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long npix = (long long)n * H * W;
+    SYN3R_LAUNCH(k_fuse_uncertainty, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, cond_ori, gs_images,
+                 soft, npix, uncertainty, cond_image);
+    const long long cells = (long long)n * h * w;
+    SYN3R_LAUNCH(k_warp_pool, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)nullptr,
+                 (const float*)uncertainty, H, W, h, w, cells, (float*)nullptr, masks);
+    SYN3R_LAUNCH_CHECK("fuse_uncertainty launch");
     return SYN3R_OK;
 }

@@ -148,13 +148,19 @@ class DiffusionGS:
         if self.interp_type != "backward_warp":
             raise NotImplementedError("only --interp_type backward_warp (used by every shipped script) is implemented")
         rs = lambda x: _resize_nearest(x, Hd, Wd)
-        image_o, image_o2, masks, cond_image, aux = O.warp_images_bw(
+        # warps, mask post-processing and the uncertainty fusion stay on the device: one
+        # batched warp per end view + two post-processing launches; the condition images go to the pipeline as
+        # device tensors
+        wd = O.warp_images_bw_device(
             self.diffusion_intrinsics, interpolated_poses, rs(image1), rs(image2), rs(depth1), rs(depth2),
             render_depth=lambda p: _resize_nearest(self.render_GS(pose=p)[2], Hd, Wd), device=self.device,
             h=Hd // 8, w=Wd // 8)
+        image_o, image_o2 = rs(image1) / 255.0, rs(image2) / 255.0
         gs_images = np.stack(pseudo_images[1:-1])
-        masks, cond_image, _ = O.fuse_uncertainty(np.stack(aux["cond_images_ori"]), gs_images,
-                                                  aux["soft_masks_reproj_ori"], h=Hd // 8, w=Wd // 8)
+        masks, cond_dev, _ = O.fuse_uncertainty_device(wd["cond_images_ori"], gs_images, wd["soft_masks_reproj_ori"],
+                                                       h=Hd // 8, w=Wd // 8)
+        masks = masks.cpu()
+        cond_image = list(cond_dev.permute(0, 3, 1, 2))               # CHW in [0,1], as preprocess_images accepts
         lambda_ts = O.search_hypers_v2(masks, None, type="double_end", diffusion_steps=self.num_inference_steps)
         frames = self.svd_render(image_o, image_o2, masks, cond_image, None, lambda_ts, num_frames=len(interpolated_poses))
         if replace:

@@ -17,7 +17,8 @@ from scipy.optimize import minimize_scalar
 from scipy.spatial.transform import Rotation as R
 from scipy.spatial.transform import Slerp
 
-from .solver_utils.forward_warp import inverse_warp
+from . import _lib as L
+from .solver_utils.forward_warp import inverse_warp, inverse_warp_batch
 
 
 def pose_interpolation(pose_start: np.ndarray, pose_end: np.ndarray, num: int = 25) -> np.ndarray:
@@ -109,46 +110,81 @@ def fuse_uncertainty(cond_images_ori: np.ndarray, gs_images: np.ndarray, soft_ma
     return torch.from_numpy(masks).float(), cond_image, geo_inten_uncertainty
 
 
+def warp_images_bw_device(intrinsics: np.ndarray, interpolated_poses: Sequence[np.ndarray], image_l: np.ndarray,
+                          image_r: np.ndarray, depth_l: np.ndarray, depth_r: np.ndarray,
+                          render_depth: Callable[[np.ndarray], np.ndarray], device="cuda:0", h: int = 72, w: int = 128):
+    """diffusionGS.py:1367-1510 on the device: the interior poses' pseudo-view depths are
+    rendered (`render_depth(pose) -> (H,W)` array or tensor = the reference's `render_GS`), the nearer end view is
+    inverse-warped into each of them (bandwidth 20) in ONE `syn3r_inverse_warp` call per end view, and
+    `syn3r_warp_post` derives, for all frames at once, the hard mask (5x5 dilate, (h,H/h,w,W/w) pooling, threshold
+    0.2), the masked uint8-rounded condition images and the soft reprojection uncertainty.  Images are (H,W,3)
+    in [0,255], already at the diffusion resolution.  Returns device tensors:
+    masks [n,h,w], cond_image [n,H,W,3], masks_ero [n,H,W] u8, soft_masks_reproj [n,h,w],
+    soft_masks_reproj_ori [n,H,W], cond_images_ori [n,H,W,3]."""
+    dev = torch.device(device)
+    n_pose = len(interpolated_poses)
+    interp_num = n_pose - 2
+    K = torch.tensor(np.asarray(intrinsics), dtype=torch.float32)
+    f32 = lambda a: torch.as_tensor(np.asarray(a) if not isinstance(a, torch.Tensor) else a, dtype=torch.float32).to(dev)
+    depth_t = torch.stack([f32(render_depth(interpolated_poses[i + 1])) for i in range(interp_num)])
+    H, W = depth_t.shape[-2:]
+    groups = (("l", image_l, depth_l, interpolated_poses[0], range(0, min(12, interp_num))),       # :1411-1420
+              ("r", image_r, depth_r, interpolated_poses[-1], range(min(12, interp_num), interp_num)))
+    parts = []
+    for _, img, dep, pose_s, idx in groups:
+        if len(idx) == 0:
+            continue
+        out = inverse_warp_batch(f32(img).permute(2, 0, 1).contiguous(), f32(dep).reshape(1, H, W),
+                                 depth_t[idx.start:idx.stop], torch.as_tensor(np.asarray(pose_s), dtype=torch.float32),
+                                 torch.as_tensor(np.stack([interpolated_poses[i + 1] for i in idx]), dtype=torch.float32), K)
+        parts.append(out)
+    cat = lambda k: torch.cat([p[k] for p in parts]).contiguous()
+    mask_reproj, warped, soft_in = cat("mask_reproj"), cat("warped_img"), cat("soft_mask_reproj")
+    n = interp_num
+    new = lambda shape, dt=torch.float32: torch.empty(shape, dtype=dt, device=dev)
+    res = dict(masks=new((n, h, w)), cond_image=new((n, H, W, 3)), masks_ero=new((n, H, W), torch.uint8),
+               soft_masks_reproj=new((n, h, w)), soft_masks_reproj_ori=new((n, H, W)), cond_images_ori=new((n, H, W, 3)))
+    rc = L.load().syn3r_warp_post(L.ptr(mask_reproj), L.ptr(warped), L.ptr(soft_in), n, H, W, h, w, L.ptr(res["masks_ero"]),
+                                  L.ptr(res["cond_image"]), L.ptr(res["cond_images_ori"]), L.ptr(res["soft_masks_reproj_ori"]),
+                                  L.ptr(res["masks"]), L.ptr(res["soft_masks_reproj"]), L.stream_ptr(dev))
+    L.check(rc, "syn3r_warp_post")
+    return res
+
+
 def warp_images_bw(intrinsics: np.ndarray, interpolated_poses: Sequence[np.ndarray], image_l: np.ndarray,
                    image_r: np.ndarray, depth_l: np.ndarray, depth_r: np.ndarray,
                    render_depth: Callable[[np.ndarray], np.ndarray], device="cuda:0", h: int = 72, w: int = 128):
-    """diffusionGS.py:1367-1510 without the PNG round trips: for every interior pose render the pseudo-view
-    depth (`render_depth(pose) -> (H,W)` = the reference's `render_GS`), inverse-warp the nearer end view into
-    it on the GPU (bandwidth 20) and derive the hard mask (5x5 dilate, 8x8 pool, threshold 0.2) and the soft
-    reprojection uncertainty.  Images are (H,W,3) in [0,255], already at the diffusion resolution."""
-    dev = torch.device(device)
-    n = len(interpolated_poses) - 1
-    interp_num = n - 1
-    K = torch.tensor(intrinsics, device=dev, dtype=torch.float32)
-    src = {side: (torch.tensor(img, device=dev, dtype=torch.float32).permute(2, 0, 1).contiguous(),
-                  torch.tensor(dep[None], device=dev, dtype=torch.float32))
-           for side, img, dep in (("l", image_l, depth_l), ("r", image_r, depth_r))}
-    masks, cond_image, masks_ero, soft_pool, soft_ori, cond_ori = [], [], [], [], [], []
-    for i in range(interp_num):
-        side = "l" if i < 12 else "r"                                   # :1411-1420
-        pose_s = interpolated_poses[0] if side == "l" else interpolated_poses[-1]
-        pose_t = interpolated_poses[i + 1]
-        depth_t = render_depth(pose_t)
-        wd = inverse_warp(src[side][0], src[side][1], torch.tensor(depth_t[None], device=dev, dtype=torch.float32),
-                          torch.tensor(pose_s, device=dev, dtype=torch.float32),
-                          torch.tensor(pose_t, device=dev, dtype=torch.float32), K)
-        mask2 = wd["mask_reproj"].cpu().numpy()
-        warped = wd["warped_img"].cpu().numpy().transpose([1, 2, 0])
-        mask = (1 - mask2 >= 0.5).astype(np.float64)
-        mask = np.repeat(mask[:, :, None] * 255.0, 3, axis=2)
-        ero = np.uint8(dilate5x5(mask)) / 255.0
-        ero = (ero >= 0.5).astype(np.float64)
-        masks_ero.append(ero)
-        cond_ori.append(warped / 255.0)
-        cond_image.append(np.asarray(np.uint8(warped * (1 - ero)), dtype=np.float32) / 255.0)   # uint8 round trip (:1469,1475)
-        pooled = block_mean_pool(np.mean(ero, axis=-1), h, w)
-        masks.append(torch.from_numpy((pooled >= 0.2).astype(np.float64)).unsqueeze(0))
-        soft = 1 - wd["soft_mask_reproj"].cpu().numpy()
-        soft_ori.append(soft)
-        soft_pool.append(torch.from_numpy(block_mean_pool(soft, h, w)).unsqueeze(0))
-    aux = dict(masks_ero=np.stack(masks_ero).astype(np.uint8), soft_masks_reproj=torch.cat(soft_pool).to(torch.float32),
-               soft_masks_reproj_ori=np.stack(soft_ori).astype(np.float32), cond_images_ori=cond_ori)
-    return image_l / 255.0, image_r / 255.0, torch.cat(masks), cond_image, aux
+    """`warp_images_bw_device` with the reference's return shapes (diffusionGS.py:1507-1510): host copies made once,
+    after the device work — (image_l/255, image_r/255, masks [n,h,w], cond_image list, aux dict)."""
+    d = warp_images_bw_device(intrinsics, interpolated_poses, image_l, image_r, depth_l, depth_r, render_depth,
+                              device=device, h=h, w=w)
+    ero = d["masks_ero"].cpu().numpy()
+    aux = dict(masks_ero=np.repeat(ero[..., None], 3, axis=-1).astype(np.uint8),
+               soft_masks_reproj=d["soft_masks_reproj"].cpu(),
+               soft_masks_reproj_ori=d["soft_masks_reproj_ori"].cpu().numpy(),
+               cond_images_ori=list(d["cond_images_ori"].cpu().numpy()))
+    return (image_l / 255.0, image_r / 255.0, d["masks"].cpu().to(torch.float64), list(d["cond_image"].cpu().numpy()), aux)
+
+
+def fuse_uncertainty_device(cond_images_ori: torch.Tensor, gs_images, soft_masks_reproj_ori: torch.Tensor,
+                            h: int = 72, w: int = 128):
+    """`fuse_uncertainty` (diffusionGS.py:821-862) in one `syn3r_fuse_uncertainty` call on device tensors
+    ([n,H,W,3], [n,H,W,3], [n,H,W]); returns (masks [n,h,w], cond_image [n,H,W,3], uncertainty [n,H,W]), all fp32
+    on the device (the numpy restatement above carries the uncertainty in float64: results agree to 1e-6)."""
+    dev = L.require_gpu(cond_images_ori, soft_masks_reproj_ori)
+    gs = torch.as_tensor(gs_images, dtype=torch.float32).to(dev).contiguous()
+    co = cond_images_ori.to(torch.float32).contiguous()
+    so = soft_masks_reproj_ori.to(torch.float32).contiguous()
+    n, H, W, _ = co.shape
+    if gs.shape != co.shape or so.shape != (n, H, W):
+        raise ValueError(f"fuse_uncertainty: shapes {tuple(co.shape)} / {tuple(gs.shape)} / {tuple(so.shape)}")
+    unc = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+    cond = torch.empty_like(co)
+    masks = torch.empty((n, h, w), dtype=torch.float32, device=dev)
+    rc = L.load().syn3r_fuse_uncertainty(L.ptr(co), L.ptr(gs), L.ptr(so), n, H, W, h, w, L.ptr(unc), L.ptr(cond),
+                                         L.ptr(masks), L.stream_ptr(dev))
+    L.check(rc, "syn3r_fuse_uncertainty")
+    return masks, cond, unc
 
 
 # ---------------------------------------------------------------------------------------------- O2

@@ -59,7 +59,8 @@ def preprocess_images(images, height: int, width: int) -> torch.Tensor:
         if t.shape[-2:] != (height, width):
             t = torch.nn.functional.interpolate(t, size=(height, width), mode="bilinear", align_corners=False)
         out.append(2.0 * t - 1.0)
-    return torch.cat(out, 0)
+    dev = next((o.device for o in out if o.is_cuda), out[0].device)   # device tensors may be mixed with host images
+    return torch.cat([o.to(dev) for o in out], 0)
 
 
 # overlapping tiles of the 72x128 latent grid used by the Post variant (…post.py:739-758) and the

@@ -54,3 +54,33 @@ with L.kernel_trace() as tr:
 tot = sum(v[1] for v in tr.result.values())
 print(f"forward_warp (W1, fp64 splat): {tot * 1e3:.1f} us device, {wall * 1e3:.1f} ms wall incl. the numpy<->device copies of its "
       f"numpy interface; 144 B/px -> {144 * px / tot / 1e6:.0f} GB/s")
+
+# orchestrator post-processing: 23 frames at once on the device vs the per-frame host loop
+from syn3r_amd import orchestrator as O
+poses25 = list(O.pose_interpolation(T1.astype(np.float64), T2.astype(np.float64), num=25))
+img_l = (rgb.transpose(1, 2, 0) * 255).astype(np.float32)
+depth_dev = d.clone()
+run_dev = lambda: O.warp_images_bw_device(K, poses25, img_l, img_l, depth, depth, render_depth=lambda p: depth_dev, h=72, w=128)
+r = dev_ms(run_dev, n=3)
+print("warp_images_bw_device (23 frames): " + ", ".join(f"{a} {b * 1e3:.0f} us" for a, b in r.items()))
+run_dev(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3):
+    wd = run_dev()
+    m, c, u = O.fuse_uncertainty_device(wd["cond_images_ori"], wd["cond_image"], wd["soft_masks_reproj_ori"])
+torch.cuda.synchronize()
+t_dev = (time.perf_counter() - t0) / 3
+t0 = time.perf_counter()
+wd1 = inverse_warp(img * 255, d[None], d[None], p1, p2, k, bandwidth=20)
+mask2 = wd1["mask_reproj"].cpu().numpy(); warped = wd1["warped_img"].cpu().numpy().transpose([1, 2, 0])
+mask = np.repeat((1 - mask2 >= 0.5).astype(np.float64)[:, :, None] * 255.0, 3, axis=2)
+ero = (np.uint8(O.dilate5x5(mask)) / 255.0 >= 0.5).astype(np.float64)
+cond = np.asarray(np.uint8(warped * (1 - ero)), dtype=np.float32) / 255.0
+pooled = O.block_mean_pool(np.mean(ero, axis=-1), 72, 128)
+soft = 1 - wd1["soft_mask_reproj"].cpu().numpy(); sp = O.block_mean_pool(soft, 72, 128)
+t_host1 = time.perf_counter() - t0
+t0 = time.perf_counter()
+O.fuse_uncertainty(np.stack([warped / 255.0] * 23), np.stack([cond] * 23), np.stack([soft] * 23))
+t_fuse_host = time.perf_counter() - t0
+print(f"warps + masks + fusion for one view pair: device path {t_dev * 1e3:.1f} ms wall; per-frame host loop "
+      f"{23 * t_host1 * 1e3:.0f} ms + numpy fusion {t_fuse_host * 1e3:.0f} ms")
