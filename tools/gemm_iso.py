@@ -41,3 +41,19 @@ for M, N, K in SHAPES:
     fl = 2 * M * N * K / 1e9
     print(f"M{M} N{N} K{K}: cold {cold * 1e3:7.1f} us {fl / cold:6.0f} TF | sustained {hot * 1e3:7.1f} us {fl / hot:6.0f} TF")
     del x, w
+
+# implicit-GEMM 3x3 convolutions of the UNet (NHWC): (frames, H, W, Cin, Cout)
+for NB, Hh, Ww, Cin, Cout in [(28, 72, 128, 320, 320), (28, 36, 64, 640, 640), (28, 18, 32, 1280, 1280), (28, 72, 128, 640, 320)]:
+    x = torch.randn(NB, Hh, Ww, Cin, device=dev).to(H)
+    w = (torch.randn(Cout, 3, 3, Cin, device=dev) * 0.01).to(H)
+    f = lambda: ops.conv3x3(x, w)
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    cold = timed(f, 20)
+    n = max(20, int(500 / cold))
+    timed(f, n)
+    hot = timed(f, n // 2)
+    fl = 2 * NB * Hh * Ww * Cout * 9 * Cin / 1e9
+    print(f"conv {NB}x{Hh}x{Ww} {Cin}->{Cout}: cold {cold * 1e3:7.1f} us {fl / cold:6.0f} TF | sustained {hot * 1e3:7.1f} us {fl / hot:6.0f} TF")
+    del x, w
