@@ -300,6 +300,21 @@ int syn3r_gemm_geglu_f16(const void* A, long long lda, const void* Wpacked, cons
                          long long ldc, int M, int D, int K, void* stream);
 
 /*
+ * FeedForward(dim, activation_fn="geglu").forward (diffusers attention.py:608-665, activations.py GEGLU): 
+ *   out = s_acc * (geglu(x @ W1^T + b1) @ W2^T + b2) + s_res * residual + s_aux * aux
+ * in two launches (syn3r_gemm_geglu_f16, syn3r_gemm_f16) whose intermediate, the gated hidden activation
+ * [M, D], lives in `workspace` in a tiled layout ([ceil(M/128)][D/64][128][64]: the second projection reads its A
+ * operand as contiguous 16 KB tile images instead of rows at a multi-KB pitch).
+ *   x [M, C_in] (row stride ldx); w1_packed / b1_packed: GEGLU packing of syn3r_gemm_geglu_f16 ([80 hidden | 80 gate]
+ *   row groups); D = hidden width (multiple of 64); w2 [C_out, D]; b2 [C_out] or NULL; residual / aux [M, C_out] or NULL.
+ */
+size_t syn3r_feedforward_workspace_bytes(int M, int D);
+int syn3r_feedforward_f16(const void* x, long long ldx, const void* w1_packed, const void* b1_packed, int D,
+                          const void* w2, const void* b2, void* out, long long ldc, const void* residual,
+                          long long ldr, const void* aux, long long ldaux, float s_acc, float s_res, float s_aux,
+                          int M, int C_in, int C_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * 3x3 Conv2d on NHWC fp16 (resnet.py:274,290; downsampling.py:116-148 with stride 2;
  * upsampling.py:172-183 with upsample != 0: nearest-2x of the input fused into the gather).
  * pad_lo = 1: padding 1 on every side.  pad_lo = 0: the VAE encoder's Downsample2D(padding=0), which pads

@@ -56,7 +56,19 @@ struct GemmParams {
     int F, HW;
     // GEGLU epilogue: W rows are packed per 160-row tile as [80 hidden | 80 gate]; out has geglu_D columns
     int geglu_D;
+    // A-tiled layout of a [M, D] matrix (the feed-forward's gated hidden activation, written by the GEGLU kernel and
+    // read once as the A operand of the second projection): [ceil(M/128)][D/64][128 rows][64 columns], i.e. the
+    // 16 KB image of every (128-row block, 64-wide k-tile) is one contiguous run: the second projection streams its
+    // A operand as whole tile images (2..5 % faster inside the UNet than from rows at a 2.5-10 KB pitch), and the
+    // writes of a wavefront stay inside two 8 KB windows.
+    int out_tiled;                        // the kernel writes `out` in that layout (ldc unused)
+    int a_tiled;                          // the kernel reads A in that layout (lda unused; dense mode only)
 };
+
+// element offset of (row m, column d) in the A-tiled layout of a matrix with D columns
+__device__ __forceinline__ long long tiled_off(int m, int d, int D) {
+    return ((long long)(m >> 7) * (D >> 6) + (d >> 6)) * 8192 + (m & 127) * 64 + (d & 63);
+}
 
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8, k = bid / 8;
@@ -169,7 +181,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
                 float ge = gelu_erf(g);
                 o[e] = (_Float16)((float)hv[e] * ge);
             }
-            if (n + 8 <= p.geglu_D) {
+            if (p.out_tiled) {
+                *(half8*)(p.out + tiled_off(m, n, p.geglu_D)) = o;
+            } else if (n + 8 <= p.geglu_D) {
                 *(half8*)(p.out + (long long)m * p.ldc + n) = o;
             } else {
                 for (int e = 0; e < 8 && n + e < p.geglu_D; ++e) ((_Float16*)p.out)[(long long)m * p.ldc + n + e] = o[e];
@@ -205,7 +219,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (_Float16)f[e];
         }
-        if (n + 8 <= p.N) {
+        if (p.out_tiled) {
+            *(half8*)(p.out + tiled_off(m, n, p.N)) = v;
+        } else if (n + 8 <= p.N) {
             *(half8*)(p.out + (long long)m * p.ldc + n) = v;
         } else {
             for (int e = 0; e < 8 && n + e < p.N; ++e) ((_Float16*)p.out)[(long long)m * p.ldc + n + e] = v[e];
@@ -418,7 +434,10 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
         bool ok = m < p.M;
         int mc = ok ? m : p.M - 1;
         if constexpr (MODE == MODE_DENSE) {
-            a_base[i] = p.A + (long long)mc * p.lda + csrc * 8;
+            // A-tiled: rows past M exist in the padded last row block (never stored); the k advance is one tile image
+            const int last_rb = (p.M + 127) >> 7, rb = (m >> 7) < last_rb ? (m >> 7) : last_rb - 1;
+            a_base[i] = p.a_tiled ? p.A + (long long)rb * (p.K >> 6) * 8192 + (m & 127) * 64 + csrc * 8
+                                  : p.A + (long long)mc * p.lda + csrc * 8;
             a_n[i] = a_y[i] = a_x[i] = 0;
         } else if constexpr (MODE == MODE_CONV2D) {
             int hw = p.Ho * p.Wo;
@@ -480,7 +499,7 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
     };
     if constexpr (MODE == MODE_DENSE) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { a_cur[i] = a_base[i]; a_inc[i] = BK; }
+        for (int i = 0; i < 4; ++i) { a_cur[i] = a_base[i]; a_inc[i] = p.a_tiled ? 8192 : BK; }
     }
 
     auto issue_stage = [&](int kt, int buf) {     // must be called with kt = 0, 1, 2, ... in order
@@ -658,9 +677,20 @@ __global__ void __launch_bounds__(512, 2) k_gemm_wide(GemmParams p) {
     };
     if constexpr (MODE == MODE_DENSE) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_cur[i] = p.A + (long long)a_m[i] * p.lda + csrc * 8;
+        for (int i = 0; i < 4; ++i) {
+            if (p.a_tiled) {              // rows past the padded matrix re-read the last allocated row block
+                int m = m0 + wv * 32 + i * 8 + prow;
+                const int last_rb = (p.M + 127) >> 7;
+                int rb = m >> 7;
+                rb = rb < last_rb ? rb : last_rb - 1;
+                a_cur[i] = p.A + (long long)rb * (p.K >> 6) * 8192 + (m & 127) * 64 + csrc * 8;
+            } else {
+                a_cur[i] = p.A + (long long)a_m[i] * p.lda + csrc * 8;
+            }
+        }
         live |= 15u;
     }
+    const int a_step = (MODE == MODE_DENSE && p.a_tiled) ? 8192 : BK;   // halfs per k-tile
     auto issue_stage = [&](int buf) {     // stages are issued in k order
         char* st = smem_raw + buf * W_STAGE;
         if constexpr (MODE != MODE_DENSE) {
@@ -670,7 +700,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_wide(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             __builtin_amdgcn_global_load_lds((gbl_void_t*)a_cur[i], (lds_void_t*)(st + (wv * 4 + i) * 1024), 16, 0, 0);
-            a_cur[i] += ((live >> i) & 1u) * BK;
+            a_cur[i] += ((live >> i) & 1u) * a_step;
         }
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
@@ -978,6 +1008,46 @@ extern "C" int syn3r_gemm_geglu_f16(const void* A, long long lda, const void* Wp
     p.ldc = save;
     SYN3R_REQUIRE(lda % 8 == 0 && lda >= K, "gemm_geglu_f16: lda=%lld must be >= K and a multiple of 8", lda);
     return launch<MODE_DENSE>(p, (hipStream_t)stream);
+}
+
+extern "C" size_t syn3r_feedforward_workspace_bytes(int M, int D) {
+    if (M <= 0 || D <= 0) return 0;
+    return (size_t)((M + 127) / 128) * 128 * (size_t)D * sizeof(__half);
+}
+
+extern "C" int syn3r_feedforward_f16(const void* x, long long ldx, const void* w1_packed, const void* b1_packed, int D,
+                                     const void* w2, const void* b2, void* out, long long ldc, const void* residual,
+                                     long long ldr, const void* aux, long long ldaux, float s_acc, float s_res,
+                                     float s_aux, int M, int C_in, int C_out, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    SYN3R_REQUIRE(x && w1_packed && b1_packed && w2 && out, "feedforward_f16: null operand");
+    SYN3R_REQUIRE(M > 0 && D > 0 && D % BK == 0 && C_in > 0 && C_out > 0, "feedforward_f16: bad sizes M=%d D=%d C_in=%d C_out=%d (D must be a multiple of %d)",
+                  M, D, C_in, C_out, BK);
+    SYN3R_REQUIRE(g_tile_bm == 0, "feedforward_f16: the register-staged tuning kernel does not read the tiled intermediate");
+    const size_t need = syn3r_feedforward_workspace_bytes(M, D);
+    if (!workspace || workspace_bytes < need) {
+        set_error("feedforward_f16: workspace %zu < %zu", workspace_bytes, need);
+        return SYN3R_E_WORKSPACE;
+    }
+    SYN3R_REQUIRE((uintptr_t)workspace % 16 == 0, "feedforward_f16: workspace must be 16-byte aligned");
+    // net.0 (GEGLU projection) -> the gated hidden activation in the A-tiled layout ...
+    GemmParams p{};
+    const int tiles = (D + WN - 1) / WN;
+    p.A = (const __half*)x; p.lda = ldx; p.W = (const __half*)w1_packed; p.out = (__half*)workspace; p.ldc = (long long)tiles * BN;
+    p.bias = (const __half*)b1_packed; p.s_acc = 1.0f; p.M = M; p.N = tiles * BN; p.K = C_in; p.geglu_D = D; p.out_tiled = 1;
+    int rc = check_common(p, "feedforward_f16(net.0)");
+    if (rc) return rc;
+    SYN3R_REQUIRE(ldx % 8 == 0 && ldx >= C_in, "feedforward_f16: ldx=%lld must be >= C_in and a multiple of 8", ldx);
+    rc = launch<MODE_DENSE>(p, (hipStream_t)stream);
+    if (rc) return rc;
+    // ... which net.2 reads as its A operand
+    GemmParams q{};
+    q.A = (const __half*)workspace; q.lda = D; q.a_tiled = 1; q.W = (const __half*)w2; q.out = (__half*)out; q.ldc = ldc;
+    q.bias = (const __half*)b2; q.residual = (const __half*)residual; q.ldr = ldr; q.aux = (const __half*)aux; q.ldaux = ldaux;
+    q.s_acc = s_acc; q.s_res = s_res; q.s_aux = s_aux; q.M = M; q.N = C_out; q.K = D;
+    rc = check_common(q, "feedforward_f16(net.2)");
+    if (rc) return rc;
+    return launch<MODE_DENSE>(q, (hipStream_t)stream);
 }
 
 extern "C" int syn3r_conv2d3x3_f16(const void* X, const void* W, void* out, long long ldc, const void* bias,

@@ -20,6 +20,7 @@ Restructurings relative to the reference graph (each keeps the reference's resul
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Sequence, Tuple, Union
 
 import torch
@@ -344,8 +345,12 @@ class UNetSpatioTemporalConditionModel:
 
     def _ff(self, pre: str, x: torch.Tensor, **epilogue) -> torch.Tensor:
         wp = self.w(pre + ".net.0.proj.geglu_w")
-        g = ops.linear_geglu(x, wp, self.w(pre + ".net.0.proj.geglu_b"), self.p.shapes[pre + ".net.0.proj.weight"][0] // 2)
-        return ops.linear(g, self.w(pre + ".net.2.weight"), self.w(pre + ".net.2.bias"), **epilogue)
+        D = self.p.shapes[pre + ".net.0.proj.weight"][0] // 2
+        if os.environ.get("SYN3R_FF_TILED") == "0":      # tuning: row-major intermediate, two separate calls
+            return ops.linear(ops.linear_geglu(x, wp, self.w(pre + ".net.0.proj.geglu_b"), D),
+                              self.w(pre + ".net.2.weight"), self.w(pre + ".net.2.bias"), **epilogue)
+        return ops.feedforward(x, wp, self.w(pre + ".net.0.proj.geglu_b"), D, self.w(pre + ".net.2.weight"),
+                               self.w(pre + ".net.2.bias"), **epilogue)
 
     def _transformer(self, pre: str, x: torch.Tensor, st: dict, ch: int, heads: int) -> torch.Tensor:
         B, F, h, w_ = st["B"], st["F"], st["h"], st["w"]

@@ -87,6 +87,30 @@ def linear_geglu(x: torch.Tensor, wpacked: torch.Tensor, bpacked: torch.Tensor, 
     return out
 
 
+def feedforward(x: torch.Tensor, w1_packed: torch.Tensor, b1_packed: torch.Tensor, D: int, w2: torch.Tensor,
+                b2: Optional[torch.Tensor] = None, *, residual: Optional[torch.Tensor] = None,
+                aux: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0, s_aux: float = 1.0) -> torch.Tensor:
+    """FeedForward.forward with the GEGLU activation (attention.py:608-665): geglu(x @ W1^T + b1) @ W2^T + b2 with
+    the fused epilogue of `linear`; the hidden activation stays in a tiled workspace (syn3r_feedforward_f16)."""
+    dev = _chk(w1_packed, b1_packed, w2, b2, residual, aux)
+    L.require_gpu(x)
+    M, K = x.shape
+    N = w2.shape[0]
+    if x.stride(1) != 1 or w2.shape[1] != D or w1_packed.shape[1] != K:
+        raise ValueError(f"feedforward: x {tuple(x.shape)} / w1 {tuple(w1_packed.shape)} / w2 {tuple(w2.shape)} / D={D} mismatch")
+    out = torch.empty((M, N), dtype=H, device=dev)
+    lib = L.load()
+    ws = L.workspace(dev, lib.syn3r_feedforward_workspace_bytes(M, D), "ff")
+    rc = lib.syn3r_feedforward_f16(x.data_ptr(), x.stride(0), L.ptr(w1_packed), L.ptr(b1_packed), D, L.ptr(w2), L.ptr(b2),
+                                   L.ptr(out), N, residual.data_ptr() if residual is not None else None,
+                                   residual.stride(0) if residual is not None else 0,
+                                   aux.data_ptr() if aux is not None else None, aux.stride(0) if aux is not None else 0,
+                                   float(s_acc), float(s_res), float(s_aux), M, K, N, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+    L.check(rc, "syn3r_feedforward_f16")
+    _count("gemm", 2.0 * M * 2 * D * K + 2.0 * M * N * D)
+    return out
+
+
 def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride: int = 1,
             upsample: bool = False, rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0,
             residual: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0,

@@ -249,3 +249,43 @@ def test_every_contraction_kernel_agrees(gpu, every_contraction_kernel):
         close(ops.tconv3(xt, wt, bt, B, F, HW), ref_t)
         close(ops.linear_geglu(x, wp, bp, D), ref_g, tol=4e-3)
     every_contraction_kernel(body)
+
+
+@pytest.mark.parametrize("M,C,D", [(700, 320, 1280), (129, 64, 128), (1000, 640, 2560), (4032, 1280, 5120), (77, 128, 192)])
+def test_feedforward_tiled_intermediate(M, C, D, gpu):
+    """`feedforward` (gated hidden activation in the tiled workspace) equals the two separate launches with the
+    row-major intermediate bit for bit (same kernels, same arithmetic; only where the intermediate lives differs), with
+    the full epilogue, on ragged M and through the default and the forced tile kernels."""
+    from syn3r_amd import _lib
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(M + D)
+    x = rnd(g, M, C, dev=gpu)
+    w1, b1 = rnd(g, 2 * D, C, scale=C ** -0.5, dev=gpu), rnd(g, 2 * D, dev=gpu)
+    w2, b2 = rnd(g, C, D, scale=D ** -0.5, dev=gpu), rnd(g, C, dev=gpu)
+    res, aux = rnd(g, M, C, dev=gpu), rnd(g, M, C, dev=gpu)
+    wp, bp, _ = ops.pack_geglu(w1, b1)
+    lib = _lib.load()
+    try:
+        for tile in (0, -128, -256, -320):
+            _lib.check(lib.syn3r_gemm_set_tile(tile), "set_tile")
+            ref = ops.linear(ops.linear_geglu(x, wp, bp, D), w2, b2, residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25)
+            out = ops.feedforward(x, wp, bp, D, w2, b2, residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25)
+            assert torch.equal(out, ref), (tile, (out.float() - ref.float()).abs().max().item())
+            assert torch.equal(ops.feedforward(x, wp, bp, D, w2, b2), ops.linear(ops.linear_geglu(x, wp, bp, D), w2, b2))
+    finally:
+        lib.syn3r_gemm_set_tile(0)
+    # against the fp32 restatement of FeedForward (attention.py:608-665): projection and gate rounded to fp16
+    y = (x.float() @ w1.float().T + b1.float()).half().float()
+    h = (y[:, :D] * Fn.gelu(y[:, D:])).half().float()
+    close(ops.feedforward(x, wp, bp, D, w2, b2), h @ w2.float().T + b2.float(), tol=4e-3)
+
+
+def test_feedforward_rejects_bad_input(gpu):
+    from syn3r_amd import _lib
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(1)
+    x = rnd(g, 64, 64, dev=gpu)
+    w1, b1 = rnd(g, 2 * 96, 64, dev=gpu), rnd(g, 2 * 96, dev=gpu)      # D = 96 is not a multiple of 64
+    wp, bp, _ = ops.pack_geglu(w1, b1)
+    with pytest.raises(_lib.Syn3rError, match="multiple of 64"):
+        ops.feedforward(x, wp, bp, 96, rnd(g, 64, 96, dev=gpu))

@@ -57,3 +57,19 @@ for NB, Hh, Ww, Cin, Cout in [(28, 72, 128, 320, 320), (28, 36, 64, 640, 640), (
     fl = 2 * NB * Hh * Ww * Cout * 9 * Cin / 1e9
     print(f"conv {NB}x{Hh}x{Ww} {Cin}->{Cout}: cold {cold * 1e3:7.1f} us {fl / cold:6.0f} TF | sustained {hot * 1e3:7.1f} us {fl / hot:6.0f} TF")
     del x, w
+
+# GEGLU projections (the feed-forward's first half): (M, hidden width D, K)
+for M, D, K in [(258048, 1280, 320), (64512, 2560, 640), (16128, 5120, 1280)]:
+    x = torch.randn(M, K, device=dev).to(H)
+    wp, bp, _ = ops.pack_geglu((torch.randn(2 * D, K, device=dev) * K ** -0.5).to(H), torch.randn(2 * D, device=dev).to(H))
+    f = lambda: ops.linear_geglu(x, wp, bp, D)
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    cold = timed(f, 20)
+    n = max(20, int(500 / cold))
+    timed(f, n)
+    hot = timed(f, n // 2)
+    fl = 2 * M * 2 * D * K / 1e9
+    print(f"geglu M{M} D{D} K{K}: cold {cold * 1e3:7.1f} us {fl / cold:6.0f} TF | sustained {hot * 1e3:7.1f} us {fl / hot:6.0f} TF")
+    del x, wp, bp
