@@ -286,7 +286,8 @@ int syn3r_gemm_f16(const void* A, long long lda, const void* W, void* out, long 
                    void* stream);
 
 /* Tuning / test hook: 0 = library default (kernel chosen per shape); 128 / 256 = register-staged kernel of that
- * block height; -128 / -256 = LDS-DMA kernel of that block height; -320 = the 256 x 320 wide-tile LDS-DMA kernel. */
+ * block height; -128 / -256 = LDS-DMA kernel of that block height; -320 = the 256 x 320 wide-tile LDS-DMA kernel;
+ * -321 = its 128 x 320 two-blocks-per-CU variant (dense contractions; the convolutions keep the default). */
 int syn3r_gemm_set_tile(int bm);
 
 /*

@@ -804,6 +804,157 @@ __global__ void __launch_bounds__(512, 2) k_gemm_wide(GemmParams p) {
     gemm_epilogue<0>(p, acc[1], smem_raw, lane, wv, wm, wn * 2 + 1, m0, n0, tile_n);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 128 x 320 variant of the wide tile: the same 64 x 160 wavefront tile (160 accumulators), FOUR wavefronts,
+// 32-wide k stages (28,672 B; 2-stage ring 57,344 B) so that TWO blocks share a CU.  In one block the contraction
+// core, the GEGLU gate (vector ALU) and the output stores run one after the other (measured on the L0 gated
+// projection: 491 + 115 + 177 us); with a second, independent block on the CU one block's gate and store tail
+// overlap the other's k-loop.  Against the 256-row tile it re-reads the weight panel twice as often (0.70
+// instead of 0.45 staged bytes per MAC row; the 128 x 160 blocks: 0.90).  Dense mode only.
+// LDS rows are 64 bytes (4 chunks of 16 B): slot = chunk ^ s(row >> 2 & 3) with s = (0,2,3,1) keeps every
+// 16-lane group of a ds_read_b128 fragment read on 16 different 16-byte bank units.
+constexpr int HBK = 32;
+constexpr int H_A_BYTES = 128 * HBK * 2;                     // 8,192
+constexpr int H_B_BYTES = WBN * HBK * 2;                     // 20,480
+constexpr int H_STAGE = H_A_BYTES + H_B_BYTES;               // 28,672
+
+__device__ __forceinline__ int h_swz(int row_in_16) { return (0x78 >> (2 * (row_in_16 >> 2))) & 3; }
+
+__global__ void __launch_bounds__(256, 2) k_gemm_w128(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int tiles_n = (p.N + WBN - 1) / WBN;
+    const int tiles_m = (p.M + 127) / 128;
+    const unsigned bid = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * WBN;
+
+    // DMA pieces: 1 KiB = 16 rows x 64 B; lane -> (row, destination slot); per wavefront 2 of A, 5 of W
+    const int prow = lane >> 2;
+    const int csrc = (lane & 3) ^ h_swz(prow);
+    const __half* a_base[2];
+    const __half* b_base[5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + (wv * 2 + i) * 16 + prow;
+        if (p.a_tiled) {
+            const int last_rb = (p.M + 127) >> 7, rb = (m >> 7) < last_rb ? (m >> 7) : last_rb - 1;
+            a_base[i] = p.A + (long long)rb * (p.K >> 6) * 8192 + (m & 127) * 64 + csrc * 8;
+        } else {
+            a_base[i] = p.A + (long long)(m < p.M ? m : p.M - 1) * p.lda + csrc * 8;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int n = n0 + (wv * 5 + j) * 16 + prow;
+        b_base[j] = p.W + (long long)(n < p.N ? n : p.N - 1) * p.K + csrc * 8;      // columns past N are never stored
+    }
+    auto issue_stage = [&](int s, int buf) {
+        char* st = smem_raw + buf * H_STAGE;
+        const int ka = p.a_tiled ? (s >> 1) * 8192 + (s & 1) * HBK : s * HBK;
+        const int kb = s * HBK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_base[i] + ka), (lds_void_t*)(st + (wv * 2 + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_base[j] + kb), (lds_void_t*)(st + H_A_BYTES + (wv * 5 + j) * 1024), 16, 0, 0);
+    };
+
+    float4v acc[2][TM][TN];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[hh][i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    const int nks = p.K / HBK;
+    const int fr = lane & 15, fq = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const unsigned slot = (unsigned)((fq ^ h_swz(fr)) << 4);
+    const unsigned a_row = (unsigned)((wm * WM + fr) * 64) + slot;
+    const unsigned b_row = (unsigned)(H_A_BYTES + (wn * 160 + fr) * 64) + slot;
+
+    issue_stage(0, 0);
+    int buf = 0;
+    for (int s = 0; s < nks; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage s (the only one in flight) has landed
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < nks) issue_stage(s + 1, buf ^ 1);        // the slot every wavefront finished reading in step s-1
+        const unsigned aa = lds0 + (unsigned)buf * H_STAGE + a_row, ba = lds0 + (unsigned)buf * H_STAGE + b_row;
+        half8 af[TM], bf[WTN];
+        DS_READ128(af[0], aa, 0); DS_READ128(af[1], aa, 1024); DS_READ128(af[2], aa, 2048); DS_READ128(af[3], aa, 3072);
+        DS_READ128(bf[0], ba, 0); DS_READ128(bf[1], ba, 1024); DS_READ128(bf[2], ba, 2048); DS_READ128(bf[3], ba, 3072);
+        DS_READ128(bf[4], ba, 4096); DS_READ128(bf[5], ba, 5120); DS_READ128(bf[6], ba, 6144); DS_READ128(bf[7], ba, 7168);
+        DS_READ128(bf[8], ba, 8192); DS_READ128(bf[9], ba, 9216);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]),
+                       "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7]), "+v"(bf[8]), "+v"(bf[9]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+                acc[j / TN][i][j % TN] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[j / TN][i][j % TN], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        buf ^= 1;
+    }
+    __syncthreads();   // every wavefront is done reading the ring before the epilogue reuses it
+
+    if (p.geglu_D > 0) {
+        // GEGLU.forward as in k_gemm_wide: the wavefront's 160 columns are one packed group [80 hidden | 80 gate]
+        const int gn = n0 + wn * 160;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = gn + j * 16 + fq * 4;
+            float bh[4], bg[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bh[r] = (p.bias && n + r < p.N) ? __half2float(p.bias[n + r]) : 0.f;
+                bg[r] = (p.bias && n + 80 + r < p.N) ? __half2float(p.bias[n + 80 + r]) : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float hv = (float)(_Float16)(acc[0][i][j][r] + bh[r]);
+                    float gv = (float)(_Float16)(acc[1][i][j][r] + bg[r]);
+                    acc[0][i][j][r] = hv * gelu_erf(gv);
+                }
+        }
+        GemmParams q = p;
+        q.bias = nullptr; q.rowvec = nullptr; q.residual = nullptr; q.aux = nullptr; q.s_acc = 1.0f;
+        q.N = p.geglu_D; q.geglu_D = 0;
+        gemm_epilogue<0>(q, acc[0], smem_raw, lane, wv, wm, wn, m0, tile_n * 160, tile_n);
+        return;
+    }
+    gemm_epilogue<0>(p, acc[0], smem_raw, lane, wv, wm, wn * 2, m0, n0, tile_n);
+    __builtin_amdgcn_wave_barrier();
+    gemm_epilogue<0>(p, acc[1], smem_raw, lane, wv, wm, wn * 2 + 1, m0, n0, tile_n);
+}
+
+int launch_w128(const GemmParams& p, hipStream_t stream) {
+    constexpr size_t lds = (size_t)2 * H_STAGE;   // 57,344 B
+    static_assert(4 * WM * EPI_LD * sizeof(__half) <= lds, "epilogue staging must fit in the ring");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_w128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_w128)");
+        attr_set = true;
+    }
+    int tiles = ((p.M + 127) / 128) * ((p.N + WBN - 1) / WBN);
+    char name[96];
+    if (trace_on()) {
+        if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_w128[M%d,N%d,K%d,e%d]", p.M, p.N, p.K, p.geglu_D > 0 ? 2 : (p.residual != nullptr));
+        else snprintf(name, sizeof(name), "k_gemm_w128");
+    }
+    SYN3R_LAUNCH_NAMED(name, k_gemm_w128, dim3(tiles), dim3(256), lds, stream, p);
+    SYN3R_LAUNCH_CHECK("gemm_w128 launch");
+    return SYN3R_OK;
+}
+
 template <int MODE>
 int launch_wide(const GemmParams& p, hipStream_t stream) {
     constexpr size_t lds = (size_t)2 * W_STAGE;   // 147,456 B
@@ -852,6 +1003,9 @@ template <int MODE>
 int launch_dma(const GemmParams& p, hipStream_t stream) {
     static int wide_env = -2;       // SYN3R_GEMM_WIDE: unset = by shape, 0 = never, 1 = always (tuning)
     if (wide_env == -2) { const char* e = getenv("SYN3R_GEMM_WIDE"); wide_env = e ? atoi(e) : -1; }
+    static int w128_env = -2;       // SYN3R_GEMM_W128: unset = by shape; 0 = never, 1 = wherever the wide tile would run (tuning)
+    if (w128_env == -2) { const char* e = getenv("SYN3R_GEMM_W128"); w128_env = e ? atoi(e) : -1; }
+    if (g_dma_bm == -321) { if constexpr (MODE == MODE_DENSE) return launch_w128(p, stream); }   // syn3r_gemm_set_tile(-321)
     if (g_dma_bm == -320) return launch_wide<MODE>(p, stream);       // forced by syn3r_gemm_set_tile(-320)
     if (g_dma_bm == 0 && wide_env != 0) {
         // measured on MI355X inside the UNet (tools/gemm_ab.py, same box): the 256 x 320 tile is 7..14 % faster on
@@ -862,7 +1016,13 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
         const long long rounds = (tiles + 255) / 256;
         const bool fills = tiles * 10 >= rounds * 256 * 8;
         const bool short_residual = p.residual != nullptr && p.K <= 1280;
-        if (wide_env == 1 || (MODE == MODE_DENSE && fills && !short_residual)) return launch_wide<MODE>(p, stream);
+        if (wide_env == 1 || (MODE == MODE_DENSE && fills && !short_residual)) {
+            // K <= 320 (5 k-tiles): the tile's time is its gate and store tail, which a second block on the CU
+            // overlaps: 128 x 320 blocks are 6 % faster on the L0 gated projection and 2 % on qkv; from K = 640 on
+            // the 256-row tile's weight reuse wins (+1..12 %) (tools/gemm_ab.py SYN3R_GEMM_W128 0 1, same box)
+            if constexpr (MODE == MODE_DENSE) { if (w128_env == 1 || (w128_env != 0 && p.K <= 320)) return launch_w128(p, stream); }
+            return launch_wide<MODE>(p, stream);
+        }
     }
     // measured on MI355X (tools/gemm_bench.py): two 128-row blocks per CU win on every UNet shape except the
     // wide feed-forward expansions at C = 1280, where re-reading the 160-column B tile per 128 rows costs more
@@ -911,9 +1071,9 @@ int check_common(const GemmParams& p, const char* who) {
 }  // namespace
 
 extern "C" int syn3r_gemm_set_tile(int bm) {
-    SYN3R_REQUIRE(bm == 0 || bm == 128 || bm == 256 || bm == -128 || bm == -256 || bm == -320,
-                  "gemm_set_tile: bm must be 0, +-128, +-256 or -320");
-    if (bm == -320) { g_tile_bm = 0; g_dma_bm = -320; }     // the 256 x 320 wide-tile LDS-DMA kernel
+    SYN3R_REQUIRE(bm == 0 || bm == 128 || bm == 256 || bm == -128 || bm == -256 || bm == -320 || bm == -321,
+                  "gemm_set_tile: bm must be 0, +-128, +-256, -320 or -321");
+    if (bm == -320 || bm == -321) { g_tile_bm = 0; g_dma_bm = bm; }   // the 256 x 320 / 128 x 320 wide-tile LDS-DMA kernels
     else if (bm < 0) { g_tile_bm = 0; g_dma_bm = -bm; }     // LDS-DMA kernel with a forced block height
     else { g_tile_bm = bm; g_dma_bm = 0; }                  // 0: LDS-DMA by shape; > 0: register-staged kernel
     return SYN3R_OK;

@@ -206,13 +206,13 @@ def test_ops_reject_bad_input(gpu):
 @pytest.fixture
 def every_contraction_kernel():
     """Run a test body once per contraction kernel: the per-shape default and every forced variant of
-    `syn3r_gemm_set_tile` (register-staged 128/256, LDS-DMA 128/256, 256x320 wide tile)."""
+    `syn3r_gemm_set_tile` (register-staged 128/256, LDS-DMA 128/256, 256x320 and 128x320 wide tiles)."""
     from syn3r_amd import _lib
     lib = _lib.load()
 
     def run(body):
         try:
-            for tile in (0, 128, 256, -128, -256, -320):
+            for tile in (0, 128, 256, -128, -256, -320, -321):
                 _lib.check(lib.syn3r_gemm_set_tile(tile), "set_tile")
                 body(tile)
         finally:
@@ -266,7 +266,7 @@ def test_feedforward_tiled_intermediate(M, C, D, gpu):
     wp, bp, _ = ops.pack_geglu(w1, b1)
     lib = _lib.load()
     try:
-        for tile in (0, -128, -256, -320):
+        for tile in (0, -128, -256, -320, -321):
             _lib.check(lib.syn3r_gemm_set_tile(tile), "set_tile")
             ref = ops.linear(ops.linear_geglu(x, wp, bp, D), w2, b2, residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25)
             out = ops.feedforward(x, wp, bp, D, w2, b2, residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25)

@@ -22,7 +22,8 @@ def run(env_val):
     for l in out.splitlines():
         m = re.match(r"(\S+)\[(\S+)\]\s+(\d+) launches\s+([\d.]+) ms", l)
         if m and m.group(1).startswith("k_gemm"):
-            mode = re.search(r"<(\d)", m.group(1)).group(1)
+            mm = re.search(r"<(\d)", m.group(1))
+            mode = mm.group(1) if mm else "0"
             d["cdt"[int(mode)] + ":" + m.group(2)] = (m.group(1), int(m.group(3)), float(m.group(4)))
     tot = [l for l in out.splitlines() if l.startswith("total")]
     return d, tot[-1] if tot else ""
