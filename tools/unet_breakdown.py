@@ -4,6 +4,9 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from syn3r_amd import _lib as L
+import os
+if os.environ.get("SYN3R_LIB_OVERRIDE"):      # A/B against another build of the library
+    L._LIB_PATH = Path(os.environ["SYN3R_LIB_OVERRIDE"]).resolve()
 from syn3r_amd.pipeline.svd_step import SvdStepBench
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 14
 b = SvdStepBench(F, torch.device("cuda", 0))
