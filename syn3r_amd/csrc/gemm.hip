@@ -228,6 +228,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
 #ifdef SYN3R_EXP_NOSTORE
         if ((float)v[0] != 12345.678f) continue;
 #endif
+#ifdef SYN3R_EXP_SMALLSTORE    // every store instruction issued, but into a 1 MB window (cache resident): request side only
+        { *(half8*)(p.out + (((long long)(gm0 + row) * 640 + gn0 + ch * 8) & 0x7fff8)) = v; continue; }
+#endif
         if (p.out_tiled) {
             OUT_STORE((half8*)(p.out + tiled_off(m, n, p.N)), v);
         } else if (n + 8 <= p.N) {
