@@ -225,6 +225,70 @@ def gen_pipeline():
     np.savez_compressed(GOLD / "pipeline_mock.npz", **out)
 
 
+def gen_pipeline_real_unet():
+    """The REFERENCE pipeline classes' own __call__ (both variants, CPU fp32) with the REFERENCE
+    UNetSpatioTemporalConditionModel in a reduced configuration on seeded weights (mock CLIP / VAE as in
+    gen_pipeline): pins the loops TOGETHER with the real UNet's numerics — CFG batch, the four guidance tiles of
+    the Post variant, time flips, blend — end to end.  2 denoise steps, output_type='latent'.  ~10 min of CPU."""
+    from diffusers import EulerDiscreteScheduler
+    from diffusers.image_processor import VaeImageProcessor
+    from diffusers.models import UNetSpatioTemporalConditionModel
+    from oracle import pipeline_mocks as PM
+    from oracle import unet_weights as UW
+    import model.SVD_2pass_prob_uncertain as P2
+    import model.SVD_2pass_prob_uncertain_post as P1
+
+    cfg = UW.PIPELINE_CONFIG
+    torch.manual_seed(0)
+    unet = UNetSpatioTemporalConditionModel(**cfg)
+    shapes = {k: tuple(v.shape) for k, v in unet.state_dict().items()}
+    unet.load_state_dict(UW.make_state_dict(shapes, seed=3))
+    unet.eval()
+    inp = PM.pipeline_inputs(seed=1)
+
+    def make(cls):
+        class Pipe(cls):
+            def __init__(self):
+                self.vae, self.image_encoder, self.unet = PM.MockVAE(), PM.MockImageEncoder(), unet
+                self.scheduler = EulerDiscreteScheduler(**GI.SCHED_CONFIG)
+                self.feature_extractor = None
+                self.vae_scale_factor = 8
+                self.image_processor = VaeImageProcessor(vae_scale_factor=8)
+
+            @property
+            def _execution_device(self):
+                return torch.device("cpu")
+
+            def check_inputs(self, *a, **k):
+                return None
+
+            def maybe_free_model_hooks(self):
+                return None
+        return Pipe()
+
+    out = {}
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import time
+    for tag, mod in (("replace", P2), ("post", P1)):
+        orig = mod.randn_tensor
+        mod.randn_tensor = lambda shape, **k: inp["noise"].clone() if tuple(shape) == tuple(inp["noise"].shape) else orig(shape, **k)
+        t0 = time.time()
+        try:
+            pipe = make(mod.StableVideoDiffusionPipeline)
+            with torch.no_grad():
+                res = pipe(inp["image"], temp_cond=inp["temp_cond"], mask=inp["mask"].clone(), lambda_ts=inp["lambda_ts"],
+                           num_frames=25, decode_chunk_size=8, num_inference_steps=2, latent_num=1,
+                           latents=inp["latents"].clone(), output_type="latent")
+        finally:
+            mod.randn_tensor = orig
+        lat = res.frames
+        out[tag] = lat.float().numpy()[..., ::3, ::3]
+        print("pipeline+unet", tag, lat.shape, lat.dtype, float(lat.abs().mean()), f"{time.time() - t0:.0f} s", flush=True)
+    torch.Tensor.cuda = orig_cuda
+    np.savez_compressed(GOLD / "pipeline_unet.npz", **out)
+
+
 def gen_orchestrator():
     """Pure-numpy methods of the reference's DiffusionGS (model/diffusionGS.py:1120-1296).  The module
     imports packages that are absent here (FSGS submodule, cv2, open3d, trimesh); they are not touched by
@@ -262,6 +326,8 @@ def main():
     which = sys.argv[1:] or ["warp", "sched", "unet", "vae", "pipeline", "orch"]
     if "pipeline" in which:
         gen_pipeline()
+    if "pipeline_unet" in which:          # ~10 min of CPU: not part of the default set
+        gen_pipeline_real_unet()
     if "orch" in which:
         gen_orchestrator()
     if "unet" in which:

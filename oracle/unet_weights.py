@@ -14,6 +14,9 @@ SMALL_CONFIG = dict(in_channels=8, out_channels=4, block_out_channels=(64, 128, 
                     num_attention_heads=(1, 2, 2, 2), cross_attention_dim=64, addition_time_embed_dim=64,
                     projection_class_embeddings_input_dim=192, layers_per_block=1, num_frames=5)
 
+# the same reduced UNet inside the SVD pipelines: their CLIP embedding is 1024 wide and they run 25 frames
+PIPELINE_CONFIG = dict(SMALL_CONFIG, cross_attention_dim=1024, num_frames=25)
+
 
 def make_state_dict(shapes, seed=0):
     sd = {}
