@@ -10,8 +10,9 @@ Pinning status:
   scheduler (scheduler_oracle) pinned by tests/golden/sched_*.npz  (generated from the reference)
   UNet (unet_oracle)          pinned by tests/golden/unet_small.npz (outputs of the reference module itself)
   VAE                         no restatement: tests compare with tests/golden/vae_small.npz (reference module outputs)
-  pipelines / orchestrator    no restatement: tests/golden/pipeline_mock.npz, pipeline_unet.npz (the reference pipeline
-                              classes' own __call__, with mock modules / with the reference UNet), orchestrator.npz
+  pipelines / orchestrator    no restatement: tests/golden/pipeline_mock.npz, pipeline_unet.npz, pipeline_unet_vae.npz (the
+                              reference pipeline classes' own __call__: with mock modules / with the reference UNet /
+                              with the reference UNet and VAE), orchestrator.npz
   rasteriser (raster_oracle)  PARITY UNPINNED — the reference's CUDA rasteriser source is an
                               un-vendored submodule; restates the published 3DGS algorithm
 """

@@ -289,6 +289,63 @@ def gen_pipeline_real_unet():
     np.savez_compressed(GOLD / "pipeline_unet.npz", **out)
 
 
+def gen_pipeline_real_unet_vae():
+    """As gen_pipeline_real_unet, 'replace' variant, with the REFERENCE AutoencoderKLTemporalDecoder too (reduced
+    four-level configuration) and output_type='np': the pipelines' VAE plumbing (scaled / noised condition encodes,
+    chunked temporal decode, fp32 upcast) end to end.  Frames stored at every 16th pixel."""
+    from diffusers import EulerDiscreteScheduler
+    from diffusers.image_processor import VaeImageProcessor
+    from diffusers.models import AutoencoderKLTemporalDecoder, UNetSpatioTemporalConditionModel
+    from oracle import pipeline_mocks as PM
+    from oracle import unet_weights as UW
+    from oracle import vae_weights as VW
+    import model.SVD_2pass_prob_uncertain as P2
+    import time
+
+    torch.manual_seed(0)
+    unet = UNetSpatioTemporalConditionModel(**UW.PIPELINE_CONFIG)
+    unet.load_state_dict(UW.make_state_dict({k: tuple(v.shape) for k, v in unet.state_dict().items()}, seed=3))
+    vae = AutoencoderKLTemporalDecoder(**VW.PIPELINE_VAE_CONFIG)
+    vae.load_state_dict(UW.make_state_dict({k: tuple(v.shape) for k, v in vae.state_dict().items()}, seed=11))
+    unet.eval(); vae.eval()
+    inp = PM.pipeline_inputs(seed=2)
+
+    class Pipe(P2.StableVideoDiffusionPipeline):
+        def __init__(self):
+            self.vae, self.image_encoder, self.unet = vae, PM.MockImageEncoder(), unet
+            self.scheduler = EulerDiscreteScheduler(**GI.SCHED_CONFIG)
+            self.feature_extractor = None
+            self.vae_scale_factor = 8
+            self.image_processor = VaeImageProcessor(vae_scale_factor=8)
+
+        @property
+        def _execution_device(self):
+            return torch.device("cpu")
+
+        def check_inputs(self, *a, **k):
+            return None
+
+        def maybe_free_model_hooks(self):
+            return None
+
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    orig = P2.randn_tensor
+    P2.randn_tensor = lambda shape, **k: inp["noise"].clone() if tuple(shape) == tuple(inp["noise"].shape) else orig(shape, **k)
+    t0 = time.time()
+    try:
+        with torch.no_grad():
+            res = Pipe()(inp["image"], temp_cond=inp["temp_cond"], mask=inp["mask"].clone(), lambda_ts=inp["lambda_ts"],
+                         num_frames=25, decode_chunk_size=8, num_inference_steps=2, latent_num=1,
+                         latents=inp["latents"].clone(), output_type="np")
+    finally:
+        P2.randn_tensor = orig
+        torch.Tensor.cuda = orig_cuda
+    frames = np.asarray(res.frames[0], dtype=np.float32)
+    print("pipeline+unet+vae replace", frames.shape, float(frames.mean()), float(frames.std()), f"{time.time() - t0:.0f} s", flush=True)
+    np.savez_compressed(GOLD / "pipeline_unet_vae.npz", frames=frames[:, ::16, ::16])
+
+
 def gen_orchestrator():
     """Pure-numpy methods of the reference's DiffusionGS (model/diffusionGS.py:1120-1296).  The module
     imports packages that are absent here (FSGS submodule, cv2, open3d, trimesh); they are not touched by
@@ -326,8 +383,10 @@ def main():
     which = sys.argv[1:] or ["warp", "sched", "unet", "vae", "pipeline", "orch"]
     if "pipeline" in which:
         gen_pipeline()
-    if "pipeline_unet" in which:          # ~10 min of CPU: not part of the default set
+    if "pipeline_unet" in which:          # ~5 min of CPU: not part of the default set
         gen_pipeline_real_unet()
+    if "pipeline_unet_vae" in which:      # ~10 min of CPU
+        gen_pipeline_real_unet_vae()
     if "orch" in which:
         gen_orchestrator()
     if "unet" in which:

@@ -8,6 +8,10 @@ import torch
 SMALL_VAE_CONFIG = dict(in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D", "DownEncoderBlock2D"),
                         block_out_channels=(64, 128), layers_per_block=2, latent_channels=4, sample_size=32)
 
+# four-level (x8) reduced VAE for the end-to-end pipeline case (the pipelines' latent grid is image / 8)
+PIPELINE_VAE_CONFIG = dict(in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",) * 4,
+                           block_out_channels=(64, 64, 128, 128), layers_per_block=1, latent_channels=4, sample_size=64)
+
 
 def make_images(n=2, h=32, w=48, seed=0):
     g = torch.Generator().manual_seed(4000 + seed)
