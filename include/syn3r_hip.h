@@ -400,6 +400,12 @@ int syn3r_l1_loss(const float* image, const float* target, long long n, float we
 int syn3r_l1_loss_backward(const float* image, const float* target, long long n, float weight,
                            const float* grad_loss, float* grad_image, void* stream);
 
+/* mse[0] = mean((image - target)^2) over n floats (device scalar, same deterministic two-level sum and workspace
+ * as syn3r_l1_loss): the MSE behind the PSNR column of the per-scene metric record (the reference
+ * tabulates PSNR/SSIM/LPIPS in scripts/summarize_dl3dv.py:11-80 from FSGS' metrics.py, not vendored). */
+int syn3r_image_mse(const float* image, const float* target, long long n, float* mse, void* ws, size_t ws_bytes,
+                    void* stream);
+
 /* The published 3DGS photometric loss in one pass:
  *   loss3[0] = weight * ((1 - lambda_dssim) * mean|I - G| + lambda_dssim * (1 - SSIM(I, G))), loss3[1] = L1, loss3[2] = SSIM
  * I, G [C,H,W] fp32; SSIM with the 11x11 Gaussian window (sigma 1.5), zero padding 5, C1 = 0.01^2, C2 = 0.03^2, mean

@@ -149,6 +149,50 @@ def gen_unet():
     np.savez_compressed(GOLD / "unet_small.npz", **out)
 
 
+UNET_FULL_CASES = {           # tag: (B, F, h, w, spatial stride of the stored sample)
+    "b2f14_72x128": (2, 14, 72, 128, 3),     # bench.py's unit (BASELINE config 2)
+    "b1f25_40x72": (1, 25, 40, 72, 2),       # Post variant guidance tiles (...post.py:739-779)
+    "b1f25_48x72": (1, 25, 48, 72, 2),
+    "b2f25_72x128": (2, 25, 72, 128, 3),     # the reference's own CFG forward (F = 25)
+}
+
+
+def gen_unet_full(which=None):
+    """The REFERENCE UNetSpatioTemporalConditionModel() in its DEFAULT configuration (= SVD-XT: 320/640/1280/1280,
+    5/10/20/20 heads, 1.52 B parameters), CPU fp32, name-keyed seeded weights, at the shapes bench.py and the
+    pipelines launch.  Stores a strided sample of the output per case (tests rebuild weights and inputs from the
+    seeds).  ~4-15 min of CPU per case; one file per case so they can be regenerated one at a time."""
+    import time
+    from diffusers.models import UNetSpatioTemporalConditionModel
+    from oracle import unet_weights as UW
+    torch.manual_seed(0)
+    t0 = time.time()
+    model = UNetSpatioTemporalConditionModel()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(UW.make_state_dict(shapes, seed=5))
+    model.eval()
+    print("unet_full: model ready", sum(math_prod(s) for s in shapes.values()) / 1e9, "B params", f"{time.time() - t0:.0f} s", flush=True)
+    for tag, (B, F, h, w, st) in UNET_FULL_CASES.items():
+        if which and tag not in which:
+            continue
+        sample, t, ehs, added = UW.make_inputs(B, F, h, w, seed=F, cross=1024)
+        t0 = time.time()
+        with torch.no_grad():
+            y = model(sample, t, ehs, added, return_dict=False)[0]
+        y = y.numpy()
+        np.savez_compressed(GOLD / f"unet_full_{tag}.npz", out=y[..., ::st, ::st].astype(np.float32), stride=np.int64(st),
+                            mean_abs=np.float64(np.abs(y).mean()), std=np.float64(y.std()),
+                            checksum=np.float64(y.astype(np.float64).sum()))
+        print("unet_full", tag, y.shape, float(np.abs(y).mean()), float(y.std()), f"{time.time() - t0:.0f} s", flush=True)
+
+
+def math_prod(s):
+    r = 1
+    for v in s:
+        r *= int(v)
+    return r
+
+
 def gen_vae():
     """Reference AutoencoderKLTemporalDecoder (reduced config, CPU fp32): encode moments and decoded frames."""
     from diffusers.models import AutoencoderKLTemporalDecoder
@@ -223,6 +267,68 @@ def gen_pipeline():
         print("pipeline", tag, lat.shape, lat.dtype, float(lat.abs().mean()))
     torch.Tensor.cuda = orig_cuda
     np.savez_compressed(GOLD / "pipeline_mock.npz", **out)
+
+
+def gen_pipeline_one_pass():
+    """BASELINE config 2's "SVD_1pass": the forward-in-time pass only.  The reference has no live 1-pass pipeline
+    (model/SVD_1pass.py is dead code), so the fixture is the REFERENCE two-pass classes' own
+    __call__ with the forward/backward blend weight `torch.linspace(1,0,num_frames)` (...post.py:667, :828) forced
+    to ones: latents = 1 * forward + 0 * backward at every step.  Mock CLIP / VAE / UNet as gen_pipeline."""
+    from diffusers import EulerDiscreteScheduler
+    from diffusers.image_processor import VaeImageProcessor
+    from oracle import pipeline_mocks as PM
+    import model.SVD_2pass_prob_uncertain as P2
+    import model.SVD_2pass_prob_uncertain_post as P1
+
+    inp = PM.pipeline_inputs(seed=0)
+
+    def make(cls):
+        class Pipe(cls):
+            def __init__(self):
+                self.vae, self.image_encoder, self.unet = PM.MockVAE(), PM.MockImageEncoder(), PM.MockUNet()
+                self.scheduler = EulerDiscreteScheduler(**GI.SCHED_CONFIG)
+                self.feature_extractor = None
+                self.vae_scale_factor = 8
+                self.image_processor = VaeImageProcessor(vae_scale_factor=8)
+
+            @property
+            def _execution_device(self):
+                return torch.device("cpu")
+
+            def check_inputs(self, *a, **k):
+                return None
+
+            def maybe_free_model_hooks(self):
+                return None
+        return Pipe()
+
+    out = {}
+    orig_cuda, orig_linspace = torch.Tensor.cuda, torch.linspace
+
+    def linspace(start, end, steps, *a, **k):
+        if (start, end) == (1, 0):
+            return torch.ones(steps)
+        return orig_linspace(start, end, steps, *a, **k)
+
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.linspace = linspace
+    try:
+        for tag, mod in (("post", P1), ("replace", P2)):
+            orig = mod.randn_tensor
+            mod.randn_tensor = lambda shape, **k: inp["noise"].clone() if tuple(shape) == tuple(inp["noise"].shape) else orig(shape, **k)
+            try:
+                with torch.no_grad():
+                    res = make(mod.StableVideoDiffusionPipeline)(
+                        inp["image"], temp_cond=inp["temp_cond"], mask=inp["mask"].clone(), lambda_ts=inp["lambda_ts"],
+                        num_frames=25, decode_chunk_size=8, num_inference_steps=3, latent_num=1,
+                        latents=inp["latents"].clone(), output_type="latent")
+            finally:
+                mod.randn_tensor = orig
+            out[tag] = res.frames.float().numpy()[..., ::3, ::3]
+            print("pipeline one-pass", tag, res.frames.shape, float(res.frames.abs().mean()))
+    finally:
+        torch.Tensor.cuda, torch.linspace = orig_cuda, orig_linspace
+    np.savez_compressed(GOLD / "pipeline_one_pass.npz", **out)
 
 
 def gen_pipeline_real_unet():
@@ -383,6 +489,8 @@ def main():
     which = sys.argv[1:] or ["warp", "sched", "unet", "vae", "pipeline", "orch"]
     if "pipeline" in which:
         gen_pipeline()
+    if "pipeline_one_pass" in which:
+        gen_pipeline_one_pass()
     if "pipeline_unet" in which:          # ~5 min of CPU: not part of the default set
         gen_pipeline_real_unet()
     if "pipeline_unet_vae" in which:      # ~10 min of CPU
@@ -391,6 +499,8 @@ def main():
         gen_orchestrator()
     if "unet" in which:
         gen_unet()
+    if "unet_full" in which:              # ~30 min of CPU, 1.52 B parameters: not part of the default set
+        gen_unet_full([w for w in which if w in UNET_FULL_CASES] or None)
     if "vae" in which:
         gen_vae()
     if "warp" in which:

@@ -140,6 +140,41 @@ def build_tile_lists(pre):
     return keys, vals, ranges
 
 
+def blend_tile(px, py, conic, rgb, zdepth, opacity, pxf, pyf, bg):
+    """Front-to-back blend of one tile's depth-sorted splats (rows) over its pixels (columns).
+    Returns colour [npix,3] (background composited), depth [npix], alpha [npix], n_contrib [npix]."""
+    dt = px.dtype
+    dx = px[:, None] - pxf[None]
+    dy = py[:, None] - pyf[None]
+    power = -0.5 * (conic[:, 0:1] * dx * dx + conic[:, 2:3] * dy * dy) - conic[:, 1:2] * dx * dy
+    raw = opacity[:, None] * torch.exp(power)
+    alpha = raw - torch.clamp(raw - 0.99, min=0).detach()     # min(0.99, raw), straight-through
+    ok = (power <= 0) & (alpha >= 1.0 / 255.0)
+    a_eff = torch.where(ok, alpha, torch.zeros_like(alpha))
+    one_m = 1.0 - a_eff
+    T_incl = torch.cumprod(one_m, 0)
+    T_excl = torch.cat([torch.ones(1, T_incl.shape[1], dtype=dt), T_incl[:-1]], 0)
+    stop = ok & (T_incl < 1e-4)
+    stopped = torch.cummax(stop.to(torch.int8), 0)[0].bool()
+    live = ok & ~stopped
+    w = torch.where(live, a_eff * T_excl, torch.zeros_like(a_eff))
+    T_final = torch.prod(torch.where(live, one_m, torch.ones_like(one_m)), 0)
+    c = (w[:, :, None] * rgb[:, None, :]).sum(0) + T_final[:, None] * bg.to(dt)[None]
+    d = (w * zdepth[:, None]).sum(0)
+    idx = torch.arange(1, live.shape[0] + 1)[:, None] * live
+    return c, d, 1.0 - T_final, idx.max(0)[0]
+
+
+BLEND_KEYS = ("px", "py", "conic", "rgb", "depth", "opacity")
+
+
+def _tile_pixels(ty, tx, H, W, dt):
+    ys = torch.arange(ty * TILE, min((ty + 1) * TILE, H))
+    xs = torch.arange(tx * TILE, min((tx + 1) * TILE, W))
+    yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+    return len(ys), len(xs), xx.reshape(-1).to(dt), yy.reshape(-1).to(dt)
+
+
 def render(pre, point_list, ranges, bg, H, W):
     dt = pre["px"].dtype
     gx, gy = pre["grid"]
@@ -150,39 +185,53 @@ def render(pre, point_list, ranges, bg, H, W):
     for ty in range(gy):
         for tx in range(gx):
             s, e = ranges[ty * gx + tx]
-            ys = torch.arange(ty * TILE, min((ty + 1) * TILE, H))
-            xs = torch.arange(tx * TILE, min((tx + 1) * TILE, W))
-            if e <= s or len(ys) == 0 or len(xs) == 0:
+            hh, ww, pxf, pyf = _tile_pixels(ty, tx, H, W, dt)
+            if e <= s or hh == 0 or ww == 0:
                 continue
             ids = torch.from_numpy(point_list[s:e])
-            yy, xx = torch.meshgrid(ys, xs, indexing="ij")
-            pxf, pyf = xx.reshape(-1).to(dt), yy.reshape(-1).to(dt)
-            dx = pre["px"][ids][:, None] - pxf[None]
-            dy = pre["py"][ids][:, None] - pyf[None]
-            con = pre["conic"][ids]
-            power = -0.5 * (con[:, 0:1] * dx * dx + con[:, 2:3] * dy * dy) - con[:, 1:2] * dx * dy
-            raw = pre["opacity"][ids][:, None] * torch.exp(power)
-            alpha = raw - torch.clamp(raw - 0.99, min=0).detach()     # min(0.99, raw), straight-through
-            ok = (power <= 0) & (alpha >= 1.0 / 255.0)
-            a_eff = torch.where(ok, alpha, torch.zeros_like(alpha))
-            one_m = 1.0 - a_eff
-            T_incl = torch.cumprod(one_m, 0)
-            T_excl = torch.cat([torch.ones(1, T_incl.shape[1], dtype=dt), T_incl[:-1]], 0)
-            stop = ok & (T_incl < 1e-4)
-            stopped = torch.cummax(stop.to(torch.int8), 0)[0].bool()
-            live = ok & ~stopped
-            w = torch.where(live, a_eff * T_excl, torch.zeros_like(a_eff))
-            T_final = torch.prod(torch.where(live, one_m, torch.ones_like(one_m)), 0)
-            c = (w[:, :, None] * pre["rgb"][ids][:, None, :]).sum(0)
-            d = (w * pre["depth"][ids][:, None]).sum(0)
-            hh, ww = len(ys), len(xs)
+            c, d, a, nc = blend_tile(*[pre[k][ids] for k in BLEND_KEYS], pxf, pyf, bg)
             y0_, x0_ = ty * TILE, tx * TILE
-            color[:, y0_:y0_ + hh, x0_:x0_ + ww] = (c + T_final[:, None] * bg.to(dt)[None]).T.reshape(3, hh, ww)
+            color[:, y0_:y0_ + hh, x0_:x0_ + ww] = c.T.reshape(3, hh, ww)
             depth[0, y0_:y0_ + hh, x0_:x0_ + ww] = d.reshape(hh, ww)
-            alpha_out[0, y0_:y0_ + hh, x0_:x0_ + ww] = (1.0 - T_final).reshape(hh, ww)
-            idx = torch.arange(1, live.shape[0] + 1)[:, None] * live
-            n_contrib[y0_:y0_ + hh, x0_:x0_ + ww] = idx.max(0)[0].reshape(hh, ww).numpy()
+            alpha_out[0, y0_:y0_ + hh, x0_:x0_ + ww] = a.reshape(hh, ww)
+            n_contrib[y0_:y0_ + hh, x0_:x0_ + ww] = nc.reshape(hh, ww).numpy()
     return color, depth, alpha_out, n_contrib
+
+
+def render_with_grads(pre, point_list, ranges, bg, H, W, wc, wd, wa):
+    """Forward AND the gradient of  L = sum(color*wc) + sum(depth*wd) + sum(alpha*wa)  with respect to the blend
+    inputs pre[BLEND_KEYS], one tile at a time (the autograd graph of a whole 1080p render of 2.6 M (splat, tile)
+    pairs does not fit in memory).  Same arithmetic as render(): blend_tile is the one implementation.
+    Returns (color, depth, alpha, n_contrib, grads) with grads[k] shaped like pre[k]."""
+    dt = pre["px"].dtype
+    gx, gy = pre["grid"]
+    color = torch.zeros(3, H, W, dtype=dt) + bg.to(dt)[:, None, None]
+    depth = torch.zeros(1, H, W, dtype=dt)
+    alpha_out = torch.zeros(1, H, W, dtype=dt)
+    n_contrib = np.zeros((H, W), dtype=np.int64)
+    grads = {k: torch.zeros_like(pre[k]) for k in BLEND_KEYS}
+    for ty in range(gy):
+        for tx in range(gx):
+            s, e = ranges[ty * gx + tx]
+            hh, ww, pxf, pyf = _tile_pixels(ty, tx, H, W, dt)
+            if e <= s or hh == 0 or ww == 0:
+                continue
+            ids = torch.from_numpy(point_list[s:e])
+            loc = [pre[k][ids].detach().requires_grad_(True) for k in BLEND_KEYS]
+            c, d, a, nc = blend_tile(*loc, pxf, pyf, bg)
+            y0_, x0_ = ty * TILE, tx * TILE
+            sl = (slice(y0_, y0_ + hh), slice(x0_, x0_ + ww))
+            loss = ((c.T.reshape(3, hh, ww) * wc[(slice(None),) + sl]).sum() + (d.reshape(hh, ww) * wd[(0,) + sl]).sum()
+                    + (a.reshape(hh, ww) * wa[(0,) + sl]).sum())
+            g = torch.autograd.grad(loss, loc, allow_unused=True)
+            for k, gk in zip(BLEND_KEYS, g):
+                if gk is not None:
+                    grads[k].index_add_(0, ids, gk)
+            color[(slice(None),) + sl] = c.detach().T.reshape(3, hh, ww)
+            depth[(0,) + sl] = d.detach().reshape(hh, ww)
+            alpha_out[(0,) + sl] = a.detach().reshape(hh, ww)
+            n_contrib[sl] = nc.reshape(hh, ww).numpy()
+    return color, depth, alpha_out, n_contrib, grads
 
 
 def rasterize(means3D, scales, rotations, opacities, shs, confidence, viewmatrix, projmatrix, campos, tanfovx, tanfovy,

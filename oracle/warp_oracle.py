@@ -104,6 +104,32 @@ def consistency_check_with_depth(depth1, pose1, K1, depth2, pose2, K2):
     return err.astype(f32)
 
 
+def reproj_border_band(depth1, pose1, K1, depth2, pose2, K2, margin=1.0):
+    """Pixels of consistency_check_with_depth whose bilinear sample of depth2 (consistency.py:71) has a tap on or
+    beyond the zero-padded border (within `margin` px of it): there a 1e-4 px rounding difference in the sample
+    position changes the sampled depth by O(depth) and the reprojection error by pixels.  Test helper: the
+    comparison of an fp32 implementation with this oracle is bounded hard everywhere else."""
+    depth1 = np.asarray(depth1, f32)
+    h, w = depth1.shape
+    pose1 = np.asarray(pose1, f32)
+    pose2 = np.asarray(pose2, f32)
+    xs, ys = np.meshgrid(np.arange(w, dtype=f32), np.arange(h, dtype=f32), indexing="xy")
+    K1inv = np.linalg.inv(np.asarray(K1, f32)).astype(f32)
+    px, py, pz = _apply3(K1inv, xs, ys, f32(1))
+    px, py, pz = px * depth1, py * depth1, pz * depth1
+    T12 = (pose2 @ np.linalg.inv(pose1)).astype(f32)
+    with np.errstate(all="ignore"):
+        ax, ay, az, aw = _apply4(T12, px, py, pz)
+        ix, iy, iz = _apply3(np.asarray(K2, f32), ax / aw, ay / aw, az / aw)
+        gx = (ix / iz) / (f32(w - 1) / f32(2)) - f32(1)
+        gy = (iy / iz) / (f32(h - 1) / f32(2)) - f32(1)
+        sx, sy = _unnormalize(gx, w), _unnormalize(gy, h)
+        m = f32(margin)
+        band = (np.abs(sx - 0) <= m) | (np.abs(sx - (w - 1)) <= m) | (np.abs(sy - 0) <= m) | (np.abs(sy - (h - 1)) <= m)
+        band |= (np.abs(sx + 1) <= m) | (np.abs(sx - w) <= m) | (np.abs(sy + 1) <= m) | (np.abs(sy - h) <= m)
+    return band | ~np.isfinite(sx) | ~np.isfinite(sy)
+
+
 def inverse_warp(img, depth, depth_pseudo, pose1, pose2, K, bandwidth=20):
     """forward_warp.py:187-279 -> dict of numpy arrays (same keys, bg mask omitted)."""
     img = np.asarray(img, f32)

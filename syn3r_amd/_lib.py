@@ -77,6 +77,7 @@ SIGNATURES = {
     "syn3r_l1_loss_workspace_bytes": (c_sz, [c_ll]),
     "syn3r_l1_loss": (c_i, [c_p, c_p, c_ll, c_f, c_p, c_p, c_sz, c_p]),
     "syn3r_l1_loss_backward": (c_i, [c_p, c_p, c_ll, c_f, c_p, c_p, c_p]),
+    "syn3r_image_mse": (c_i, [c_p, c_p, c_ll, c_p, c_p, c_sz, c_p]),
     "syn3r_photo_loss_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "syn3r_photo_loss": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_sz, c_p]),
     "syn3r_photo_loss_backward": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_p]),

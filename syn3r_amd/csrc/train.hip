@@ -18,6 +18,11 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxBlocks = 2048;
 
+// SQ = false: sum |a - b| (L1); SQ = true: sum (a - b)^2 (the MSE behind the PSNR of the metric record)
+template <bool SQ>
+__device__ __forceinline__ float dist_term(float d) { return SQ ? d * d : fabsf(d); }
+
+template <bool SQ>
 __global__ void __launch_bounds__(kThreads) k_l1_partial(const float* __restrict__ a, const float* __restrict__ b,
                                                         long long n, float* __restrict__ partial) {
     float s = 0.0f;
@@ -26,11 +31,11 @@ __global__ void __launch_bounds__(kThreads) k_l1_partial(const float* __restrict
     const float4* b4 = (const float4*)b;
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long long)gridDim.x * kThreads) {
         float4 x = a4[i], y = b4[i];
-        s += (fabsf(x.x - y.x) + fabsf(x.y - y.y)) + (fabsf(x.z - y.z) + fabsf(x.w - y.w));
+        s += (dist_term<SQ>(x.x - y.x) + dist_term<SQ>(x.y - y.y)) + (dist_term<SQ>(x.z - y.z) + dist_term<SQ>(x.w - y.w));
     }
     if (blockIdx.x == 0) {
         long long i = (n4 << 2) + threadIdx.x;
-        if (i < n) s += fabsf(a[i] - b[i]);
+        if (i < n) s += dist_term<SQ>(a[i] - b[i]);
     }
     s = wave_sum(s);
     __shared__ float ws[kThreads / 64];
@@ -255,9 +260,23 @@ extern "C" int syn3r_l1_loss(const float* image, const float* target, long long 
     SYN3R_REQUIRE(ws_bytes >= syn3r_l1_loss_workspace_bytes(n), "l1_loss: workspace too small");
     SYN3R_REQUIRE((((uintptr_t)image | (uintptr_t)target) & 15) == 0, "l1_loss: image/target must be 16-byte aligned");
     const int nb = l1_blocks(n);
-    SYN3R_LAUNCH(k_l1_partial, dim3(nb), dim3(kThreads), 0, stream, image, target, n, (float*)ws);
+    SYN3R_LAUNCH(k_l1_partial<false>, dim3(nb), dim3(kThreads), 0, stream, image, target, n, (float*)ws);
     SYN3R_LAUNCH(k_l1_final, dim3(1), dim3(kThreads), 0, stream, (const float*)ws, nb, weight / (float)n, loss);
     SYN3R_LAUNCH_CHECK("l1_loss launch");
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_image_mse(const float* image, const float* target, long long n, float* mse, void* ws,
+                               size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SYN3R_REQUIRE(n > 0, "image_mse: n must be positive");
+    SYN3R_REQUIRE(image && target && mse && ws, "image_mse: null pointer");
+    SYN3R_REQUIRE(ws_bytes >= syn3r_l1_loss_workspace_bytes(n), "image_mse: workspace too small");
+    SYN3R_REQUIRE((((uintptr_t)image | (uintptr_t)target) & 15) == 0, "image_mse: image/target must be 16-byte aligned");
+    const int nb = l1_blocks(n);
+    SYN3R_LAUNCH(k_l1_partial<true>, dim3(nb), dim3(kThreads), 0, stream, image, target, n, (float*)ws);
+    SYN3R_LAUNCH(k_l1_final, dim3(1), dim3(kThreads), 0, stream, (const float*)ws, nb, 1.0f / (float)n, mse);
+    SYN3R_LAUNCH_CHECK("image_mse launch");
     return SYN3R_OK;
 }
 

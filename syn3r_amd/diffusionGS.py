@@ -10,7 +10,7 @@ What runs where: the rasteriser behind `gsTrainer.render_view` / `training`, the
 scheduler steps are HIP kernels; poses, masks and the lambda schedule are host numerics (`syn3r_amd.orchestrator`).
 Everything stays on the device between stages (the reference round-trips through numpy and PNG files,
 diffusionGS.py:151-169,1447-1475).  Out of scope and therefore rejected: dust3r/GMFlow point-cloud densification
-(`num_views_for_pcd_densification > 1`, sources absent — SURVEY.md N2) and the forward-warp interpolation variant.
+(`num_views_for_pcd_densification > 1`, sources absent — SURVEY.md N2).
 CLIP and the temporal VAE are passed in as modules (`svd_components`), see `pipeline/svd_2pass.py`.
 """
 from __future__ import annotations
@@ -145,9 +145,9 @@ class DiffusionGS:
             _, im, dp = self.render_GS(pose=p)
             pseudo_images.append(_resize_linear(im.transpose([1, 2, 0]), Hd, Wd))
             pseudo_depths.append(_resize_linear(dp, Hd, Wd))
-        if self.interp_type != "backward_warp":
-            raise NotImplementedError("only --interp_type backward_warp (used by every shipped script) is implemented")
         rs = lambda x: _resize_nearest(x, Hd, Wd)
+        if self.interp_type == "forward_warp":
+            return self._finish_forward_warp(interpolated_poses, image1, image2, depth1, depth2, pseudo_images, replace)
         # warps, mask post-processing and the uncertainty fusion stay on the device: one
         # batched warp per end view + two post-processing launches; the condition images go to the pipeline as
         # device tensors
@@ -163,14 +163,40 @@ class DiffusionGS:
         cond_image = list(cond_dev.permute(0, 3, 1, 2))               # CHW in [0,1], as preprocess_images accepts
         lambda_ts = O.search_hypers_v2(masks, None, type="double_end", diffusion_steps=self.num_inference_steps)
         frames = self.svd_render(image_o, image_o2, masks, cond_image, None, lambda_ts, num_frames=len(interpolated_poses))
+        return self._frames_to_gs(frames, image_o, image_o2, replace), interpolated_poses, pseudo_images
+
+    def _frames_to_gs(self, frames, image_o, image_o2, replace):
+        """diffusionGS.py:909-916: end frames replaced by the input views, every frame resized to the GS resolution as
+        the reference's `PIL.Image.resize` does on uint8 frames (bicubic, with the area-scaled support PIL uses when
+        shrinking = `antialias=True`), CHW in [0,1]."""
         if replace:
             frames[0], frames[-1] = image_o, image_o2
         out = []
-        for fr in frames:                                             # back to the GS resolution, CHW in [0,1]
-            t = torch.from_numpy(np.ascontiguousarray(fr, dtype=np.float32)).permute(2, 0, 1)[None]
-            t = torch.nn.functional.interpolate(t, size=(self.gs_height, self.gs_width), mode="bicubic", align_corners=False)
-            out.append(t[0].clamp(0, 1))
-        return out, interpolated_poses, pseudo_images
+        for fr in frames:
+            u8 = np.clip(np.asarray(fr, dtype=np.float32) * 255.0, 0, 255).astype(np.uint8)      # PIL frames are uint8
+            t = torch.from_numpy(u8).permute(2, 0, 1)[None].float()
+            if t.shape[-2:] != (self.gs_height, self.gs_width):
+                t = torch.nn.functional.interpolate(t, size=(self.gs_height, self.gs_width), mode="bicubic",
+                                                    align_corners=False, antialias=True)
+                t = t.round().clamp(0, 255)                                                         # PIL rounds back to uint8
+            out.append(t[0] / 255.0)
+        return out
+
+    def _finish_forward_warp(self, interpolated_poses, image1, image2, depth1, depth2, pseudo_images, replace):
+        """`--interp_type forward_warp` (diffusionGS.py:814-815 -> warp_images, :1512).  In the reference this branch
+        cannot complete: both accepted diffusion types contain 'Prob', whose fusion block reads `aux[...]`, a name only
+        the backward-warp branch defines (:822 -> NameError).  Here the forward splat's own hard hole masks and masked
+        condition images go to the pipeline directly (the soft reprojection confidence the fusion needs does not exist
+        for a splat) — an extension, documented as such."""
+        Hd, Wd = self.diffusion_height, self.diffusion_width
+        image_o, image_o2, masks, cond_image = O.warp_images(
+            self.diffusion_intrinsics, interpolated_poses, _resize_linear(image1, Hd, Wd), _resize_linear(image2, Hd, Wd),
+            _resize_nearest(depth1, Hd, Wd), _resize_nearest(depth2, Hd, Wd), h=Hd // 8, w=Wd // 8)
+        masks = masks.float()
+        cond_image = [torch.from_numpy(np.ascontiguousarray(c)).permute(2, 0, 1) for c in cond_image]
+        lambda_ts = O.search_hypers_v2(masks, None, type="double_end", diffusion_steps=self.num_inference_steps)
+        frames = self.svd_render(image_o, image_o2, masks, cond_image, None, lambda_ts, num_frames=len(interpolated_poses))
+        return self._frames_to_gs(frames, image_o, image_o2, replace), interpolated_poses, pseudo_images
 
     def densify_views(self, cycle_num, down_sample_rate=1, densify_type="interpolate", num_views_for_pcd_densification=4):
         """diffusionGS.py:174-340 (view densification; point-cloud densification is out of scope)."""
@@ -207,21 +233,46 @@ class DiffusionGS:
 
     def refine_GS(self, dense_views, dense_poses, intrinsics, cam_confidence=0.01, gs_start_iter=0,
                   disable_densification=False, load_iteration=None, pseudo_cam_sampling_rate=1, load_ckpt=True):
-        """diffusionGS.py:1608-1643 (checkpoint reload omitted: the Gaussians stay resident)."""
-        self.gsTrainer.update_cameras(dense_views, dense_poses, intrinsics, cam_confidences=cam_confidence, append=True)
-        self.gsTrainer.reset_optimizers()
-        self.gsTrainer.reset_gs()
-        self.gsTrainer.finetune(0, self.refine_epoch, disable_densification=disable_densification,
-                                pseudo_cam_sampling_rate=pseudo_cam_sampling_rate)
+        """diffusionGS.py:1608-1643: reload the latest refined (else the initial) checkpoint, append the dense views to
+        the training cameras, finetune, restore the original cameras."""
+        import glob
+        tr = self.gsTrainer
+        model_path = getattr(tr.scene, "model_path", None)
+        if load_ckpt and model_path:
+            refine_ckpts = glob.glob(f"{model_path}/refine_*_chkpnt*.pth")
+            if len(refine_ckpts) > 0:
+                refine_ckpts = sorted(refine_ckpts, key=lambda x: int(os.path.basename(x).split("_")[1]))
+                tr.load_checkpoint(checkpoint=refine_ckpts[-1])                       # the latest refined GS
+            else:
+                checkpoint_path = None
+                if tr.checkpoint_iterations:
+                    checkpoint_path = os.path.join(model_path, "chkpnt" + str(tr.checkpoint_iterations[-1]) + ".pth")
+                if checkpoint_path is None or not os.path.exists(checkpoint_path):
+                    checkpoint_path = os.path.join(model_path, "chkpnt_latest.pth")
+                tr.load_checkpoint(checkpoint=checkpoint_path)                        # the initial GS
+        # the reference deep-copies scene.train_cameras (:1627); the camera objects are not mutated by a finetune, so
+        # copying the lists is enough to restore them (:1641)
+        self.original_GS_train_cameras_bak = {k: list(v) for k, v in tr.scene.train_cameras.items()}
+        tr.update_cameras(dense_views, dense_poses, intrinsics, cam_confidences=cam_confidence, append=True,
+                          load_iteration=load_iteration)
+        tr.reset_optimizers()
+        tr.reset_gs()
+        tr.finetune(0, self.refine_epoch, disable_densification=disable_densification,
+                    pseudo_cam_sampling_rate=pseudo_cam_sampling_rate)
+        tr.scene.train_cameras = self.original_GS_train_cameras_bak                   # restore the original GS cameras
         self.refine_epoch += 1
 
     def run(self, refine_cycles=1):
         """diffusionGS.py:1668-1697."""
         self.init_GS()
         for i in range(refine_cycles):
-            dense_views, dense_poses, _ = self.densify_views(
+            dense_views, dense_poses, dense_pcds = self.densify_views(
                 cycle_num=i, down_sample_rate=1, densify_type=self.densify_type,
                 num_views_for_pcd_densification=self.args.num_views_for_pcd_densification)
+            if dense_pcds is not None:                                                # :1683-1687
+                self.gsTrainer.reset_gaussians_from_pcd(dense_pcds, append_to_old_gaussians=(i != 0))
+            self.gsTrainer.opt.use_lpips_loss = True                                  # :1690
             self.refine_GS(dense_views=dense_views, dense_poses=dense_poses, intrinsics=self.gs_intrinsics,
                            cam_confidence=self.cam_confidence, load_iteration=None,
                            pseudo_cam_sampling_rate=self.pseudo_cam_sampling_rate, load_ckpt=(i > 0))
+            self.gsTrainer.opt.use_lpips_loss = False                                 # :1697

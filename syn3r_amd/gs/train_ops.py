@@ -86,6 +86,25 @@ def photometric_loss(image: torch.Tensor, target: torch.Tensor, lambda_dssim: fl
     return (loss, parts) if return_parts else loss
 
 
+def image_metrics(image: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """Device tensor [PSNR (dB, peak 1), SSIM] of two float32 [C,H,W] images in [0,1]: the MSE from `syn3r_image_mse`
+    (deterministic two-level sum) and the SSIM the fused photometric-loss kernel computes (published 3DGS window).
+    No host synchronisation."""
+    L.require_gpu(image, target)
+    image, target = image.detach().contiguous(), target.detach().contiguous()
+    if image.shape != target.shape or image.dim() != 3 or image.dtype != torch.float32:
+        raise ValueError("image_metrics: float32 [C,H,W] images of the same shape")
+    lib = L.load()
+    n = image.numel()
+    mse = torch.empty((), dtype=torch.float32, device=image.device)
+    ws = L.workspace(image.device, lib.syn3r_l1_loss_workspace_bytes(n), "l1")
+    L.check(lib.syn3r_image_mse(L.ptr(image), L.ptr(target), n, L.ptr(mse), L.ptr(ws), ws.numel(),
+                                L.stream_ptr(image.device)), "image_mse")
+    _, parts = _PhotoLoss.apply(image, target, 1.0, 1.0)
+    psnr = -10.0 * torch.log10(mse.clamp_min(1e-12))
+    return torch.stack([psnr, parts[2]])
+
+
 class FusedAdam:
     """`torch.optim.Adam(param_groups, eps=...)` (no weight decay / amsgrad) with one kernel per parameter tensor.
     Keeps torch's `param_groups` / `state` layout so checkpoints and lr schedules written for the torch optimiser

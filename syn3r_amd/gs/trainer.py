@@ -11,14 +11,17 @@ heuristics (out of scope).  Camera conventions follow the publishe
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
-from typing import List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
 
 from ..raster import GaussianRasterizationSettings, GaussianRasterizer
-from .train_ops import FusedAdam, l1_loss, photometric_loss
+from .train_ops import FusedAdam, image_metrics, l1_loss, photometric_loss
+
+SH_C0 = 0.28209479177387814
 
 
 def _world2view(R: np.ndarray, t: np.ndarray) -> np.ndarray:
@@ -51,6 +54,7 @@ class Camera:
         self.uid, self.colmap_id, self.image_name = uid, colmap_id, image_name
         self.R, self.T, self.FoVx, self.FoVy = np.asarray(R, np.float32), np.asarray(T, np.float32), FoVx, FoVy
         self.cam_confidence = float(cam_confidence)
+        self.is_pseudo = False           # set by GSTrainer.update_cameras for SVD pseudo-views
         self.data_device = torch.device(data_device)
         self.original_image = None
         if image is not None:
@@ -109,6 +113,51 @@ class GaussianModel:
     @property
     def get_features(self): return self._features
 
+    def capture(self) -> dict:
+        """Parameter tensors of a checkpoint (published 3DGS `GaussianModel.capture`, reduced to what this model holds)."""
+        return dict(active_sh_degree=self.active_sh_degree, xyz=self._xyz.detach().clone(),
+                    features=self._features.detach().clone(), scaling=self._scaling.detach().clone(),
+                    rotation=self._rotation.detach().clone(), opacity=self._opacity.detach().clone(),
+                    confidence=self.confidence.clone())
+
+    def restore(self, state: dict):
+        dev = self._xyz.device
+        p = lambda t: torch.nn.Parameter(t.to(dev, torch.float32).contiguous())
+        self._xyz, self._features, self._scaling = p(state["xyz"]), p(state["features"]), p(state["scaling"])
+        self._rotation, self._opacity = p(state["rotation"]), p(state["opacity"])
+        self.confidence = state["confidence"].to(dev)
+        self.active_sh_degree = int(state["active_sh_degree"])
+
+    def set_from_pcd(self, points: np.ndarray, colors: np.ndarray, append: bool):
+        """Published 3DGS `create_from_pcd`: DC colour = (rgb - 0.5) / C0, higher SH zero, isotropic scale =
+        sqrt(mean squared distance to the 3 nearest neighbours), identity rotation, opacity 0.1.  The reference does this
+        inside FSGS (`simple-knn` CUDA extension, absent); the k-NN here is a chunked `torch.cdist` on the device."""
+        dev = self._xyz.device
+        pts = torch.as_tensor(np.asarray(points), dtype=torch.float32, device=dev)
+        rgb = torch.as_tensor(np.asarray(colors), dtype=torch.float32, device=dev)
+        if pts.dim() != 2 or pts.shape[1] != 3 or rgb.shape != pts.shape:
+            raise ValueError("reset_gaussians_from_pcd: points and colours must both be [n,3]")
+        n = pts.shape[0]
+        d2 = torch.empty(n, device=dev)
+        for s0 in range(0, n, 4096):
+            d = torch.cdist(pts[s0:s0 + 4096], pts) ** 2
+            k = min(4, n)
+            d2[s0:s0 + 4096] = d.topk(k, dim=1, largest=False).values[:, 1:].mean(1) if k > 1 else 1e-4
+        scales = torch.log(torch.sqrt(d2.clamp_min(1e-7)))[:, None].repeat(1, 3)
+        M = self._features.shape[1]
+        feats = torch.zeros(n, M, 3, device=dev)
+        feats[:, 0] = (rgb - 0.5) / SH_C0
+        rots = torch.zeros(n, 4, device=dev)
+        rots[:, 0] = 1.0
+        opac = torch.full((n,), math.log(0.1 / 0.9), device=dev)
+        conf = torch.ones(n, device=dev)
+        cat = (lambda old, new: torch.cat([old.detach(), new])) if append else (lambda old, new: new)
+        p = lambda t: torch.nn.Parameter(t.contiguous())
+        self._xyz, self._features = p(cat(self._xyz, pts)), p(cat(self._features, feats))
+        self._scaling, self._rotation = p(cat(self._scaling, scales)), p(cat(self._rotation, rots))
+        self._opacity = p(cat(self._opacity, opac))
+        self.confidence = cat(self.confidence, conf)
+
     def to(self, device):
         """diffusionGS.py:901-907 moves the Gaussians off and back on the GPU around svd_render; with 288 GB of HBM
         nothing has to move — kept as a no-op-compatible method."""
@@ -131,21 +180,36 @@ class OptimizationParams:
     lambda_dssim: float = 0.2          # published 3DGS: L = (1 - lambda) L1 + lambda (1 - SSIM)
     pseudo_cam_sampling_rate: float = 0.02
     seed: int = 0
+    use_lpips_loss: bool = False       # toggled by DiffusionGS.run (diffusionGS.py:1690,1697); see GSTrainer.train_step
+    lpips_weight: float = 0.0
 
 
 class _Scene:
-    def __init__(self, cams): self._train = list(cams)
-    def getTrainCameras(self): return self._train
+    """The part of FSGS' `Scene` the orchestrator touches: `model_path` (checkpoint directory, diffusionGS.py:1611),
+    `train_cameras` ({resolution scale: [Camera]}; backed up and restored around a finetune, :1627,1641) and
+    `getTrainCameras()`.  Pseudo-views appended by `update_cameras` carry `is_pseudo`; `getTrainCameras` returns the
+    real input views, `getPseudoCameras` the appended ones."""
+
+    def __init__(self, cams, model_path: Optional[str] = None):
+        self.train_cameras: Dict[float, List[Camera]] = {1.0: list(cams)}
+        self.model_path = model_path
+
+    def getTrainCameras(self, scale: float = 1.0, ordered: bool = False):
+        return [c for c in self.train_cameras[scale] if not getattr(c, "is_pseudo", False)]
+
+    def getPseudoCameras(self, scale: float = 1.0):
+        return [c for c in self.train_cameras[scale] if getattr(c, "is_pseudo", False)]
 
 
 class GSTrainer:
     def __init__(self, gaussians: GaussianModel, train_cameras: Sequence[Camera], opt: Optional[OptimizationParams] = None,
-                 background=(0.0, 0.0, 0.0)):
+                 background=(0.0, 0.0, 0.0), model_path: Optional[str] = None,
+                 checkpoint_iterations: Optional[Sequence[int]] = None):
         self.gaussians, self.opt = gaussians, opt or OptimizationParams()
-        self.scene = _Scene(train_cameras)
-        self.pseudo_cameras: List[Camera] = []
+        self.scene = _Scene(train_cameras, model_path)
         self.dust3r = None
-        self.checkpoint_iterations: List[int] = []
+        self.checkpoint_iterations: List[int] = list(checkpoint_iterations or [])
+        self.iteration = 0
         self.background = torch.tensor(background, dtype=torch.float32, device=gaussians._xyz.device)
         self._rng = np.random.default_rng(self.opt.seed)
         self.reset_optimizers()
@@ -161,13 +225,91 @@ class GSTrainer:
     def reset_gs(self):
         return None
 
-    def update_cameras(self, views, poses, K, cam_confidences, append: bool = True):
-        """diffusionGS.py:1631 — register SVD pseudo-views ([3,H,W] tensors + w2c poses) with their confidence."""
+    @property
+    def pseudo_cameras(self) -> List[Camera]:
+        return self.scene.getPseudoCameras()
+
+    def update_cameras(self, views, poses, K, cam_confidences, append: bool = True, load_iteration=None):
+        """diffusionGS.py:1631 — register SVD pseudo-views ([3,H,W] tensors + w2c poses) with their confidence in
+        `scene.train_cameras` (appended, as the reference; the orchestrator restores the list after the finetune)."""
         if np.isscalar(cam_confidences):
             cam_confidences = [float(cam_confidences)] * len(views)
         cams = [Camera.from_w2c(np.asarray(p), np.asarray(K), v.shape[1], v.shape[2], image=v, cam_confidence=c,
                                 data_device=self.gaussians._xyz.device) for v, p, c in zip(views, poses, cam_confidences)]
-        self.pseudo_cameras = (self.pseudo_cameras + cams) if append else cams
+        for c in cams:
+            c.is_pseudo = True
+        for scale, lst in self.scene.train_cameras.items():
+            keep = list(lst) if append else [c for c in lst if not getattr(c, "is_pseudo", False)]
+            self.scene.train_cameras[scale] = keep + cams
+
+    # ---- checkpoints with the reference's file names (diffusionGS.py:1611-1625)
+    def _ckpt_dir(self) -> str:
+        if not self.scene.model_path:
+            raise RuntimeError("GSTrainer: scene.model_path is not set (checkpoints need a directory)")
+        os.makedirs(self.scene.model_path, exist_ok=True)
+        return self.scene.model_path
+
+    def save_checkpoint(self, iteration: int, refine_epoch: Optional[int] = None, latest: bool = False) -> str:
+        """`chkpnt{iteration}.pth` after the initial training, `refine_{epoch}_chkpnt{iteration}.pth` after a finetune,
+        `chkpnt_latest.pth` as the fallback the reference looks for: a `(capture, iteration)` tuple as published 3DGS."""
+        name = "chkpnt_latest.pth" if latest else (f"chkpnt{iteration}.pth" if refine_epoch is None
+                                                   else f"refine_{refine_epoch}_chkpnt{iteration}.pth")
+        path = os.path.join(self._ckpt_dir(), name)
+        torch.save((self.gaussians.capture(), int(iteration)), path)
+        return path
+
+    def load_checkpoint(self, checkpoint: str):
+        """diffusionGS.py:1618,1624 — restore the Gaussians from a checkpoint file; optimiser state starts afresh
+        (the orchestrator calls reset_optimizers right after, :1634)."""
+        state, it = torch.load(checkpoint, map_location=self.gaussians._xyz.device, weights_only=False)
+        self.gaussians.restore(state)
+        self.iteration = int(it)
+        self.reset_optimizers()
+
+    def reset_gaussians_from_pcd(self, pcd, append_to_old_gaussians: bool = False):
+        """diffusionGS.py:1685-1687 — re-initialise (or extend) the Gaussians from a dense point cloud: an object with
+        `.points` / `.colors` (open3d) or a (points [n,3], colours [n,3] in [0,1]) pair."""
+        if hasattr(pcd, "points"):
+            pts, col = np.asarray(pcd.points), np.asarray(pcd.colors)
+        else:
+            pts, col = pcd
+        self.gaussians.set_from_pcd(pts, col, append=append_to_old_gaussians)
+        self.reset_optimizers()
+
+    def find_nearest_cam(self, cams: Sequence[Camera], candidates: Sequence[Camera], multi_view_max_angle: float = 30.0,
+                         multi_view_min_dis: float = 0.01, multi_view_max_dis: float = 1.5, multi_view_num: int = 8):
+        """diffusionGS.py:475-477 (only reached from the dead `_extrapolate_from_gs`; FSGS source absent, so this follows
+        the public multi-view neighbour selection it is named after — UNPINNED): for every camera the candidates
+        whose viewing direction is within `multi_view_max_angle` degrees and whose centre is within
+        [min_dis, max_dis], nearest first; stored as `cam.nearest_id` and returned."""
+        out = []
+        c_pos = np.stack([c.camera_center.detach().cpu().numpy() for c in candidates]) if len(candidates) else np.zeros((0, 3))
+        c_dir = np.stack([np.asarray(c.R)[:, 2] for c in candidates]) if len(candidates) else np.zeros((0, 3))
+        for cam in cams:
+            pos, d = cam.camera_center.detach().cpu().numpy(), np.asarray(cam.R)[:, 2]
+            dis = np.linalg.norm(c_pos - pos[None], axis=1)
+            cosang = np.clip(c_dir @ d / (np.linalg.norm(c_dir, axis=1) * np.linalg.norm(d) + 1e-12), -1, 1)
+            ang = np.degrees(np.arccos(cosang))
+            ok = (ang < multi_view_max_angle) & (dis > multi_view_min_dis) & (dis < multi_view_max_dis)
+            order = [int(i) for i in np.argsort(dis) if ok[i]][:multi_view_num]
+            cam.nearest_id = order
+            out.append(order)
+        return out
+
+    def evaluate(self, cams: Optional[Sequence[Camera]] = None) -> dict:
+        """PSNR / SSIM of the current Gaussians over held-out (or the training) cameras, computed on the device
+        (`train_ops.image_metrics`): the psnr / ssim columns of the per-scene record (SURVEY.md §8e;
+        scripts/summarize_dl3dv.py:11-80 tabulates them).  LPIPS needs the pretrained VGG weights (absent offline):
+        reported as NaN."""
+        cams = list(cams) if cams is not None else self.scene.getTrainCameras()
+        ps, ss = [], []
+        with torch.no_grad():
+            for cam in cams:
+                m = image_metrics(self.render_view(cam)["render"].clamp(0, 1), cam.original_image)
+                ps.append(m[0])
+                ss.append(m[1])
+        p, s_ = torch.stack(ps).mean(), torch.stack(ss).mean()
+        return {"psnr": float(p), "ssim": float(s_), "lpips": float("nan"), "n": len(cams)}
 
     def render_view(self, cam: Camera, scaling_modifier: float = 1.0):
         """-> {'render' [3,H,W], 'depth' [1,H,W], 'alpha' [1,H,W], ...} (diffusionGS.py:154-172)."""
@@ -185,12 +327,17 @@ class GSTrainer:
                 "visibility_filter": radii > 0, "radii": radii}
 
     def _pick_camera(self) -> Camera:
-        if self.pseudo_cameras and self._rng.random() < self.opt.pseudo_cam_sampling_rate:
-            return self.pseudo_cameras[int(self._rng.integers(len(self.pseudo_cameras)))]
+        pseudo = self.scene.getPseudoCameras()
+        if pseudo and self._rng.random() < self.opt.pseudo_cam_sampling_rate:
+            return pseudo[int(self._rng.integers(len(pseudo)))]
         cams = self.scene.getTrainCameras()
         return cams[int(self._rng.integers(len(cams)))]
 
-    def train_step(self, cam: Optional[Camera] = None) -> float:
+    def train_step(self, cam: Optional[Camera] = None) -> torch.Tensor:
+        """One optimisation step; returns the loss as a DEVICE scalar (no host synchronisation: the loop queues
+        iterations back to back, `float(loss)` is the caller's choice).  `opt.use_lpips_loss` (set by the orchestrator
+        around refine_GS, diffusionGS.py:1690,1697) is accepted but inert: the LPIPS term of FSGS' loss needs the
+        pretrained VGG weights, which are not reachable offline (DESIGN.md out of scope)."""
         cam = cam or self._pick_camera()
         out = self.render_view(cam)
         if self.opt.lambda_dssim > 0.0:
@@ -200,19 +347,49 @@ class GSTrainer:
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.optimizer.step()
-        return float(loss.detach())
+        self.iteration += 1
+        return loss.detach()
+
+    def _loop(self, first_iter: int, n: int) -> float:
+        from .. import raster
+        prev = raster.get_pair_count_mode()
+        # async mode sizes the binning buffer from earlier renders of the same (N, H, W): one exact (sync) render per
+        # camera first, so the capacity covers the view with the most (Gaussian, tile) pairs with 1.5x headroom
+        raster.set_pair_count_mode("sync")
+        if n > first_iter:
+            with torch.no_grad():
+                for cam in self.scene.train_cameras[1.0]:
+                    self.render_view(cam)
+        raster.set_pair_count_mode("async")          # no host round trip per render inside the loop
+        last = None
+        try:
+            for _ in range(first_iter, n):
+                last = self.train_step()
+            raster.flush_pair_checks()               # every render's pair list was complete (raises otherwise)
+        finally:
+            raster.set_pair_count_mode(prev)
+        return float(last) if last is not None else 0.0     # ONE synchronisation, at the end of the loop
 
     def training(self, first_iter: int = 0, epoch_indicator: int = 0, iterations: Optional[int] = None):
-        """HOT LOOP A (diffusionGS.py:139): `opt.iterations` optimisation steps."""
+        """HOT LOOP A (diffusionGS.py:139): `opt.iterations` optimisation steps, then the checkpoints the
+        orchestrator's refine_GS looks for (`chkpnt{N}.pth` for the configured checkpoint iterations, else
+        `chkpnt_latest.pth`, diffusionGS.py:1620-1624) when `scene.model_path` is set."""
         n = iterations if iterations is not None else self.opt.iterations
-        last = 0.0
-        for _ in range(first_iter, n):
-            last = self.train_step()
+        last = self._loop(first_iter, n)
+        if self.scene.model_path:
+            if self.checkpoint_iterations:
+                self.save_checkpoint(self.checkpoint_iterations[-1])
+            self.save_checkpoint(n, latest=True)
         return last
 
     def finetune(self, first_iter: int = 0, refine_epoch: int = 0, disable_densification: bool = True,
                  pseudo_cam_sampling_rate: Optional[float] = None, iterations: Optional[int] = None):
-        """diffusionGS.py:1640 — same loop, now also sampling the confidence-weighted pseudo-views."""
+        """diffusionGS.py:1640 — same loop, now also sampling the confidence-weighted pseudo-views; writes
+        `refine_{epoch}_chkpnt{N}.pth` (the file the next cycle's refine_GS reloads, :1611-1618)."""
         if pseudo_cam_sampling_rate is not None:
             self.opt.pseudo_cam_sampling_rate = pseudo_cam_sampling_rate
-        return self.training(first_iter, refine_epoch, iterations)
+        n = iterations if iterations is not None else self.opt.iterations
+        last = self._loop(first_iter, n)
+        if self.scene.model_path:
+            self.save_checkpoint(n, refine_epoch=refine_epoch)
+        return last

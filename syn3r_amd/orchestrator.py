@@ -18,7 +18,7 @@ from scipy.spatial.transform import Rotation as R
 from scipy.spatial.transform import Slerp
 
 from . import _lib as L
-from .solver_utils.forward_warp import inverse_warp, inverse_warp_batch
+from .solver_utils.forward_warp import forward_warp, inverse_warp, inverse_warp_batch
 
 
 def pose_interpolation(pose_start: np.ndarray, pose_end: np.ndarray, num: int = 25) -> np.ndarray:
@@ -164,6 +164,38 @@ def warp_images_bw(intrinsics: np.ndarray, interpolated_poses: Sequence[np.ndarr
                soft_masks_reproj_ori=d["soft_masks_reproj_ori"].cpu().numpy(),
                cond_images_ori=list(d["cond_images_ori"].cpu().numpy()))
     return (image_l / 255.0, image_r / 255.0, d["masks"].cpu().to(torch.float64), list(d["cond_image"].cpu().numpy()), aux)
+
+
+def warp_images(intrinsics: np.ndarray, interpolated_poses: Sequence[np.ndarray], image_l: np.ndarray,
+                image_r: Optional[np.ndarray] = None, depth_l: Optional[np.ndarray] = None,
+                depth_r: Optional[np.ndarray] = None, h: int = 72, w: int = 128):
+    """diffusionGS.py:1512-1606 — the FORWARD-warp variant (`--interp_type forward_warp`, the constructor default):
+    every interior pose receives the nearer end view splatted forward (`syn3r_forward_warp`, fp64, HIP), holes are the
+    complement of the splat mask, dilated 5x5, pooled to the latent grid and thresholded at 0.2; the condition image is
+    the uint8 warped frame with the dilated holes zeroed.  Images (H,W,3) in [0,255] at the diffusion resolution.
+    Returns (image_l/255, image_r/255 or None, masks [n,h,w] float64 tensor, cond_image list) as the reference."""
+    n_pose = len(interpolated_poses)
+    interp_num = n_pose - 1
+    if image_r is not None:
+        interp_num -= 1
+    K = np.asarray(intrinsics, dtype=np.float64)
+    cond_image, masks = [], []
+    for i in range(interp_num):
+        left = image_r is None or i < 12
+        image, depth, pose_s = (image_l, depth_l, interpolated_poses[0]) if left else (image_r, depth_r, interpolated_poses[-1])
+        warped, mask2, _ = forward_warp(np.asarray(image, dtype=np.float64), None, np.asarray(depth, dtype=np.float64),
+                                        np.asarray(pose_s, dtype=np.float64), np.asarray(interpolated_poses[i + 1], dtype=np.float64),
+                                        K, None)
+        mask = (1 - mask2.astype(np.float64) >= 0.5).astype(np.float64)
+        mask = np.repeat(mask[:, :, None] * 255.0, 3, axis=2)
+        ero = np.uint8(dilate5x5(mask)) / 255.0
+        ero = (ero >= 0.5).astype(np.float64)
+        frame = np.uint8(np.uint8(warped) * (1 - ero))
+        cond_image.append(np.asarray(frame, dtype=np.float32) / 255.0)
+        pooled = block_mean_pool(np.mean(ero, axis=-1), h, w)
+        masks.append(torch.from_numpy((pooled >= 0.2).astype(np.float64)).unsqueeze(0))
+    masks = torch.cat(masks)
+    return image_l / 255.0, (image_r / 255.0 if image_r is not None else None), masks, cond_image
 
 
 def fuse_uncertainty_device(cond_images_ori: torch.Tensor, gs_images, soft_masks_reproj_ori: torch.Tensor,

@@ -73,6 +73,10 @@ def set_pair_count_mode(mode: str) -> None:
     _pair_mode = mode
 
 
+def get_pair_count_mode() -> str:
+    return _pair_mode
+
+
 def _check_pending(key, wait: bool):
     """Examine finished renders of this shape (all of them if `wait`), oldest first; never blocks the host
     unless asked to or more than 8 renders are unchecked."""

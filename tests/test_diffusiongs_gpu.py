@@ -35,10 +35,27 @@ def build(gpu, tmp_path, iterations=20):
     cams = [Camera.from_w2c(p, K, H, W, image=v, data_device=gpu) for p, v in zip(poses, views)]
     m2 = m + 0.01 * torch.randn_like(m)
     gm = GaussianModel(m2, torch.log(s), q, logit, sh, device=gpu)
-    trainer = GSTrainer(gm, cams, OptimizationParams(iterations=iterations))
+    trainer = GSTrainer(gm, cams, OptimizationParams(iterations=iterations), model_path=str(tmp_path / "model"),
+                        checkpoint_iterations=[iterations])
     args = SimpleNamespace(cam_confidence=0.05, pseudo_cam_sampling_rate=0.5, fps_keyframe_sampling=0,
                            densify_type="interpolate_gs_v2", num_views_for_pcd_densification=1)
     return trainer, args
+
+
+def _spy_finetune(trainer):
+    """record what the trainer sees at the start of every finetune"""
+    seen = dict(pseudo=[], conf=[], lpips=[], xyz=[])
+    orig = trainer.finetune
+
+    def finetune(*a, **k):
+        seen["pseudo"].append(len(trainer.pseudo_cameras))
+        seen["conf"].append(trainer.pseudo_cameras[0].cam_confidence if trainer.pseudo_cameras else None)
+        seen["lpips"].append(trainer.opt.use_lpips_loss)
+        seen["xyz"].append(trainer.gaussians._xyz.detach().clone())
+        return orig(*a, **k)
+
+    trainer.finetune = finetune
+    return seen
 
 
 def test_run_without_svd_is_plain_training(gpu, tmp_path):
@@ -62,13 +79,57 @@ def test_one_refine_cycle_with_mock_svd(gpu, tmp_path):
     d = DiffusionGS(trainer, num_input_views=3, save_dir=str(tmp_path), diffusion_type="2PassProbUncertain",
                     interp_type="backward_warp", input_args=args, svd_components=comps, num_inference_steps=2)
     np.random.seed(0)
+    seen = _spy_finetune(trainer)
     d.run(refine_cycles=1)
     files = sorted(p.name for p in tmp_path.iterdir() if p.suffix == ".pt")
     assert files == [f"dense_viewsinterpolated_dense_views_cyc0_view{i}.pt" for i in range(3)]   # reference artefact names
     data = torch.load(tmp_path / files[0], weights_only=False)
     assert len(data["views"]) == 25 and len(data["poses"]) == 25 and data["views"][3].shape == (3, 72, 128)
-    assert len(trainer.pseudo_cameras) == 3 * 24 and trainer.pseudo_cameras[0].cam_confidence == 0.05
+    # the pseudo-views are registered for the finetune and removed again afterwards (diffusionGS.py:1627,1641)
+    assert seen["pseudo"] == [3 * 24] and seen["conf"] == [0.05] and len(trainer.pseudo_cameras) == 0
+    assert len(trainer.scene.getTrainCameras()) == 3
     assert d.refine_epoch == 1
+    model = tmp_path / "model"
+    assert sorted(p.name for p in model.iterdir()) == ["chkpnt5.pth", "chkpnt_latest.pth", "refine_0_chkpnt5.pth"]
     args.num_views_for_pcd_densification = 4
     with pytest.raises(NotImplementedError):
         d.densify_views(1, densify_type="interpolate_gs_v2", num_views_for_pcd_densification=4)
+
+
+def test_two_refine_cycles_reload_and_reset_cameras(gpu, tmp_path):
+    """--refine_cycle_num 2 (every shipped script): cycle 2 fine-tunes on cycle 2's pseudo-views only (the reference
+    restores scene.train_cameras after each finetune, diffusionGS.py:1627,1641) and starts from the checkpoint cycle 1
+    wrote (`refine_0_chkpnt*.pth`, :1611-1618); `use_lpips_loss` is raised around each refine (:1690,1697)."""
+    from syn3r_amd.diffusionGS import DiffusionGS
+    trainer, args = build(gpu, tmp_path, iterations=4)
+    args.densify_type = "interpolate_loop0_gs"          # config 3's mode: open chain, last pair skipped (:244-247,286-290)
+    comps = dict(vae=PM.MockVAE(), image_encoder=PM.MockImageEncoder(), unet=PM.MockUNet().to(gpu), dtype=torch.float32)
+    d = DiffusionGS(trainer, num_input_views=3, save_dir=str(tmp_path), diffusion_type="2PassProbUncertain",
+                    interp_type="backward_warp", input_args=args, svd_components=comps, num_inference_steps=2)
+    np.random.seed(1)
+    seen = _spy_finetune(trainer)
+    d.run(refine_cycles=2)
+    # open chain of 3 views: pairs (0,1), (1,2); 24 frames each + the final end view
+    assert seen["pseudo"] == [2 * 24 + 1, 2 * 24 + 1] and seen["lpips"] == [True, True]
+    assert trainer.opt.use_lpips_loss is False and len(trainer.pseudo_cameras) == 0 and d.refine_epoch == 2
+    files = sorted(p.name for p in tmp_path.iterdir() if p.suffix == ".pt")
+    assert files == [f"dense_viewsinterpolated_dense_views_cyc{c}_view{i}.pt" for c in range(2) for i in range(2)]
+    names = sorted(p.name for p in (tmp_path / "model").iterdir())
+    assert names == ["chkpnt4.pth", "chkpnt_latest.pth", "refine_0_chkpnt4.pth", "refine_1_chkpnt4.pth"]
+    # cycle 2 started from the Gaussians cycle 1's finetune saved
+    state, it = torch.load(tmp_path / "model" / "refine_0_chkpnt4.pth", weights_only=False)
+    assert torch.equal(state["xyz"].to(gpu), seen["xyz"][1]) and it == 4
+
+
+def test_forward_warp_interp_type_runs(gpu, tmp_path):
+    """`--interp_type forward_warp` (the constructor default; W1 kernel through orchestrator.warp_images)."""
+    from syn3r_amd.diffusionGS import DiffusionGS
+    trainer, args = build(gpu, tmp_path, iterations=3)
+    comps = dict(vae=PM.MockVAE(), image_encoder=PM.MockImageEncoder(), unet=PM.MockUNet().to(gpu), dtype=torch.float32)
+    d = DiffusionGS(trainer, num_input_views=3, save_dir=str(tmp_path), diffusion_type="2PassProbUncertainPost",
+                    input_args=args, svd_components=comps, num_inference_steps=2)
+    assert d.interp_type == "forward_warp"
+    np.random.seed(2)
+    frames, poses, pseudo = d._interpolate_between_gs_v3(0, 1, replace=True, perturb_interp_poses=False)
+    assert len(frames) == 25 and len(poses) == 25 and frames[5].shape == (3, 72, 128)
+    assert all(torch.isfinite(f).all() and float(f.min()) >= 0 and float(f.max()) <= 1 for f in frames)

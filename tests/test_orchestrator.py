@@ -61,3 +61,39 @@ def test_perturb_candidates_match_reference(golden_dir):
     assert cands.shape == (7, 6, 4, 4) and cands.dtype == np.float32
     np.testing.assert_allclose(cands, g["perturbed"], atol=1e-6)
     np.testing.assert_array_equal(cands[:, 0], anchors)          # candidate 0 is the unperturbed anchor
+
+
+def test_host_helpers_match_independent_oracle():
+    """O3/O5 host numerics (dilate5x5, block_mean_pool, fuse_uncertainty) against oracle/orchestrator_oracle.py:
+    scipy.ndimage maximum filter / explicit block loops — a second implementation that shares no code with the product."""
+    from oracle import orchestrator_oracle as OO
+    rng = np.random.default_rng(5)
+    for shape in ((48, 64), (40, 72, 3), (17, 23)):
+        m = (rng.uniform(size=shape) > 0.93).astype(np.float64) * 255.0
+        m[0] = 255.0
+        m[:, -1] = 0.0
+        assert np.array_equal(O.dilate5x5(m), OO.dilate5x5(m))
+    x = rng.uniform(size=(48, 64)).astype(np.float32)
+    assert np.allclose(O.block_mean_pool(x, 6, 8), OO.block_mean_pool(x, 6, 8), rtol=0, atol=1e-7)
+    n, H, W, h, w = 3, 48, 64, 6, 8
+    warped = rng.uniform(0, 1, (n, H, W, 3)).astype(np.float32)
+    warped[:, :4] = 0.0
+    gs = np.clip(warped + rng.normal(0, 0.25, warped.shape), -0.1, 1.1).astype(np.float32)
+    soft = rng.uniform(0, 1, (n, H, W)).astype(np.float32)
+    m1, c1, u1 = O.fuse_uncertainty(warped, gs, soft, h=h, w=w)
+    m2, c2, u2 = OO.fuse_uncertainty(warped, gs, soft, h=h, w=w)
+    assert np.abs(m1.numpy() - m2).max() < 1e-6 and np.array_equal(u1, u2)
+    assert all(np.array_equal(a, b) for a, b in zip(c1, c2))
+
+
+def test_oracle_resize_semantics():
+    """cv2.resize restatements used by the oracle: INTER_LINEAR is pixel-centre aligned (identity at equal size, exact on
+    linear ramps in the interior), INTER_NEAREST picks floor(dst * scale)."""
+    from oracle import orchestrator_oracle as OO
+    x = np.arange(12, dtype=np.float32).reshape(3, 4)
+    assert np.array_equal(OO.resize_linear(x, 3, 4), x)
+    ramp = np.tile(np.arange(8, dtype=np.float32), (4, 1))
+    up = OO.resize_linear(ramp, 4, 16)
+    assert np.allclose(up[0, 1:-1], (np.arange(16)[1:-1] + 0.5) * 0.5 - 0.5)
+    assert np.array_equal(OO.resize_nearest(ramp, 4, 16)[0], np.arange(16) // 2)
+    assert np.array_equal(OO.resize_nearest(ramp, 2, 4)[0], np.array([0, 2, 4, 6], dtype=np.float32))

@@ -46,7 +46,8 @@ def test_render_view_and_one_adam_step_match_oracle(gpu):
     loss_o.backward()
     opt.step()
     loss_h = tr.train_step(cam)
-    assert abs(loss_h - float(loss_o)) < 1e-4
+    assert torch.is_tensor(loss_h) and loss_h.is_cuda          # no host synchronisation inside the step
+    assert abs(float(loss_h) - float(loss_o)) < 1e-4
     for a, b in zip(gm.parameters(), P):
         # Adam's first step is lr * sign(grad): identical wherever the gradient sign is unambiguous
         d = (a.detach().cpu().double() - b.detach()).abs()
@@ -62,7 +63,7 @@ def test_training_loop_fits_a_view(gpu):
     gm, _ = make_scene(N, H, W, 12, gpu)            # different Gaussians
     cam = Camera.from_w2c(np.eye(4, dtype=np.float32), K, H, W, image=target, data_device=gpu)
     tr = GSTrainer(gm, [cam], OptimizationParams(iterations=150, position_lr=2e-3))
-    first = tr.train_step(cam)
+    first = float(tr.train_step(cam))
     last = tr.training(0, 0)
     assert last < 0.6 * first, (first, last)
     k, w2c = cam.get_calib_matrix_nerf()
@@ -70,3 +71,52 @@ def test_training_loop_fits_a_view(gpu):
     tr.update_cameras([target], [np.eye(4, dtype=np.float32)], K, [0.05])
     assert len(tr.pseudo_cameras) == 1 and tr.pseudo_cameras[0].cam_confidence == 0.05
     tr.finetune(0, 1, iterations=3, pseudo_cam_sampling_rate=1.0)
+
+
+def test_checkpoints_pcd_reset_metrics_and_neighbours(gpu, tmp_path):
+    """Trainer surface the orchestrator consumes beyond render/train (diffusionGS.py:1611-1625,1685-1687,475-477)."""
+    from syn3r_amd.gs import Camera, GSTrainer, OptimizationParams
+    from syn3r_amd.gs.train_ops import image_metrics
+    N, H, W = 600, 48, 64
+    gm, K = make_scene(N, H, W, 21, gpu)
+    cam0 = Camera.from_w2c(np.eye(4, dtype=np.float32), K, H, W, data_device=gpu)
+    target = GSTrainer(gm, [cam0]).render_view(cam0)["render"].detach().clamp(0, 1)
+    p1 = np.eye(4, dtype=np.float32)
+    p1[0, 3] = 0.2
+    cams = [Camera.from_w2c(np.eye(4, dtype=np.float32), K, H, W, image=target, data_device=gpu),
+            Camera.from_w2c(p1, K, H, W, image=target, data_device=gpu)]
+    tr = GSTrainer(gm, cams, OptimizationParams(iterations=3), model_path=str(tmp_path), checkpoint_iterations=[3])
+    tr.training(0, 0)
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["chkpnt3.pth", "chkpnt_latest.pth"]
+    saved = gm._xyz.detach().clone()
+    tr.training(0, 0, iterations=2)
+    assert not torch.equal(saved, gm._xyz.detach())
+    tr.load_checkpoint(str(tmp_path / "chkpnt3.pth"))
+    assert torch.equal(saved, tr.gaussians._xyz.detach()) and tr.iteration == 3 and tr.optimizer.state == {}
+    assert tr.finetune(0, 1, iterations=2) >= 0 and (tmp_path / "refine_1_chkpnt2.pth").exists()
+    # metrics on the device vs their definitions
+    g = torch.Generator().manual_seed(4)
+    a, b = torch.rand(3, H, W, generator=g).to(gpu), torch.rand(3, H, W, generator=g).to(gpu)
+    m = image_metrics(a, b)
+    from tests.test_train_ops_gpu import _published_ssim
+    assert abs(float(m[0]) - float(-10 * torch.log10(((a - b) ** 2).mean()))) < 1e-4
+    assert abs(float(m[1]) - float(_published_ssim(a.cpu().double(), b.cpu().double()))) < 1e-5
+    ev = tr.evaluate()
+    assert ev["n"] == 2 and np.isfinite(ev["psnr"]) and 0 < ev["ssim"] <= 1 and np.isnan(ev["lpips"])
+    # point-cloud re-initialisation (published create_from_pcd): replace, then append
+    rng = np.random.default_rng(0)
+    pts, col = rng.uniform(-1, 1, (500, 3)).astype(np.float32) + [0, 0, 4], rng.uniform(0, 1, (500, 3)).astype(np.float32)
+    tr.reset_gaussians_from_pcd((pts, col), append_to_old_gaussians=False)
+    g2 = tr.gaussians
+    assert g2._xyz.shape == (500, 3) and g2._features.shape == (500, 16, 3) and g2.confidence.shape == (500,)
+    d = np.sort(((pts[:, None] - pts[None]) ** 2).sum(-1), axis=1)[:, 1:4].mean(1)
+    np.testing.assert_allclose(g2.get_scaling[:, 0].detach().cpu().numpy(), np.sqrt(d), rtol=2e-3)
+    np.testing.assert_allclose(g2._features[:, 0].detach().cpu().numpy(), (col - 0.5) / 0.28209479177387814, atol=1e-5)
+    assert float(g2.get_opacity[0]) == pytest.approx(0.1, abs=1e-6) and float(g2._features[:, 1:].abs().max()) == 0
+    tr.reset_gaussians_from_pcd((pts[:100], col[:100]), append_to_old_gaussians=True)
+    assert tr.gaussians._xyz.shape == (600, 3)
+    out = tr.render_view(cams[0])
+    assert torch.isfinite(out["render"]).all()
+    tr.train_step(cams[0])                                   # the optimiser was rebuilt for the new tensors
+    nn = tr.find_nearest_cam([cams[0]], cams, multi_view_max_angle=30, multi_view_min_dis=0.01, multi_view_max_dis=1.5)
+    assert nn == [[1]] and cams[0].nearest_id == [1]

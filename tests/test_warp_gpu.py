@@ -48,17 +48,23 @@ def test_reproj_error_vs_oracle_and_golden(name, gpu, golden_dir):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
     err = consistency_check_with_depth(t(c["depth_pseudo"]), t(c["pose2"]), t(c["K"]), t(c["depth"]), t(c["pose1"]),
                                        t(c["K"])).cpu().numpy()
-    ref = WO.consistency_check_with_depth(c["depth_pseudo"], c["pose2"], c["K"], c["depth"], c["pose1"], c["K"])
+    args = (c["depth_pseudo"], c["pose2"], c["K"], c["depth"], c["pose1"], c["K"])
+    ref = WO.consistency_check_with_depth(*args)
     fin = np.isfinite(ref)
     assert np.array_equal(fin, np.isfinite(err))
-    # taps that straddle the zero-padded border turn a 1e-4 px rounding difference into pixels of error:
-    # allow that for the border band only (<0.3 % of the image)
-    assert_mostly_close(err[fin], ref[fin], atol=2e-3, rtol=1e-4, max_frac=3e-3)
+    # A bilinear tap that straddles the zero-padded border turns a 1e-4 px rounding difference of the sample position
+    # into pixels of error.  That band is identified from the sample positions (oracle helper) and is the ONLY place
+    # where an unbounded difference is accepted; everywhere else the error is bounded hard.
+    band = WO.reproj_border_band(*args)
+    assert band.mean() < (0.02 if c["H"] >= 256 else 0.15)      # two-pixel frames of the 64x96 cases are 9-12 %
+    inner = fin & ~band
+    assert_mostly_close(err[inner], ref[inner], atol=2e-3, rtol=1e-4, max_frac=1e-3, hard=5e-2)
+    assert_mostly_close(err[fin & band], ref[fin & band], atol=2e-3, rtol=1e-4, max_frac=0.5)
     g = np.load(golden_dir / f"warp_{name}.npz")["reproj_error"]
     sy, sx = c["stride"]
-    e = err[::sy, ::sx]
+    e, b = err[::sy, ::sx], band[::sy, ::sx]
     fin = np.isfinite(g)
-    assert_mostly_close(e[fin], g[fin], atol=2e-3, rtol=1e-4, max_frac=3e-3)
+    assert_mostly_close(e[fin & ~b], g[fin & ~b], atol=2e-3, rtol=1e-4, max_frac=1e-3, hard=5e-2)
 
 
 def test_inverse_warp_batch_matches_single(gpu):
