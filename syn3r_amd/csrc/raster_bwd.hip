@@ -6,10 +6,11 @@
 // reference CUDA source absent).  Gradients are validated against autograd
 // through oracle/raster_oracle.py.
 //
-// MI355X mapping: each wavefront owns an 8 x 8 pixel quadrant of the tile and walks only the splats that can
-// reach alpha >= 1/255 on that quadrant (splat_reaches_rect, raster_common.h).  Per visited splat the up to 64
-// pixel contributions to 10 quantities are summed by reduce12 (two half/row swap levels + DPP row rotates,
-// 30 VALU instructions), accumulated per (tile, splat) in LDS across the four wavefronts, and flushed with
+// MI355X mapping: each wavefront owns a 16 x 8 pixel half of the tile, two pixels per lane on packed fp32
+// arithmetic, and walks only the splats that can reach alpha >= 1/255 on that half (splat_reaches_rect,
+// raster_common.h).  Per visited splat the up to 128 pixel contributions to 10 quantities are summed by
+// reduce12 (two half/row swap levels + DPP row rotates,
+// 30 VALU instructions), accumulated per (tile, splat) in LDS across the two wavefronts, and flushed with
 // ONE atomic per record slot onto a contiguous 64-byte gradient record (MI355X float atomics want
 // contiguous segments, MI355X_MICROARCH.md "Global float atomics").
 #include "common.h"
@@ -63,40 +64,53 @@ __device__ __forceinline__ float reduce12(float (&v)[12], int lane) {
     return c == 0 ? w3[0] : (c == 1 ? w3[1] : w3[2]);
 }
 
-// value index -> slot of the 64-byte gradient record, for the lane layout reduce12 returns:
-// row 0 (lower half, even row) owns v[0..2], row 1 owns v[3..5], row 2 owns v[6..8], row 3 owns v[9..11]
-__global__ void __launch_bounds__(kTilePix) k_render_bwd(
+// ---------------------------------------------------------------------------------------------
+// Blend backward, two pixels per lane.
+//
+// A 16 x 16 tile is a block of TWO wavefronts; wavefront w owns the 16 x 8 half (rows 8w .. 8w+7) and lane l the
+// pixels (l & 15, 8w + (l >> 4)) and (l & 15, 8w + (l >> 4) + 4).  Every per-pixel quantity is a float2 and the
+// arithmetic is written on float2 so that it compiles to gfx950's packed fp32 instructions (v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32: two pixels per VALU issue); only exp, rcp, min and the compares stay one per pixel.
+// The kernel is VALU-bound (rocprofv3 round 1: 78 % VALU issue): against one pixel per lane this halves the issue
+// slots of the chain-rule arithmetic and halves the number of cross-lane reductions per pixel (the two pixels of a
+// lane are added before reduce12).  The visit list is per wavefront, i.e. per 16 x 8 half: coarser than the former
+// 8 x 8 quadrant (more visits pass the reach test), but a visit now carries 128 pixels for ~0.6 of the issue cost
+// of two 64-pixel visits.  Splats are staged 128 at a time (one per thread).
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int kBwdThreads = 128;
+
+__device__ __forceinline__ f2 splat2(float s) { return (f2){s, s}; }
+
+__global__ void __launch_bounds__(kBwdThreads) k_render_bwd(
     int H, int W, int gx, int gy, const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list,
     const Splat* __restrict__ splats, float bg0, float bg1, float bg2, const unsigned* __restrict__ n_contrib,
     const float* __restrict__ final_T, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const float* __restrict__ dL_dalpha_out, float* __restrict__ grad_rec) {
-    __shared__ float4 sm[kTilePix * 3];
-    __shared__ unsigned sid[kTilePix];
-    __shared__ float sacc[kTilePix * kGradSlots];   // per-round gradient records: the 4 wavefronts meet here first
+    __shared__ float4 sm[kBwdThreads * 3];
+    __shared__ unsigned sid[kBwdThreads];
+    __shared__ float sacc[kBwdThreads * kGradSlots];   // per-round gradient records: the 2 wavefronts meet here first
     const unsigned tile = xcd_remap(blockIdx.x, (unsigned)(gx * gy));
     const int tx = tile % gx, ty = tile / gx;
-    // wavefront w owns the 8 x 8 quadrant (w & 1, w >> 1) of the tile: squarer than a 16 x 4 strip, so fewer
-    // (wavefront, splat) visits for the same covered pixels
-    const int wq = threadIdx.x >> 6, lq = threadIdx.x & 63;
-    const int lx = (wq & 1) * 8 + (lq & 7), ly = (wq >> 1) * 8 + (lq >> 3);
-    const int px = tx * kTileX + lx, py = ty * kTileY + ly;
-    const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
-    const int lane = threadIdx.x & 63;
+    const int wq = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lx = lane & 15, ly = wq * 8 + (lane >> 4);
+    const int px = tx * kTileX + lx, py0 = ty * kTileY + ly, py1 = py0 + 4;
+    const bool in0 = px < W && py0 < H, in1 = px < W && py1 < H;
+    const float fx = (float)px;
+    const f2 fy = (f2){(float)py0, (float)py1};
     const uint2 range = ranges[tile];
-    const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
+    const size_t hw = (size_t)H * W, pix0 = (size_t)py0 * W + px, pix1 = (size_t)py1 * W + px;
 
-    const float T_final = inside ? final_T[pix] : 0.0f;
-    float T = T_final;
-    const int last_contributor = inside ? (int)n_contrib[pix] : 0;
+    const f2 T_final = (f2){in0 ? final_T[pix0] : 0.0f, in1 ? final_T[pix1] : 0.0f};
+    f2 T = T_final;
+    const int lc0 = in0 ? (int)n_contrib[pix0] : 0, lc1 = in1 ? (int)n_contrib[pix1] : 0;
     // The forward pass stops a tile once every pixel is saturated; the backward walks back from the LAST splat
     // any pixel of the tile took (max of n_contrib), not from the end of the tile's list.
     __shared__ int s_live;
-    int wave_live;                        // the same bound for this wavefront's quadrant alone
+    int wave_live;                        // the same bound for this wavefront's half alone
     if (threadIdx.x == 0) s_live = 0;
     __syncthreads();
     {
-        int mc = last_contributor;
+        int mc = max(lc0, lc1);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mc = max(mc, __shfl_xor(mc, o, 64));
         if (lane == 0) atomicMax(&s_live, mc);
@@ -104,24 +118,30 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
     }
     __syncthreads();
     const int total = min(s_live, (int)(range.y - range.x));
-    const int rounds = (total + kTilePix - 1) / kTilePix;
-    const float sx0 = (float)(tx * kTileX + (wq & 1) * 8), sx1 = sx0 + 7.0f;
-    const float sy0 = (float)(ty * kTileY + (wq >> 1) * 8), sy1 = sy0 + 7.0f;
-    float gr = 0.f, gg = 0.f, gb = 0.f, gD = 0.f, gA = 0.f;
-    if (inside) {
-        gr = dL_dcolor[pix]; gg = dL_dcolor[hw + pix]; gb = dL_dcolor[2 * hw + pix];
-        gD = dL_ddepth ? dL_ddepth[pix] : 0.0f;
-        gA = dL_dalpha_out ? dL_dalpha_out[pix] : 0.0f;
+    const int rounds = (total + kBwdThreads - 1) / kBwdThreads;
+    const float sx0 = (float)(tx * kTileX), sx1 = sx0 + 15.0f;
+    const float sy0 = (float)(ty * kTileY + wq * 8), sy1 = sy0 + 7.0f;
+    f2 gr = splat2(0.f), gg = splat2(0.f), gb = splat2(0.f), gD = splat2(0.f), gA = splat2(0.f);
+    if (in0) {
+        gr.x = dL_dcolor[pix0]; gg.x = dL_dcolor[hw + pix0]; gb.x = dL_dcolor[2 * hw + pix0];
+        gD.x = dL_ddepth ? dL_ddepth[pix0] : 0.0f;
+        gA.x = dL_dalpha_out ? dL_dalpha_out[pix0] : 0.0f;
     }
-    const float bg_dot = bg0 * gr + bg1 * gg + bg2 * gb;
-    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f;
-    float last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f, last_d = 0.f;
+    if (in1) {
+        gr.y = dL_dcolor[pix1]; gg.y = dL_dcolor[hw + pix1]; gb.y = dL_dcolor[2 * hw + pix1];
+        gD.y = dL_ddepth ? dL_ddepth[pix1] : 0.0f;
+        gA.y = dL_dalpha_out ? dL_dalpha_out[pix1] : 0.0f;
+    }
+    // output terms that do not depend on the splat: background of the colour output and A = 1 - T_final
+    const f2 tail = T_final * (gA - (bg0 * gr + bg1 * gg + bg2 * gb));
+    f2 acc_r = splat2(0.f), acc_g = splat2(0.f), acc_b = splat2(0.f), acc_d = splat2(0.f), last_alpha = splat2(0.f);
+    float last_r = 0.f, last_g = 0.f, last_b = 0.f, last_d = 0.f;      // colour of the last visited splat: wave-uniform
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
     int todo = total;
-    for (int rd = 0; rd < rounds; ++rd, todo -= kTilePix) {
+    for (int rd = 0; rd < rounds; ++rd, todo -= kBwdThreads) {
         __syncthreads();
-        int progress = rd * kTilePix + threadIdx.x;
+        int progress = rd * kBwdThreads + threadIdx.x;
         if (progress < total) {
             unsigned gid = point_list[range.x + total - 1 - progress];   // back to front
             const float4* src = (const float4*)(splats + gid);
@@ -134,62 +154,67 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
         for (int k = 0; k < kGradSlots / 4; ++k)
             ((float4*)sacc)[threadIdx.x * (kGradSlots / 4) + k] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
-        const int cnt = min(kTilePix, todo);
-        // visit list of this wavefront's quadrant (see k_render): one lane-test per staged splat, then a
-        // scalar walk over the ballot; splats that cannot reach alpha >= 1/255 on the quadrant are never evaluated
+        const int cnt = min(kBwdThreads, todo);
+        // visit list of this wavefront's half (see k_render): one lane-test per staged splat, then a scalar walk
+        // over the ballot; splats that cannot reach alpha >= 1/255 on the half are never evaluated
         for (int c0 = 0; c0 < cnt; c0 += 64) {
           bool hit = false;
           if (c0 + lane < cnt) {
               const float4 ta = sm[(c0 + lane) * 3], tb = sm[(c0 + lane) * 3 + 1];
               hit = splat_reaches_rect(ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, sx0, sx1, sy0, sy1) &&
-                    (total - 1 - (rd * kTilePix + c0 + lane)) < wave_live;
+                    (total - 1 - (rd * kBwdThreads + c0 + lane)) < wave_live;
           }
           unsigned long long vm = __ballot(hit);
           while (vm) {
             const int j = c0 + (int)__builtin_ctzll(vm);
             vm &= vm - 1;
-            const int contributor = total - 1 - (rd * kTilePix + j);
-            float4 a = sm[j * 3], b = sm[j * 3 + 1], c = sm[j * 3 + 2];
-            float dx = a.x - fx, dy = a.y - fy;
-            float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            float G = __expf(power);
-            float alpha = fminf(kAlphaMax, b.y * G);
-            bool active = (contributor < last_contributor) && (power <= 0.0f) && (alpha >= kAlphaMin);
-            if (__ballot(active) == 0ull) continue;   // wave-uniform
-            // Branch-free: a lane that does not take this splat blends it with alpha = 0 and G = 0, which is an exact
+            const int contributor = total - 1 - (rd * kBwdThreads + j);
+            const float4 a = sm[j * 3], b = sm[j * 3 + 1], c = sm[j * 3 + 2];
+            // a = (x, y, cxx, cxy)  b = (cyy, opacity, r, g)  c = (b, depth, -, -)
+            const float dx = a.x - fx;
+            const f2 dy = splat2(a.y) - fy;
+            const float hxx = -0.5f * a.z * dx * dx, bxy = a.w * dx;
+            const f2 power = (-0.5f * b.x) * dy * dy - bxy * dy + hxx;
+            f2 G = (f2){__expf(power.x), __expf(power.y)};
+            const f2 araw = b.y * G;
+            const bool act0 = (contributor < lc0) && (power.x <= 0.0f) && (fminf(kAlphaMax, araw.x) >= kAlphaMin);
+            const bool act1 = (contributor < lc1) && (power.y <= 0.0f) && (fminf(kAlphaMax, araw.y) >= kAlphaMin);
+            if (__ballot(act0 || act1) == 0ull) continue;   // wave-uniform
+            // Branch-free: a pixel that does not take this splat blends it with alpha = 0 and G = 0, which is an exact
             // no-op on its running state (T * rcp(1) = T, the colour recursion absorbs a zero-weight layer exactly)
-            // and makes every gradient term an exact zero - no EXEC-masked region, no zero-fill of v[].
-            const float a_eff = active ? alpha : 0.0f;
-            const float G_eff = active ? G : 0.0f;
+            // and makes every gradient term an exact zero - no EXEC-masked region.
+            const f2 a_eff = (f2){act0 ? fminf(kAlphaMax, araw.x) : 0.0f, act1 ? fminf(kAlphaMax, araw.y) : 0.0f};
+            G = (f2){act0 ? G.x : 0.0f, act1 ? G.y : 0.0f};
+            const f2 one_m = 1.0f - a_eff;
+            const f2 inv1ma = (f2){__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};   // 1 ulp reciprocal
+            T = T * inv1ma;
+            const f2 wgt = a_eff * T;
+            // colour / depth recursion of the contribution behind this splat
+            const f2 one_la = 1.0f - last_alpha;
+            acc_r = last_alpha * last_r + one_la * acc_r;
+            acc_g = last_alpha * last_g + one_la * acc_g;
+            acc_b = last_alpha * last_b + one_la * acc_b;
+            acc_d = last_alpha * last_d + one_la * acc_d;
+            last_r = b.z; last_g = b.w; last_b = c.x; last_d = c.y;
+            last_alpha = a_eff;
+            f2 dL_da = (b.z - acc_r) * gr + (b.w - acc_g) * gg + (c.x - acc_b) * gb + (c.y - acc_d) * gD;
+            dL_da = dL_da * T + tail * inv1ma;
+            const f2 dL_dG = b.y * dL_da;
+            const f2 gdx = G * dx, gdy = G * dy;
+            const f2 dG_ddelx = -(gdx * a.z) - gdy * a.w;
+            const f2 dG_ddely = -(gdy * b.x) - gdx * a.w;
+            f2 w[10];
+            w[G_R] = wgt * gr; w[G_G] = wgt * gg; w[G_B] = wgt * gb; w[G_DEPTH] = wgt * gD;
+            w[G_MX] = dL_dG * dG_ddelx * ddelx_dx;
+            w[G_MY] = dL_dG * dG_ddely * ddely_dy;
+            w[G_CXX] = (-0.5f * dx) * gdx * dL_dG;
+            w[G_CXY] = -(gdx * dy) * dL_dG;
+            w[G_CYY] = -0.5f * (gdy * dy) * dL_dG;
+            w[G_OP] = G * dL_da;
             float v[12];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) v[k] = w[k].x + w[k].y;
             v[10] = 0.0f; v[11] = 0.0f;
-            {
-                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - a_eff);   // 1 ulp reciprocal: one instruction, not a 10-op IEEE divide
-                T = T * inv1ma;
-                float wgt = a_eff * T;
-                // colour / depth recursion of the contribution behind this splat
-                acc_r = last_alpha * last_r + (1.0f - last_alpha) * acc_r;
-                acc_g = last_alpha * last_g + (1.0f - last_alpha) * acc_g;
-                acc_b = last_alpha * last_b + (1.0f - last_alpha) * acc_b;
-                acc_d = last_alpha * last_d + (1.0f - last_alpha) * acc_d;
-                last_r = b.z; last_g = b.w; last_b = c.x; last_d = c.y;
-                float dL_da = (b.z - acc_r) * gr + (b.w - acc_g) * gg + (c.x - acc_b) * gb + (c.y - acc_d) * gD;
-                dL_da *= T;
-                last_alpha = a_eff;
-                dL_da += (-T_final * inv1ma) * bg_dot;   // background term of the colour output
-                dL_da += (T_final * inv1ma) * gA;        // alpha output  A = 1 - T_final
-                float dL_dG = b.y * dL_da;
-                float gdx = G_eff * dx, gdy = G_eff * dy;
-                float dG_ddelx = -gdx * a.z - gdy * a.w;
-                float dG_ddely = -gdy * b.x - gdx * a.w;
-                v[G_R] = wgt * gr; v[G_G] = wgt * gg; v[G_B] = wgt * gb; v[G_DEPTH] = wgt * gD;
-                v[G_MX] = dL_dG * dG_ddelx * ddelx_dx;
-                v[G_MY] = dL_dG * dG_ddely * ddely_dy;
-                v[G_CXX] = -0.5f * gdx * dx * dL_dG;
-                v[G_CXY] = -gdx * dy * dL_dG;
-                v[G_CYY] = -0.5f * gdy * dy * dL_dG;
-                v[G_OP] = G_eff * dL_da;
-            }
             float s = reduce12(v, lane);
             const int slot = 3 * (lane >> 4) + (lane & 15);
             if ((lane & 15) < 3 && slot < G_USED) atomicAdd(&sacc[j * kGradSlots + slot], s);   // LDS, 10 banks
@@ -200,7 +225,7 @@ __global__ void __launch_bounds__(kTilePix) k_render_bwd(
         __syncthreads();
         {
             const int slot = threadIdx.x & 15;
-            for (int q = threadIdx.x >> 4; q < cnt; q += kTilePix / 16) {
+            for (int q = threadIdx.x >> 4; q < cnt; q += kBwdThreads / 16) {
                 float val = sacc[q * kGradSlots + slot];
                 if (slot < G_USED && val != 0.0f) unsafeAtomicAdd(grad_rec + (size_t)sid[q] * kGradSlots + slot, val);
             }
@@ -442,7 +467,7 @@ extern "C" int syn3r_raster_backward(int N, int sh_degree, int sh_coeffs, long l
     if (rc) return rc;
     const unsigned tiles = (unsigned)(cam.grid_x * cam.grid_y);
     if (P > 0)
-        SYN3R_LAUNCH(k_render_bwd, dim3(tiles), dim3(kTilePix), 0, stream, H, W, cam.grid_x, cam.grid_y, im.ranges,
+        SYN3R_LAUNCH(k_render_bwd, dim3(tiles), dim3(kBwdThreads), 0, stream, H, W, cam.grid_x, cam.grid_y, im.ranges,
                            point_list, g.splats, bg[0], bg[1], bg[2], im.n_contrib, im.final_T, dL_dcolor, dL_ddepth,
                            dL_dalpha, grad_rec);
     SYN3R_LAUNCH(k_preprocess_bwd, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,

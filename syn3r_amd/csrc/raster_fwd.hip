@@ -338,36 +338,41 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     return start + k;
 }
 
-__global__ void __launch_bounds__(kTilePix) k_render(int H, int W, int gx, int gy, const uint2* __restrict__ ranges,
-                                                     const unsigned* __restrict__ point_list,
-                                                     const Splat* __restrict__ splats, float bg0, float bg1,
-                                                     float bg2, unsigned* __restrict__ n_contrib,
-                                                     float* __restrict__ final_T, float* __restrict__ out_color,
-                                                     float* __restrict__ out_depth, float* __restrict__ out_alpha) {
-    __shared__ float4 sm[kTilePix * 3];
+// Two pixels per lane (see k_render_bwd in raster_bwd.hip): a 16 x 16 tile is a block of TWO wavefronts, wavefront w
+// owns the 16 x 8 half (rows 8w .. 8w+7) and lane l the pixels (l & 15, 8w + (l >> 4)) and (.., + 4).  The
+// quadratic form, the exponent argument, the weights and the colour / depth accumulation are float2 arithmetic
+// (v_pk_fma_f32 / v_pk_mul_f32: two pixels per VALU issue); exp, min and the compares stay one per pixel.
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int kFwdThreads = 128;
+
+__global__ void __launch_bounds__(kFwdThreads) k_render(int H, int W, int gx, int gy, const uint2* __restrict__ ranges,
+                                                        const unsigned* __restrict__ point_list,
+                                                        const Splat* __restrict__ splats, float bg0, float bg1,
+                                                        float bg2, unsigned* __restrict__ n_contrib,
+                                                        float* __restrict__ final_T, float* __restrict__ out_color,
+                                                        float* __restrict__ out_depth, float* __restrict__ out_alpha) {
+    __shared__ float4 sm[kFwdThreads * 3];
     const unsigned tile = xcd_remap(blockIdx.x, (unsigned)(gx * gy));
     const int tx = tile % gx, ty = tile / gx;
-    // wavefront w owns the 8 x 8 quadrant (w & 1, w >> 1) of the tile: squarer than a 16 x 4 strip, so fewer
-    // (wavefront, splat) visits for the same covered pixels
-    const int wq = threadIdx.x >> 6, lq = threadIdx.x & 63;
-    const int lx = (wq & 1) * 8 + (lq & 7), ly = (wq >> 1) * 8 + (lq >> 3);
-    const int px = tx * kTileX + lx, py = ty * kTileY + ly;
-    const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
+    const int wq = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lx = lane & 15, ly = wq * 8 + (lane >> 4);
+    const int px = tx * kTileX + lx, py0 = ty * kTileY + ly, py1 = py0 + 4;
+    const bool in0 = px < W && py0 < H, in1 = px < W && py1 < H;
+    const float fx = (float)px;
+    const f2 fy = (f2){(float)py0, (float)py1};
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
-    const int rounds = (total + kTilePix - 1) / kTilePix;
+    const int rounds = (total + kFwdThreads - 1) / kFwdThreads;
 
-    bool done = !inside;
-    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dp = 0.f;
-    unsigned last = 0;
+    bool done0 = !in0, done1 = !in1;
+    f2 T = (f2){1.0f, 1.0f}, Cr = (f2){0.f, 0.f}, Cg = Cr, Cb = Cr, Dp = Cr;
+    unsigned last0 = 0, last1 = 0;
     int todo = total;
-    const int lane = threadIdx.x & 63;
-    const float sx0 = (float)(tx * kTileX + (wq & 1) * 8), sx1 = sx0 + 7.0f;
-    const float sy0 = (float)(ty * kTileY + (wq >> 1) * 8), sy1 = sy0 + 7.0f;
-    for (int rd = 0; rd < rounds; ++rd, todo -= kTilePix) {
-        if (__syncthreads_count(done) == kTilePix) break;
-        int idx = rd * kTilePix + threadIdx.x;
+    const float sx0 = (float)(tx * kTileX), sx1 = sx0 + 15.0f;
+    const float sy0 = (float)(ty * kTileY + wq * 8), sy1 = sy0 + 7.0f;
+    for (int rd = 0; rd < rounds; ++rd, todo -= kFwdThreads) {
+        if (__syncthreads_count(done0 && done1) == kFwdThreads) break;
+        int idx = rd * kFwdThreads + threadIdx.x;
         if (idx < total) {
             unsigned gid = point_list[range.x + idx];
             const float4* src = (const float4*)(splats + gid);
@@ -376,13 +381,13 @@ __global__ void __launch_bounds__(kTilePix) k_render(int H, int W, int gx, int g
             sm[threadIdx.x * 3 + 2] = src[2];
         }
         __syncthreads();
-        const int cnt = min(kTilePix, todo);
-        // Visit list: each lane tests ONE staged splat against the wavefront's 8 x 8 quadrant (splat_reaches_rect); the
-        // ballot is the list, walked in order with scalar bit operations.  Two thirds of the (wavefront, splat)
-        // visits of the 3-sigma tile lists never reach alpha >= 1/255 on the quadrant and are skipped for the price
-        // of one lane-test instead of a 64-lane evaluation.
+        const int cnt = min(kFwdThreads, todo);
+        // Visit list: each lane tests ONE staged splat against the wavefront's 16 x 8 half (splat_reaches_rect); the
+        // ballot is the list, walked in order with scalar bit operations.  Most (wavefront, splat) visits of the
+        // 3-sigma tile lists never reach alpha >= 1/255 on the half and are skipped for the price of one lane-test
+        // instead of a 128-pixel evaluation.
         for (int c0 = 0; c0 < cnt; c0 += 64) {
-            if (__ballot(!done) == 0ull) break;
+            if (__ballot(!(done0 && done1)) == 0ull) break;
             bool hit = false;
             if (c0 + lane < cnt) {
                 const float4 a = sm[(c0 + lane) * 3], b = sm[(c0 + lane) * 3 + 1];
@@ -394,30 +399,48 @@ __global__ void __launch_bounds__(kTilePix) k_render(int H, int W, int gx, int g
                 m &= m - 1;
                 const float4 a = sm[j * 3], b = sm[j * 3 + 1], c = sm[j * 3 + 2];
                 // a = (x, y, cxx, cxy)  b = (cyy, opacity, r, g)  c = (b, depth, -, -)
-                const float dx = a.x - fx, dy = a.y - fy;
-                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                const float alpha = fminf(kAlphaMax, b.y * __expf(power));
-                const float test_T = T * (1.0f - alpha);
-                const bool contrib = !done && power <= 0.0f && alpha >= kAlphaMin;
-                if (contrib && test_T < kTransmittanceMin) done = true;
-                if (contrib && !done) {
-                    const float w = alpha * T;
-                    Cr += b.z * w; Cg += b.w * w; Cb += c.x * w; Dp += c.y * w;
-                    T = test_T;
-                    last = (unsigned)(rd * kTilePix + j + 1);
-                }
+                const float dx = a.x - fx;
+                const f2 dy = (f2){a.y, a.y} - fy;
+                const float hxx = -0.5f * a.z * dx * dx, bxy = a.w * dx;
+                const f2 power = (-0.5f * b.x) * dy * dy - bxy * dy + hxx;
+                const f2 araw = b.y * (f2){__expf(power.x), __expf(power.y)};
+                const float al0 = fminf(kAlphaMax, araw.x), al1 = fminf(kAlphaMax, araw.y);
+                const f2 test_T = T * (1.0f - (f2){al0, al1});
+                const bool c0_ = !done0 && power.x <= 0.0f && al0 >= kAlphaMin;
+                const bool c1_ = !done1 && power.y <= 0.0f && al1 >= kAlphaMin;
+                if (c0_ && test_T.x < kTransmittanceMin) done0 = true;
+                if (c1_ && test_T.y < kTransmittanceMin) done1 = true;
+                const bool t0 = c0_ && !done0, t1 = c1_ && !done1;
+                // a pixel that does not take the splat adds a zero weight and keeps its transmittance: branch-free
+                const f2 w = (f2){t0 ? al0 : 0.0f, t1 ? al1 : 0.0f} * T;
+                Cr += b.z * w; Cg += b.w * w; Cb += c.x * w; Dp += c.y * w;
+                T = (f2){t0 ? test_T.x : T.x, t1 ? test_T.y : T.y};
+                const unsigned here = (unsigned)(rd * kFwdThreads + j + 1);
+                last0 = t0 ? here : last0;
+                last1 = t1 ? here : last1;
             }
         }
     }
-    if (inside) {
-        size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
-        final_T[pix] = T;
-        n_contrib[pix] = last;
-        out_color[pix] = Cr + T * bg0;
-        out_color[hw + pix] = Cg + T * bg1;
-        out_color[2 * hw + pix] = Cb + T * bg2;
-        out_depth[pix] = Dp;
-        out_alpha[pix] = 1.0f - T;
+    const size_t hw = (size_t)H * W;
+    if (in0) {
+        const size_t pix = (size_t)py0 * W + px;
+        final_T[pix] = T.x;
+        n_contrib[pix] = last0;
+        out_color[pix] = Cr.x + T.x * bg0;
+        out_color[hw + pix] = Cg.x + T.x * bg1;
+        out_color[2 * hw + pix] = Cb.x + T.x * bg2;
+        out_depth[pix] = Dp.x;
+        out_alpha[pix] = 1.0f - T.x;
+    }
+    if (in1) {
+        const size_t pix = (size_t)py1 * W + px;
+        final_T[pix] = T.y;
+        n_contrib[pix] = last1;
+        out_color[pix] = Cr.y + T.y * bg0;
+        out_color[hw + pix] = Cg.y + T.y * bg1;
+        out_color[2 * hw + pix] = Cb.y + T.y * bg2;
+        out_depth[pix] = Dp.y;
+        out_alpha[pix] = 1.0f - T.y;
     }
 }
 
@@ -537,7 +560,7 @@ extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const i
         point_list = in_b ? bn.vals_b : bn.vals_a;
         SYN3R_LAUNCH(k_tile_ranges, dim3(ceil_div(P, 256)), dim3(256), 0, stream, P, g.header, keys, im.ranges);
     }
-    SYN3R_LAUNCH(k_render, dim3((unsigned)tiles), dim3(kTilePix), 0, stream, H, W, gx, gy, im.ranges, point_list,
+    SYN3R_LAUNCH(k_render, dim3((unsigned)tiles), dim3(kFwdThreads), 0, stream, H, W, gx, gy, im.ranges, point_list,
                        g.splats, bg[0], bg[1], bg[2], im.n_contrib, im.final_T, out_color, out_depth, out_alpha);
     SYN3R_LAUNCH_CHECK("raster_render launch");
     if (point_list_out) *point_list_out = point_list;

@@ -377,8 +377,8 @@ class GSTrainer:
         n = iterations if iterations is not None else self.opt.iterations
         last = self._loop(first_iter, n)
         if self.scene.model_path:
-            if self.checkpoint_iterations:
-                self.save_checkpoint(self.checkpoint_iterations[-1])
+            if n in self.checkpoint_iterations:
+                self.save_checkpoint(n)
             self.save_checkpoint(n, latest=True)
         return last
 
