@@ -316,6 +316,19 @@ int syn3r_feedforward_f16(const void* x, long long ldx, const void* w1_packed, c
                           int M, int C_in, int C_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The same FeedForward.forward (attention.py:608-665, GEGLU of activations.py) in ONE kernel for C_in = C_out = 320
+ * (the level-0 transformer blocks of SVD): the gated hidden activation never leaves the CU, no workspace.
+ *   w1_chunked [D/64][128][320]: rows of net.0.proj regrouped per 64-wide hidden chunk j as
+ *       4 x [hidden 64j+16q..+15 | gate 64j+16q..+15], q = 0..3;  b1_chunked [D/64][128] likewise
+ *   w2 [320, D] (net.2.weight as stored), b2 [320] or NULL; epilogue as syn3r_gemm_f16 (bias, residual, aux, scales).
+ * Other channel counts are rejected (SYN3R_E_INVALID): use syn3r_feedforward_f16.
+ */
+int syn3r_feedforward_fused_f16(const void* x, long long ldx, const void* w1_chunked, const void* b1_chunked, int D,
+                                const void* w2, const void* b2, void* out, long long ldc, const void* residual,
+                                long long ldr, const void* aux, long long ldaux, float s_acc, float s_res, float s_aux,
+                                int M, int C, void* stream);
+
+/*
  * 3x3 Conv2d on NHWC fp16 (resnet.py:274,290; downsampling.py:116-148 with stride 2;
  * upsampling.py:172-183 with upsample != 0: nearest-2x of the input fused into the gather).
  * pad_lo = 1: padding 1 on every side.  pad_lo = 0: the VAE encoder's Downsample2D(padding=0), which pads

@@ -182,10 +182,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
             half8 gv = *(const half8*)(gs + row * EPI_LD + ch * 8);
             half8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float g = (float)gv[e];
-                float ge = gelu_erf(g);
-                o[e] = (_Float16)((float)hv[e] * ge);
+            for (int e = 0; e < 8; e += 2) {
+                const syn3r_f2 y = (syn3r_f2){(float)hv[e], (float)hv[e + 1]} * gelu_pk((syn3r_f2){(float)gv[e], (float)gv[e + 1]});
+                o[e] = (_Float16)y.x; o[e + 1] = (_Float16)y.y;
             }
             if (p.out_tiled) {
                 OUT_STORE((half8*)(p.out + tiled_off(m, n, p.geglu_D)), o);
@@ -798,14 +797,15 @@ __global__ void __launch_bounds__(512, 2) k_gemm_wide(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float hv = (float)(_Float16)(acc[0][i][j][r] + bh[r]);
-                    float gv = (float)(_Float16)(acc[1][i][j][r] + bg[r]);
+                for (int r = 0; r < 4; r += 2) {       // pairs: the gate is packed fp32 arithmetic (gelu_pk, common.h)
+                    const syn3r_f2 hv = (syn3r_f2){(float)(_Float16)(acc[0][i][j][r] + bh[r]), (float)(_Float16)(acc[0][i][j][r + 1] + bh[r + 1])};
+                    const syn3r_f2 gv = (syn3r_f2){(float)(_Float16)(acc[1][i][j][r] + bg[r]), (float)(_Float16)(acc[1][i][j][r + 1] + bg[r + 1])};
 #ifdef SYN3R_EXP_NOGATE        // timing experiments (wrong results): compile the gate / the output stores out
-                    acc[0][i][j][r] = hv + gv;
+                    const syn3r_f2 y = hv + gv;
 #else
-                    acc[0][i][j][r] = hv * gelu_erf(gv);
+                    const syn3r_f2 y = hv * gelu_pk(gv);
 #endif
+                    acc[0][i][j][r] = y.x; acc[0][i][j][r + 1] = y.y;
                 }
         }
         GemmParams q = p;
@@ -934,14 +934,15 @@ __global__ void __launch_bounds__(256, 2) k_gemm_w128(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float hv = (float)(_Float16)(acc[0][i][j][r] + bh[r]);
-                    float gv = (float)(_Float16)(acc[1][i][j][r] + bg[r]);
+                for (int r = 0; r < 4; r += 2) {       // pairs: the gate is packed fp32 arithmetic (gelu_pk, common.h)
+                    const syn3r_f2 hv = (syn3r_f2){(float)(_Float16)(acc[0][i][j][r] + bh[r]), (float)(_Float16)(acc[0][i][j][r + 1] + bh[r + 1])};
+                    const syn3r_f2 gv = (syn3r_f2){(float)(_Float16)(acc[1][i][j][r] + bg[r]), (float)(_Float16)(acc[1][i][j][r + 1] + bg[r + 1])};
 #ifdef SYN3R_EXP_NOGATE        // timing experiments (wrong results): compile the gate / the output stores out
-                    acc[0][i][j][r] = hv + gv;
+                    const syn3r_f2 y = hv + gv;
 #else
-                    acc[0][i][j][r] = hv * gelu_erf(gv);
+                    const syn3r_f2 y = hv * gelu_pk(gv);
 #endif
+                    acc[0][i][j][r] = y.x; acc[0][i][j][r + 1] = y.y;
                 }
         }
         GemmParams q = p;
@@ -953,6 +954,243 @@ __global__ void __launch_bounds__(256, 2) k_gemm_w128(GemmParams p) {
     gemm_epilogue<0>(p, acc[0], smem_raw, lane, wv, wm, wn * 2, m0, n0, tile_n);
     __builtin_amdgcn_wave_barrier();
     gemm_epilogue<0>(p, acc[1], smem_raw, lane, wv, wm, wn * 2 + 1, m0, n0, tile_n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused feed-forward for C = 320 (the level-0 transformer blocks: FeedForward.forward, attention.py:608-665, with the
+// GEGLU of activations.py):   out = epilogue( geglu(x . W1^T + b1) . W2^T )   in ONE kernel.
+// The two-kernel path writes the gated hidden activation ([M, 1280] fp16 = 660 MB at M = 258 048) and reads it back;
+// round 1 measured the first projection at half its matrix rate because of that output stream.  Here a
+// block owns 128 rows: its x tile (80 KB) stays in LDS, the hidden dimension is walked in chunks of 64 —
+//     phase 1   S[128, 128]  = x . W1_j^T            (K = 320, five 64-wide k-tiles of the chunk's 128 packed rows)
+//     gate      h[128, 64]   = (S_h + b) * gelu(S_g + b)   in registers, fp16-rounded as the reference's projection output
+//     phase 2   out[128,320] += h . W2[:, j]^T       (K = 64)
+// and the [128, 320] fp32 result lives in registers for the whole kernel: EIGHT wavefronts (2 x 4), each 64 rows x 80
+// output columns (80 accumulators) + its 64 x 32 slice of S (32), so a wavefront stays under 256 registers and every
+// SIMD holds TWO: one wavefront's gate arithmetic, LDS-DMA issue (≈60-100 cycles per 1 KiB piece, MI355X_MICROARCH.md)
+// and barrier waits overlap the other's MFMAs (a one-wavefront-per-SIMD build of this kernel ran 2.1x slower: 590
+// TFLOP/s, those phases serialise).  Nothing but x and out touches HBM; the weights (2.4 MB, L2-resident) stream
+// through a 3-slot LDS ring by LDS-DMA with counted vmcnt and ONE barrier per stage.
+// LDS: x 80 KB | ring 3 x 20 KB | h 16 KB | per-wavefront bias lines 4 KB = 163,840 B (all of it).
+// W1 rows are packed per 64-wide chunk as 4 x [16 hidden | 16 gate] (wavefront column wn owns one group, so a lane
+// holds a hidden value and its gate in matching accumulator tiles).
+constexpr int F_C = 320, F_HC = 64, F_BM = 128;
+constexpr int F_X_BYTES = F_BM * F_C * 2;            // 81,920
+constexpr int F_SLOT = 160 * BK * 2;                 // 20,480: a W2 half-chunk [160 x 64]; W1 k-tiles [128 x 64] use 16,384 of it
+constexpr int F_RING = F_X_BYTES;                    // ring offset
+constexpr int F_H = F_RING + 3 * F_SLOT;             // 143,360
+constexpr int F_BIAS = F_H + F_BM * F_HC * 2;        // 159,744
+constexpr int F_LDS = F_BIAS + 8 * 512;              // 163,840
+
+struct FfnParams {
+    GemmParams e;            // A = x, lda; W = w2 [320, D]; out / ldc; bias = b2; residual / aux / scales; M; N = 320
+    const __half* w1;        // [D/64][128][320] packed rows
+    const __half* b1;        // [D/64][128] packed
+    int D;                   // hidden width (multiple of 64)
+};
+
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+#define DS_READ64(dst, addr, OFF) asm volatile("ds_read_b64 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+#define DS_WRITE64(addr, val) asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(val) : "memory")
+
+__global__ void __launch_bounds__(512, 2) k_ffn320(FfnParams q) {
+    const GemmParams& p = q.e;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 2, wn = wv & 3;
+    const int tiles_m = (p.M + F_BM - 1) / F_BM;
+    const int m0 = (int)xcd_remap(blockIdx.x, (unsigned)tiles_m) * F_BM;
+    const int nchunks = q.D / F_HC;
+    const long long D = q.D;
+
+    // ---- DMA lane assignment (as k_gemm_dma): a wave-instruction moves 8 rows x 128 B; lane -> (row, slot), the
+    // XOR swizzle is applied to the SOURCE chunk and undone by the fragment reads.  Pieces per wavefront and stage:
+    // x / W1 k-tile (16 pieces) 2; W2 half (20 pieces) 3 (wavefronts 0-3) or 2 (4-7).
+    const int prow = lane >> 3;
+    const int csrc = (lane & 7) ^ prow;
+    const int nbw = wv < 4 ? 3 : 2;
+    const int b_first = wv < 4 ? wv * 3 : 12 + (wv - 4) * 2;
+    const __half* w1_lane = q.w1 + (long long)((wv * 2) * 8 + prow) * F_C + csrc * 8;      // + i * 8 * 320 per piece
+    const __half* w2_lane = p.W + (long long)(b_first * 8 + prow) * D + csrc * 8;           // + i * 8 * D per piece
+    const __half* b1_lane = q.b1 + lane * 2;
+    char* const ring = smem_raw + F_RING;
+    char* const bias_line = smem_raw + F_BIAS + wv * 512;
+
+    int ij = 0, ir = 0, islot = 0;       // issue cursor: chunk, stage within the chunk (0..4 = W1 k-tiles, 5..6 = W2 halves), ring slot
+    auto issue_next = [&]() {
+        if (ij >= nchunks) return;
+        char* slot = ring + islot * F_SLOT;
+        if (ir < 5) {
+            const __half* src = w1_lane + (long long)ij * (128 * F_C) + ir * BK;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + i * 8 * F_C), (lds_void_t*)(slot + (wv * 2 + i) * 1024), 16, 0, 0);
+            if (ir == 0)       // the chunk's 128 packed bias values ride with its first stage (one 4-byte DMA per lane)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(b1_lane + ij * 128), (lds_void_t*)(bias_line + (ij & 1) * 256), 4, 0, 0);
+        } else {
+            const __half* src = w2_lane + (long long)(ir - 5) * 160 * D + (long long)ij * F_HC;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < nbw)
+                    __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + (long long)i * 8 * D), (lds_void_t*)(slot + (b_first + i) * 1024), 16, 0, 0);
+        }
+        if (++ir == 7) { ir = 0; ++ij; }
+        if (++islot == 3) islot = 0;
+    };
+
+    // ---- prologue: the x tile (five k-tile images of [128 x 64]) and the first weight stage
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int m = m0 + (wv * 2 + i) * 8 + prow;
+            m = m < p.M ? m : p.M - 1;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(p.A + (long long)m * p.lda + kt * BK + csrc * 8),
+                                             (lds_void_t*)(smem_raw + kt * 16384 + (wv * 2 + i) * 1024), 16, 0, 0);
+        }
+    issue_next();
+
+    float4v acc[TM][TN];                  // out: 64 rows x 80 columns of this wavefront
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const unsigned sw0 = (unsigned)(((0 + fq) ^ (fr & 7)) << 4), sw1 = (unsigned)(((4 + fq) ^ (fr & 7)) << 4);
+    const unsigned x_row = lds0 + (unsigned)((wm * 64 + fr) * 128);               // + kt * 16384 + i * 2048 + sw
+    const unsigned w1_row = (unsigned)((wn * 32 + fr) * 128);                      // inside a slot: hidden tile, gate tile at + 2048
+    const unsigned w2_row = (unsigned)(((wn & 1) * 80 + fr) * 128);                // inside the wavefront's half slot, + jt * 2048
+    const unsigned h_rd = lds0 + F_H + (unsigned)((wm * 64 + fr) * 128);           // + i * 2048 + sw
+    // gate output: lane owns rows wm*64 + i*16 + fr, hidden columns c = wn*16 + fq*4 .. +3
+    const int hc = wn * 16 + fq * 4;
+    const unsigned h_wr = lds0 + F_H + (unsigned)((wm * 64 + fr) * 128) + (unsigned)((((hc >> 3) ^ (fr & 7)) << 4) + (hc & 7) * 2);
+    const unsigned bias_rd = lds0 + F_BIAS + (unsigned)(wv * 512 + (wn * 32 + fq * 4) * 2);   // + (j & 1) * 256 ; gate at + 32
+
+    int cslot = 0;
+    for (int j = 0; j < nchunks; ++j) {
+        float4v S[TM][2];                 // [row tile][0 = hidden tile | 1 = gate tile]
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { S[i][0] = (float4v){0.f, 0.f, 0.f, 0.f}; S[i][1] = (float4v){0.f, 0.f, 0.f, 0.f}; }
+        half4v bh, bg;
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt) {
+            // stage (j, kt) has landed once only the stage issued after it is still in flight (per-wave DMA counts:
+            // W1 k-tile 2 (+1 bias line with k-tile 0), W2 half 3 or 2)
+            if (kt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (kt < 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (wv < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned xa = x_row + (unsigned)(kt * 16384);
+            const unsigned wa = lds0 + F_RING + (unsigned)(cslot * F_SLOT) + w1_row;
+            half8 a0[TM], b0[2], a1[TM], b1[2];
+            DS_READ128(a0[0], xa + sw0, 0); DS_READ128(a0[1], xa + sw0, 2048); DS_READ128(a0[2], xa + sw0, 4096); DS_READ128(a0[3], xa + sw0, 6144);
+            DS_READ128(b0[0], wa + sw0, 0); DS_READ128(b0[1], wa + sw0, 2048);
+            DS_READ128(a1[0], xa + sw1, 0); DS_READ128(a1[1], xa + sw1, 2048); DS_READ128(a1[2], xa + sw1, 4096); DS_READ128(a1[3], xa + sw1, 6144);
+            DS_READ128(b1[0], wa + sw1, 0); DS_READ128(b1[1], wa + sw1, 2048);
+            if (kt == 0) {
+                const unsigned ba = bias_rd + (unsigned)((j & 1) * 256);
+                DS_READ64(bh, ba, 0); DS_READ64(bg, ba, 32);
+            }
+            // the next stage's DMA is issued AFTER this stage's fragment reads: its issue time (60-100 cycles per piece)
+            // covers the reads' latency instead of preceding it
+            issue_next();                 // into the slot every wavefront finished reading before this barrier
+            if (kt == 0) issue_next();    // ... and the second slot the previous chunk's phase 2 released
+            if (kt == 0) {
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(b0[0]), "+v"(b0[1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(b0[0]), "+v"(b0[1]));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                S[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0[0], a0[i], S[i][0], 0, 0, 0);
+                S[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0[1], a0[i], S[i][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(b1[0]), "+v"(b1[1]), "+v"(bh), "+v"(bg));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(b1[0]), "+v"(b1[1]));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                S[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[0], a1[i], S[i][0], 0, 0, 0);
+                S[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[1], a1[i], S[i][1], 0, 0, 0);
+            }
+            if (++cslot == 3) cslot = 0;
+        }
+        // ---- gate (GEGLU.forward): hidden * gelu(gate) on the fp16-rounded projection outputs (packed fp32 pairs,
+        // gelu_pk), written as the k-tile image of the second contraction (same swizzle as the DMA'd tiles)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            half4v o;
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const syn3r_f2 hv = (syn3r_f2){(float)(_Float16)(S[i][0][r] + (float)bh[r]), (float)(_Float16)(S[i][0][r + 1] + (float)bh[r + 1])};
+                const syn3r_f2 gv = (syn3r_f2){(float)(_Float16)(S[i][1][r] + (float)bg[r]), (float)(_Float16)(S[i][1][r + 1] + (float)bg[r + 1])};
+                const syn3r_f2 y = hv * gelu_pk(gv);
+                o[r] = (_Float16)y.x; o[r + 1] = (_Float16)y.y;
+            }
+            DS_WRITE64(h_wr + (unsigned)(i * 2048), o);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // both W2 halves have landed, h is written
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: out[64 x 80] += h[64 x 64] . W2[80 x 64]^T ; the wavefront's columns sit in half wn >> 1
+        {
+            int bslot = cslot + (wn >> 1);
+            if (bslot >= 3) bslot -= 3;
+            const unsigned wa = lds0 + F_RING + (unsigned)(bslot * F_SLOT) + w2_row;
+            half8 af[TM], bf[TN], ag[TM], bgf[TN];
+            DS_READ128(af[0], h_rd + sw0, 0); DS_READ128(af[1], h_rd + sw0, 2048); DS_READ128(af[2], h_rd + sw0, 4096); DS_READ128(af[3], h_rd + sw0, 6144);
+            DS_READ128(bf[0], wa + sw0, 0); DS_READ128(bf[1], wa + sw0, 2048); DS_READ128(bf[2], wa + sw0, 4096); DS_READ128(bf[3], wa + sw0, 6144);
+            DS_READ128(bf[4], wa + sw0, 8192);
+            DS_READ128(ag[0], h_rd + sw1, 0); DS_READ128(ag[1], h_rd + sw1, 2048); DS_READ128(ag[2], h_rd + sw1, 4096); DS_READ128(ag[3], h_rd + sw1, 6144);
+            DS_READ128(bgf[0], wa + sw1, 0); DS_READ128(bgf[1], wa + sw1, 2048); DS_READ128(bgf[2], wa + sw1, 4096); DS_READ128(bgf[3], wa + sw1, 6144);
+            DS_READ128(bgf[4], wa + sw1, 8192);
+            issue_next();                 // next chunk's first W1 k-tile (+ bias line) into the slot of this chunk's last
+            asm volatile("s_waitcnt lgkmcnt(9)"
+                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jt = 0; jt < TN; ++jt) acc[i][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[jt], af[i], acc[i][jt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ag[0]), "+v"(ag[1]), "+v"(ag[2]), "+v"(ag[3]), "+v"(bgf[0]), "+v"(bgf[1]), "+v"(bgf[2]), "+v"(bgf[3]), "+v"(bgf[4]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jt = 0; jt < TN; ++jt) acc[i][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bgf[jt], ag[i], acc[i][jt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cslot += 2;
+        if (cslot >= 3) cslot -= 3;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // every wavefront is done with the tiles before the epilogue reuses the LDS
+    gemm_epilogue<1>(p, acc, smem_raw, lane, wv, wm, wn, m0, 0, 0);
+}
+
+int launch_ffn320(const FfnParams& q, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn320, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(ffn320)");
+        attr_set = true;
+    }
+    const int tiles = (q.e.M + F_BM - 1) / F_BM;
+    char name[96];
+    if (trace_on()) {
+        if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_ffn320[M%d,D%d,e%d]", q.e.M, q.D, q.e.residual != nullptr);
+        else snprintf(name, sizeof(name), "k_gemm_ffn320");
+    }
+    SYN3R_LAUNCH_NAMED(name, k_ffn320, dim3(tiles), dim3(512), F_LDS, stream, q);
+    SYN3R_LAUNCH_CHECK("ffn320 launch");
+    return SYN3R_OK;
 }
 
 int launch_w128(const GemmParams& p, hipStream_t stream) {
@@ -1230,6 +1468,26 @@ extern "C" int syn3r_feedforward_f16(const void* x, long long ldx, const void* w
     rc = check_common(q, "feedforward_f16(net.2)");
     if (rc) return rc;
     return launch<MODE_DENSE>(q, (hipStream_t)stream);
+}
+
+extern "C" int syn3r_feedforward_fused_f16(const void* x, long long ldx, const void* w1_chunked, const void* b1_chunked,
+                                           int D, const void* w2, const void* b2, void* out, long long ldc,
+                                           const void* residual, long long ldr, const void* aux, long long ldaux,
+                                           float s_acc, float s_res, float s_aux, int M, int C, void* stream) {
+    SYN3R_REQUIRE(x && w1_chunked && b1_chunked && w2 && out, "feedforward_fused_f16: null operand");
+    SYN3R_REQUIRE(C == F_C, "feedforward_fused_f16: the fused kernel is built for C = %d channels (got %d): use syn3r_feedforward_f16", F_C, C);
+    SYN3R_REQUIRE(M > 0 && D >= F_HC && D % F_HC == 0, "feedforward_fused_f16: bad sizes M=%d D=%d (D must be a multiple of %d)", M, D, F_HC);
+    FfnParams q{};
+    GemmParams& p = q.e;
+    p.A = (const __half*)x; p.lda = ldx; p.W = (const __half*)w2; p.out = (__half*)out; p.ldc = ldc;
+    p.bias = (const __half*)b2; p.residual = (const __half*)residual; p.ldr = ldr; p.aux = (const __half*)aux; p.ldaux = ldaux;
+    p.s_acc = s_acc; p.s_res = s_res; p.s_aux = s_aux; p.M = M; p.N = F_C; p.K = D;
+    q.w1 = (const __half*)w1_chunked; q.b1 = (const __half*)b1_chunked; q.D = D;
+    int rc = check_common(p, "feedforward_fused_f16");
+    if (rc) return rc;
+    SYN3R_REQUIRE(ldx % 8 == 0 && ldx >= C, "feedforward_fused_f16: ldx=%lld must be >= C and a multiple of 8", ldx);
+    SYN3R_REQUIRE(((uintptr_t)w1_chunked | (uintptr_t)b1_chunked) % 16 == 0, "feedforward_fused_f16: weights must be 16-byte aligned");
+    return launch_ffn320(q, (hipStream_t)stream);
 }
 
 extern "C" int syn3r_conv2d3x3_f16(const void* X, const void* W, void* out, long long ldc, const void* bias,

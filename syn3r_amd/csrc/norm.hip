@@ -198,10 +198,9 @@ __global__ void __launch_bounds__(256) k_geglu(const __half* __restrict__ x, __h
         const __half* src = x + row * 2 * D + cv * 8;
         half8 hv = *(const half8*)src, gv = *(const half8*)(src + D), o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float g = (float)gv[e];
-            float ge = gelu_erf(g);
-            o[e] = (_Float16)((float)hv[e] * ge);
+        for (int e = 0; e < 8; e += 2) {       // the same packed GELU as the contraction kernels' fused gates (common.h)
+            const syn3r_f2 r = (syn3r_f2){(float)hv[e], (float)hv[e + 1]} * gelu_pk((syn3r_f2){(float)gv[e], (float)gv[e + 1]});
+            o[e] = (_Float16)r.x; o[e + 1] = (_Float16)r.y;
         }
         *(half8*)(y + row * D + cv * 8) = o;
     }

@@ -78,6 +78,12 @@ __device__ __forceinline__ float reduce12(float (&v)[12], int lane) {
 // of two 64-pixel visits.  Splats are staged 128 at a time (one per thread).
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kBwdThreads = 128;
+#ifdef SYN3R_RASTER_STATS      // developer build: [0] lane tests, [1] wavefront visits, [2] visits with an active pixel, [3] active pixels
+__device__ unsigned long long g_bwd_stats[4];
+#define BSTAT(i, n) do { if (lane == 0) atomicAdd(&g_bwd_stats[i], (unsigned long long)(n)); } while (0)
+#else
+#define BSTAT(i, n)
+#endif
 
 __device__ __forceinline__ f2 splat2(float s) { return (f2){s, s}; }
 
@@ -139,17 +145,30 @@ __global__ void __launch_bounds__(kBwdThreads) k_render_bwd(
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
     int todo = total;
+    // The records of round rd + 1 are requested (list entry, then the 48-byte record: two dependent global loads)
+    // BEFORE round rd is processed and land in registers meanwhile: the gather latency is off the critical path.
+    float4 n0, n1, n2;
+    unsigned ngid = 0;
+    bool have = false;
+    auto fetch = [&](int rd) {
+        const int progress = rd * kBwdThreads + threadIdx.x;
+        have = progress < total;
+        if (have) {
+            ngid = point_list[range.x + total - 1 - progress];   // back to front
+            const float4* src = (const float4*)(splats + ngid);
+            n0 = src[0]; n1 = src[1]; n2 = src[2];
+        }
+    };
+    fetch(0);
     for (int rd = 0; rd < rounds; ++rd, todo -= kBwdThreads) {
         __syncthreads();
-        int progress = rd * kBwdThreads + threadIdx.x;
-        if (progress < total) {
-            unsigned gid = point_list[range.x + total - 1 - progress];   // back to front
-            const float4* src = (const float4*)(splats + gid);
-            sm[threadIdx.x * 3 + 0] = src[0];
-            sm[threadIdx.x * 3 + 1] = src[1];
-            sm[threadIdx.x * 3 + 2] = src[2];
-            sid[threadIdx.x] = gid;
+        if (have) {
+            sm[threadIdx.x * 3 + 0] = n0;
+            sm[threadIdx.x * 3 + 1] = n1;
+            sm[threadIdx.x * 3 + 2] = n2;
+            sid[threadIdx.x] = ngid;
         }
+        fetch(rd + 1);
 #pragma unroll
         for (int k = 0; k < kGradSlots / 4; ++k)
             ((float4*)sacc)[threadIdx.x * (kGradSlots / 4) + k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -165,6 +184,8 @@ __global__ void __launch_bounds__(kBwdThreads) k_render_bwd(
                     (total - 1 - (rd * kBwdThreads + c0 + lane)) < wave_live;
           }
           unsigned long long vm = __ballot(hit);
+          BSTAT(0, min(64, cnt - c0));
+          BSTAT(1, __popcll(vm));
           while (vm) {
             const int j = c0 + (int)__builtin_ctzll(vm);
             vm &= vm - 1;
@@ -180,6 +201,9 @@ __global__ void __launch_bounds__(kBwdThreads) k_render_bwd(
             const bool act0 = (contributor < lc0) && (power.x <= 0.0f) && (fminf(kAlphaMax, araw.x) >= kAlphaMin);
             const bool act1 = (contributor < lc1) && (power.y <= 0.0f) && (fminf(kAlphaMax, araw.y) >= kAlphaMin);
             if (__ballot(act0 || act1) == 0ull) continue;   // wave-uniform
+#ifdef SYN3R_RASTER_STATS
+            BSTAT(2, 1); BSTAT(3, __popcll(__ballot(act0)) + __popcll(__ballot(act1)));
+#endif
             // Branch-free: a pixel that does not take this splat blends it with alpha = 0 and G = 0, which is an exact
             // no-op on its running state (T * rcp(1) = T, the colour recursion absorbs a zero-weight layer exactly)
             // and makes every gradient term an exact zero - no EXEC-masked region.
@@ -476,3 +500,11 @@ extern "C" int syn3r_raster_backward(int N, int sh_degree, int sh_coeffs, long l
     SYN3R_LAUNCH_CHECK("raster_backward launch");
     return SYN3R_OK;
 }
+
+#ifdef SYN3R_RASTER_STATS
+extern "C" __attribute__((visibility("default"))) int syn3r_debug_bwd_stats(unsigned long long* out4, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_bwd_stats), sizeof(unsigned long long) * 4);
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stats), z, sizeof(z)); }
+    return rc;
+}
+#endif

@@ -344,6 +344,12 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 // (v_pk_fma_f32 / v_pk_mul_f32: two pixels per VALU issue); exp, min and the compares stay one per pixel.
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kFwdThreads = 128;
+#ifdef SYN3R_RASTER_STATS      // developer build: [0] lane tests, [1] wavefront visits, [2] visits with an active pixel, [3] active pixels
+__device__ unsigned long long g_fwd_stats[4];
+#define FSTAT(i, n) do { if (lane == 0) atomicAdd(&g_fwd_stats[i], (unsigned long long)(n)); } while (0)
+#else
+#define FSTAT(i, n)
+#endif
 
 __global__ void __launch_bounds__(kFwdThreads) k_render(int H, int W, int gx, int gy, const uint2* __restrict__ ranges,
                                                         const unsigned* __restrict__ point_list,
@@ -370,16 +376,27 @@ __global__ void __launch_bounds__(kFwdThreads) k_render(int H, int W, int gx, in
     int todo = total;
     const float sx0 = (float)(tx * kTileX), sx1 = sx0 + 15.0f;
     const float sy0 = (float)(ty * kTileY + wq * 8), sy1 = sy0 + 7.0f;
+    // The records of round rd + 1 are requested (list entry, then the 48-byte record: two dependent global loads)
+    // BEFORE round rd is blended and land in registers meanwhile: the gather latency is off the critical path.
+    float4 n0, n1, n2;
+    bool have = false;
+    auto fetch = [&](int rd) {
+        const int idx = rd * kFwdThreads + threadIdx.x;
+        have = idx < total;
+        if (have) {
+            const float4* src = (const float4*)(splats + point_list[range.x + idx]);
+            n0 = src[0]; n1 = src[1]; n2 = src[2];
+        }
+    };
+    fetch(0);
     for (int rd = 0; rd < rounds; ++rd, todo -= kFwdThreads) {
         if (__syncthreads_count(done0 && done1) == kFwdThreads) break;
-        int idx = rd * kFwdThreads + threadIdx.x;
-        if (idx < total) {
-            unsigned gid = point_list[range.x + idx];
-            const float4* src = (const float4*)(splats + gid);
-            sm[threadIdx.x * 3 + 0] = src[0];
-            sm[threadIdx.x * 3 + 1] = src[1];
-            sm[threadIdx.x * 3 + 2] = src[2];
+        if (have) {
+            sm[threadIdx.x * 3 + 0] = n0;
+            sm[threadIdx.x * 3 + 1] = n1;
+            sm[threadIdx.x * 3 + 2] = n2;
         }
+        fetch(rd + 1);
         __syncthreads();
         const int cnt = min(kFwdThreads, todo);
         // Visit list: each lane tests ONE staged splat against the wavefront's 16 x 8 half (splat_reaches_rect); the
@@ -394,6 +411,8 @@ __global__ void __launch_bounds__(kFwdThreads) k_render(int H, int W, int gx, in
                 hit = splat_reaches_rect(a.x, a.y, a.z, a.w, b.x, b.y, sx0, sx1, sy0, sy1);
             }
             unsigned long long m = __ballot(hit);
+            FSTAT(0, min(64, cnt - c0));
+            FSTAT(1, __popcll(m));
             while (m) {
                 const int j = c0 + (int)__builtin_ctzll(m);
                 m &= m - 1;
@@ -411,6 +430,9 @@ __global__ void __launch_bounds__(kFwdThreads) k_render(int H, int W, int gx, in
                 if (c0_ && test_T.x < kTransmittanceMin) done0 = true;
                 if (c1_ && test_T.y < kTransmittanceMin) done1 = true;
                 const bool t0 = c0_ && !done0, t1 = c1_ && !done1;
+#ifdef SYN3R_RASTER_STATS
+                { unsigned long long b0 = __ballot(t0), b1 = __ballot(t1); FSTAT(2, (b0 | b1) != 0ull); FSTAT(3, __popcll(b0) + __popcll(b1)); }
+#endif
                 // a pixel that does not take the splat adds a zero weight and keeps its transmittance: branch-free
                 const f2 w = (f2){t0 ? al0 : 0.0f, t1 ? al1 : 0.0f} * T;
                 Cr += b.z * w; Cg += b.w * w; Cb += c.x * w; Dp += c.y * w;
@@ -566,3 +588,11 @@ extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const i
     if (point_list_out) *point_list_out = point_list;
     return SYN3R_OK;
 }
+
+#ifdef SYN3R_RASTER_STATS
+extern "C" __attribute__((visibility("default"))) int syn3r_debug_fwd_stats(unsigned long long* out4, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_fwd_stats), sizeof(unsigned long long) * 4);
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_stats), z, sizeof(z)); }
+    return rc;
+}
+#endif

@@ -293,8 +293,13 @@ class UNetSpatioTemporalConditionModel:
         for k in list(p.t):
             if k.endswith(".net.0.proj.weight"):
                 pre = k[: -len("weight")]
-                wp, bp, D = ops.pack_geglu(p.t[k], p.t[pre + "bias"])
-                pk[pre + "geglu_w"], pk[pre + "geglu_b"] = wp, bp
+                if p.t[k].shape[1] == ops.FUSED_FF_CHANNELS and os.environ.get("SYN3R_FF_FUSED") != "0":
+                    # C = 320: the single-kernel feed-forward (per-64-chunk packing); the two-kernel packing is not kept
+                    wp, bp, D = ops.pack_geglu_chunked(p.t[k], p.t[pre + "bias"])
+                    pk[pre + "geglu_cw"], pk[pre + "geglu_cb"] = wp, bp
+                else:
+                    wp, bp, D = ops.pack_geglu(p.t[k], p.t[pre + "bias"])
+                    pk[pre + "geglu_w"], pk[pre + "geglu_b"] = wp, bp
         self.packed = pk
         # AlphaBlender scales as host floats, computed ONCE (reading a device scalar per block would drain the
         # launch queue 60 times per forward): alpha in fp16 as `alpha.to(x_spatial.dtype)` (resnet.py:797), and
@@ -344,8 +349,12 @@ class UNetSpatioTemporalConditionModel:
         return ops.linear(v, self.w(pre + ".to_out.0.weight"), self.w(pre + ".to_out.0.bias"))
 
     def _ff(self, pre: str, x: torch.Tensor, **epilogue) -> torch.Tensor:
-        wp = self.w(pre + ".net.0.proj.geglu_w")
         D = self.p.shapes[pre + ".net.0.proj.weight"][0] // 2
+        cw = self.packed.get(pre + ".net.0.proj.geglu_cw")
+        if cw is not None:               # C = 320: one kernel, no intermediate in HBM
+            return ops.feedforward_fused(x, cw, self.packed[pre + ".net.0.proj.geglu_cb"], D, self.w(pre + ".net.2.weight"),
+                                         self.w(pre + ".net.2.bias"), **epilogue)
+        wp = self.w(pre + ".net.0.proj.geglu_w")
         if os.environ.get("SYN3R_FF_TILED") == "0":      # tuning: row-major intermediate, two separate calls
             return ops.linear(ops.linear_geglu(x, wp, self.w(pre + ".net.0.proj.geglu_b"), D),
                               self.w(pre + ".net.2.weight"), self.w(pre + ".net.2.bias"), **epilogue)

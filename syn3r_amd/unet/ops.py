@@ -111,6 +111,47 @@ def feedforward(x: torch.Tensor, w1_packed: torch.Tensor, b1_packed: torch.Tenso
     return out
 
 
+def pack_geglu_chunked(weight: torch.Tensor, bias: torch.Tensor):
+    """Regroup the [2D, K] GEGLU projection per 64-wide hidden chunk j as 4 x [hidden 64j+16q..+15 | gate 64j+16q..+15]
+    (q = 0..3): the layout syn3r_feedforward_fused_f16 expects (w1_chunked [D/64 * 128, K], b1_chunked [D/64 * 128])."""
+    D2, K = weight.shape
+    D = D2 // 2
+    if D % 64:
+        raise ValueError("pack_geglu_chunked: hidden width must be a multiple of 64")
+    idx = []
+    for j in range(D // 64):
+        for q in (0, 16, 32, 48):
+            idx.extend(range(64 * j + q, 64 * j + q + 16))
+            idx.extend(range(D + 64 * j + q, D + 64 * j + q + 16))
+    idx = torch.tensor(idx, device=weight.device)
+    return weight.index_select(0, idx).contiguous(), bias.index_select(0, idx).contiguous(), D
+
+
+FUSED_FF_CHANNELS = 320      # syn3r_feedforward_fused_f16 is built for this width (level 0 of the SVD UNet)
+
+
+def feedforward_fused(x: torch.Tensor, w1_chunked: torch.Tensor, b1_chunked: torch.Tensor, D: int, w2: torch.Tensor,
+                      b2: Optional[torch.Tensor] = None, *, residual: Optional[torch.Tensor] = None,
+                      aux: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0, s_aux: float = 1.0) -> torch.Tensor:
+    """FeedForward.forward (attention.py:608-665) in ONE kernel for C = 320: geglu(x @ W1^T + b1) @ W2^T + b2 with the
+    `linear` epilogue; the hidden activation never leaves the CU (syn3r_feedforward_fused_f16)."""
+    dev = _chk(w1_chunked, b1_chunked, w2, b2, residual, aux)
+    L.require_gpu(x)
+    M, K = x.shape
+    N = w2.shape[0]
+    if x.stride(1) != 1 or K != N or w2.shape[1] != D or tuple(w1_chunked.shape) != (2 * D, K):
+        raise ValueError(f"feedforward_fused: x {tuple(x.shape)} / w1 {tuple(w1_chunked.shape)} / w2 {tuple(w2.shape)} / D={D} mismatch")
+    out = torch.empty((M, N), dtype=H, device=dev)
+    rc = L.load().syn3r_feedforward_fused_f16(
+        x.data_ptr(), x.stride(0), L.ptr(w1_chunked), L.ptr(b1_chunked), D, L.ptr(w2), L.ptr(b2), L.ptr(out), N,
+        residual.data_ptr() if residual is not None else None, residual.stride(0) if residual is not None else 0,
+        aux.data_ptr() if aux is not None else None, aux.stride(0) if aux is not None else 0,
+        float(s_acc), float(s_res), float(s_aux), M, K, L.stream_ptr(dev))
+    L.check(rc, "syn3r_feedforward_fused_f16")
+    _count("gemm", 2.0 * M * 2 * D * K + 2.0 * M * N * D)
+    return out
+
+
 def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride: int = 1,
             upsample: bool = False, rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0,
             residual: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0,

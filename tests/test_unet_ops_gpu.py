@@ -280,6 +280,48 @@ def test_feedforward_tiled_intermediate(M, C, D, gpu):
     close(ops.feedforward(x, wp, bp, D, w2, b2), h @ w2.float().T + b2.float(), tol=4e-3)
 
 
+@pytest.mark.parametrize("M,D", [(128, 64), (700, 1280), (4097, 1280), (129, 192)])
+def test_feedforward_fused_c320(M, D, gpu):
+    """`feedforward_fused` (syn3r_feedforward_fused_f16: x -> net.0 -> GEGLU -> net.2 in one kernel, C = 320) against the
+    two-kernel path (same arithmetic: fp32 accumulation in k order, projection and gate rounded to fp16) and the fp32
+    restatement of FeedForward (attention.py:608-665); ragged M, one and many hidden chunks, the full epilogue."""
+    from syn3r_amd.unet import ops
+    C = 320
+    g = torch.Generator().manual_seed(M + D)
+    x = rnd(g, M, C, dev=gpu)
+    w1, b1 = rnd(g, 2 * D, C, scale=C ** -0.5, dev=gpu), rnd(g, 2 * D, dev=gpu)
+    w2, b2 = rnd(g, C, D, scale=D ** -0.5, dev=gpu), rnd(g, C, dev=gpu)
+    res, aux = rnd(g, M, C, dev=gpu), rnd(g, M, C, dev=gpu)
+    wc, bc, d_ = ops.pack_geglu_chunked(w1, b1)
+    assert d_ == D and wc.shape == (2 * D, C)
+    wp, bp, _ = ops.pack_geglu(w1, b1)
+    out = ops.feedforward_fused(x, wc, bc, D, w2, b2, residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25)
+    ref2 = ops.feedforward(x, wp, bp, D, w2, b2, residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25)
+    close(out, ref2.float(), tol=2e-3)
+    y = (x.float() @ w1.float().T + b1.float()).half().float()
+    h = (y[:, :D] * Fn.gelu(y[:, D:])).half().float()
+    close(ops.feedforward_fused(x, wc, bc, D, w2, b2), h @ w2.float().T + b2.float(), tol=4e-3)
+    close(ops.feedforward_fused(x, wc, bc, D, w2, None, residual=res), h @ w2.float().T + res.float(), tol=4e-3)
+    # a column slice of a wider matrix as the input (row stride > C)
+    wide = rnd(g, M, 2 * C, dev=gpu)
+    close(ops.feedforward_fused(wide[:, C:], wc, bc, D, w2, b2),
+          ((wide[:, C:].float() @ w1.float().T + b1.float()).half().float()[:, :D]
+           * Fn.gelu((wide[:, C:].float() @ w1.float().T + b1.float()).half().float()[:, D:])).half().float() @ w2.float().T + b2.float(),
+          tol=4e-3)
+    assert torch.equal(out, ops.feedforward_fused(x, wc, bc, D, w2, b2, residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25))
+
+
+def test_feedforward_fused_rejects_other_widths(gpu):
+    from syn3r_amd import _lib
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(2)
+    x = rnd(g, 64, 640, dev=gpu)
+    w1, b1 = rnd(g, 2 * 128, 640, dev=gpu), rnd(g, 2 * 128, dev=gpu)
+    wc, bc, _ = ops.pack_geglu_chunked(w1, b1)
+    with pytest.raises(_lib.Syn3rError, match="C = 320"):
+        ops.feedforward_fused(x, wc, bc, 128, rnd(g, 640, 128, dev=gpu))
+
+
 def test_feedforward_rejects_bad_input(gpu):
     from syn3r_amd import _lib
     from syn3r_amd.unet import ops
