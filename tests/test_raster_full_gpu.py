@@ -139,7 +139,7 @@ def _edge_scene(kind, N, H, W):
     if kind == "opaque_front":        # a few large, nearly opaque Gaussians in front: T < 1e-4 after three of them
         m[:6, 2] = 2.0 + 0.01 * torch.arange(6, dtype=dt)
         s[:6] = 2.0
-        o[:6] = 0.995
+        o[:6] = 0.98          # alpha < 0.99 (no clamp): T = 0.02^k never sits ON the 1e-4 threshold
     elif kind == "whole_frame":       # one Gaussian whose 3-sigma footprint covers every tile
         m[0] = torch.tensor([0.0, 0.0, 2.5], dtype=dt)
         s[0] = 3.0
