@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--loss", choices=["l1", "l1+ssim"], default="l1",
                     help="photometric loss of the raster iteration (SURVEY 8d defines the composite with L1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub-benchmarks", action="store_true",
+                    help="skip the extra timed sub-results (Post / Replace units at F = 25, full trainer iteration, inverse warp)")
     ap.add_argument("--no-kernel-trace", action="store_true",
                     help="skip the HIP-event kernel timing (rocprofv3 --pmc passes: the counters serialise every launch)")
     ap.add_argument("--trace-steps", type=int, default=1,
@@ -88,6 +90,43 @@ class RasterLoop:
         for t in list(p.values()) + [self.m2]:
             t.grad = None
         return loss
+
+    def full_iteration_rate(self, iters: int = 50) -> float:
+        """A COMPLETE trainer iteration as `GSTrainer.train_step` runs it (render -> 0.8 L1 + 0.2 (1 - SSIM), FSGS's default
+        lambda_dssim -> backward -> fused Adam step on all five parameter groups), no host synchronisation inside:
+        iterations per second.  Runs on copies of the parameters (the headline loop's inputs stay fixed)."""
+        from syn3r_amd.gs.train_ops import FusedAdam, photometric_loss
+        ps = {k: v.detach().clone().requires_grad_(True) for k, v in self.p.items()}
+        opt = FusedAdam([{"params": [ps["m"]], "lr": 1.6e-4}, {"params": [ps["sh"]], "lr": 2.5e-3}, {"params": [ps["o"]], "lr": 5e-2},
+                         {"params": [ps["s"]], "lr": 5e-3}, {"params": [ps["q"]], "lr": 1e-3}], eps=1e-15)
+
+        def one():
+            color, _, _, _ = self.rast(ps["m"], self.m2, ps["o"], shs=ps["sh"], scales=ps["s"], rotations=ps["q"])
+            loss = photometric_loss(color, self.target, 0.2)
+            opt.zero_grad(set_to_none=True)
+            self.m2.grad = None
+            loss.backward()
+            opt.step()
+
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            one()
+        torch.cuda.synchronize()
+        return iters / (time.perf_counter() - t0)
+
+    def metrics(self):
+        """device-side PSNR / SSIM of the current render against the loop's target (the psnr / ssim columns of the
+        per-scene record; the synthetic target is noise, so the values only exercise the path)"""
+        from syn3r_amd.gs.train_ops import image_metrics
+        p = self.p
+        with torch.no_grad():
+            color, _, _, _ = self.rast(p["m"].detach(), self.m2.detach(), p["o"].detach(), shs=p["sh"].detach(),
+                                       scales=p["s"].detach(), rotations=p["q"].detach())
+            m = image_metrics(color.clamp(0, 1), self.target)
+        return float(m[0]), float(m[1])
 
     def pairs(self):
         """number of (Gaussian, tile) pairs of this scene/camera (for the roofline byte count)"""
@@ -198,27 +237,92 @@ def cpu_baseline(args, with_unet: bool):
                          f"value = {args.raster_iters} / ({args.raster_iters} x raster + unit)")
 
 
+def other_rooflines(kern, alg, loop_b, units):
+    """Roofline entries of the other kernels of the path next to the dominant one (same HIP-event trace):
+    the blend kernels against SURVEY 8d's byte model (they are VALU-issue-bound, see DESIGN.md: the HBM fraction says how
+    far the traffic is from mattering, not how good the kernel is) and the spatial attention against the MFMA peak."""
+    out = {}
+    for name in ("k_render_bwd", "k_render"):
+        if name in kern and name in alg:
+            calls, ms = kern[name]
+            ach = alg[name] / (ms / calls / 1e3) / 1e9
+            out[name] = dict(bound="hbm (SURVEY 8d byte model; measured VALU-issue-bound)", achieved=round(ach, 1), peak=HBM_PEAK_GBS,
+                             unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), avg_ms=round(ms / calls, 4), calls=calls,
+                             algorithmic_bytes=alg[name])
+    if loop_b is not None and "k_attn_spatial" in kern and loop_b.flops_per_unit:
+        calls, ms = kern["k_attn_spatial"]
+        ach = loop_b.flops_per_unit["attn"] * units / (ms / 1e3) / 1e12
+        out["k_attn_spatial"] = dict(bound="mfma", achieved=round(ach, 1), peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
+                                     frac=round(ach / MFMA_F16_PEAK_TFLOPS, 4), avg_ms=round(ms / calls, 4), calls=calls)
+    return out
+
+
+def sub_benchmarks(args, dev, loop_a, loop_b, log):
+    """Timed here, by the same process, AFTER the headline's timed region (rank 0 of the 1-GPU run): the configurations
+    the reference's scripts actually run next to BASELINE config 2's — the Post unit at F = 25
+    (bash_scripts/batch_llff_train.sh:39), the Replace unit at F = 25 (batch_dtu_train.sh:42), a complete trainer
+    iteration (L1 + SSIM + Adam), and the fused inverse warp at 576x1024 with its SURVEY 8d roofline."""
+    from syn3r_amd import _lib as L
+    out = {}
+
+    def wall_ms(fn, n):
+        fn(); fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+
+    if loop_b is not None:
+        from syn3r_amd.pipeline.svd_step import SvdStepBench
+        out["svd_post_unit_f14_ms"] = round(wall_ms(loop_b.step_pass_post, 3), 2)
+        b25 = SvdStepBench(25, dev, seed=args.seed, unet=loop_b.unet)
+        out["svd_replace_unit_f25_ms"] = round(wall_ms(b25.step_pass, 3), 2)
+        out["svd_post_unit_f25_ms"] = round(wall_ms(b25.step_pass_post, 3), 2)
+        # one svd_render = 100 denoise steps x 2 passes of the unit (SURVEY 3.3)
+        out["svd_render_f25_s"] = {"replace": round(0.2 * out["svd_replace_unit_f25_ms"], 1), "post": round(0.2 * out["svd_post_unit_f25_ms"], 1)}
+        del b25
+        torch.cuda.empty_cache()
+        log("sub-benchmarks: SVD units done")
+    out["raster_full_iteration_per_s"] = round(loop_a.full_iteration_rate(50), 1)
+    out["raster_full_iteration_note"] = "render + (0.8 L1 + 0.2 (1-SSIM)) + backward + fused Adam on 5 parameter groups, no host sync"
+    # fused inverse warp + reprojection consistency (W2 + C1) at the reference's 576x1024 working size
+    from syn3r_amd.solver_utils.forward_warp import inverse_warp
+    H, W = 576, 1024
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    depth = torch.from_numpy((2 + 0.5 * np.sin(xs / 97) + 0.3 * np.cos(ys / 53)).astype(np.float32)).to(dev)
+    K = torch.tensor([[800, 0, W / 2], [0, 800, H / 2], [0, 0, 1]], dtype=torch.float32, device=dev)
+    T1 = torch.eye(4, device=dev)
+    T2 = torch.eye(4, device=dev); T2[0, 3], T2[2, 3] = 0.05, 0.02
+    img = torch.rand(3, H, W, generator=torch.Generator().manual_seed(0)).to(dev)
+    fn = lambda: inverse_warp(img, depth[None], depth[None], T1, T2, K, bandwidth=20)
+    fn(); torch.cuda.synchronize()
+    with L.kernel_trace() as tr:
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+    us = 1e3 * sum(v[1] for v in tr.result.values()) / 20
+    gbs = 49.0 * H * W / (us * 1e-6) / 1e9
+    out["inverse_warp_576x1024"] = {"device_us": round(us, 1), "kernels": {k: round(1e3 * v[1] / 20, 1) for k, v in tr.result.items()},
+                                    "roofline": {"bound": "hbm", "algorithmic_bytes": 49 * H * W, "achieved": round(gbs, 1),
+                                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                                 "note": "29 MB per call: two launches of ~13 us each, latency- not bandwidth-limited"}}
+    return out
+
+
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the SYN3R hot path has no CPU fallback)")
     # rehearsal knobs (not used by the driver): all ranks on one GPU and/or gloo instead of RCCL
     if os.environ.get("SYN3R_BENCH_SINGLE_DEVICE") == "1":
-        local = 0
-    backend = os.environ.get("SYN3R_BENCH_BACKEND", "nccl")
+        os.environ["LOCAL_RANK"] = "0"
+    from syn3r_amd import dist as D
+    rank, world, local = D.init(os.environ.get("SYN3R_BENCH_BACKEND"))     # one process per GPU; "nccl" is RCCL
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cdev = dev if backend == "nccl" else torch.device("cpu")     # where collective payloads live
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    dist = torch.distributed if world > 1 else None
     from syn3r_amd import _lib as L
     L.load()
 
@@ -256,7 +360,7 @@ def main():
     barrier()
     # start/stop events only on the kernels that can be the dominant one (a timed launch costs microseconds):
     # the contraction family and the spatial attention when the SVD unit is part of the step, else the blend kernels
-    only = "k_gemm,k_attn_spatial" if loop_b is not None else "k_render"
+    only = "k_gemm,k_attn_spatial,k_render" if loop_b is not None else "k_render"
     # ... and only during the last --trace-steps of the timed steps: still inside the timed region, for a fraction
     # of the events' cost (2-3 % of a step when every launch of every step is timed)
     traced = 0 if args.no_kernel_trace else max(1, min(args.trace_steps, args.steps))
@@ -271,19 +375,12 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
     log(f"timed region done: {dt:.3f} s")
-    tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max = float(tmax.item())
-
-    # one collective at the end: fixed-size per-rank record (scene id, iters/s, svd units/s, wall)
-    rec = torch.tensor([rank, args.raster_iters * args.steps / dt, (args.steps / dt) if loop_b else 0.0, dt],
-                       device=cdev, dtype=torch.float32)
-    if dist is not None:
-        allrec = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(allrec, rec)
-    else:
-        allrec = [rec]
+    # ONE collective at the end (north_star): the fixed 8-field per-scene record of syn3r_amd/dist.py; the job's time is
+    # the MAX of the ranks' wall-clocks, read from the gathered records
+    psnr, ssim = loop_a.metrics()
+    rec = [float(rank), psnr, ssim, float("nan"), args.raster_iters * args.steps / dt, (args.steps / dt) if loop_b else 0.0, dt, 1.0]
+    allrec = D.gather_records(rec)
+    dt_max = float(allrec[:, D.RECORD_FIELDS.index("wall_s")].max())
 
     if rank == 0:
         iters = args.raster_iters * args.steps * world
@@ -330,9 +427,14 @@ def main():
                 "parallelism": f"scene-parallel x{world}",
             },
             "roofline": dict(roof, traced_steps=traced) if roof else roof,
+            "roofline_other": other_rooflines(kern, alg, loop_b, max(traced, 1)),
             "kernels_ms": {k: [v[0], round(v[1], 3)] for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])[:12]},
-            "per_rank": [[round(float(x), 3) for x in r.tolist()] for r in allrec],
+            "record_fields": list(D.RECORD_FIELDS),
+            "per_rank": [[None if x != x else round(float(x), 3) for x in r.tolist()] for r in allrec],
         }
+        if not args.no_sub_benchmarks and world == 1:
+            log("sub-benchmarks (Post / Replace units at F = 25, full trainer iteration, inverse warp) ...")
+            out["sub_benchmarks"] = sub_benchmarks(args, dev, loop_a, loop_b, log)
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 of the single-GPU run only
             log("cpu baseline (oracle on the host cores, bounded sample) ...")
             out["cpu_baseline"] = cpu_baseline(args, loop_b is not None)

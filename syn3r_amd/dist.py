@@ -54,6 +54,24 @@ def gather_records(record: Sequence[float], device: torch.device | None = None) 
     return torch.stack(out)
 
 
+def gather_record_table(records: Sequence[Sequence[float]], device: torch.device | None = None) -> torch.Tensor:
+    """All-gather a rank's [k, fields] table of records (k equal on every rank: pad with NaN / ok = 0 rows) in ONE
+    collective -> [world * k, fields] on every rank, rank-major.  This is the job's only collective."""
+    rows = [list(r) for r in records]
+    if any(len(r) != len(RECORD_FIELDS) for r in rows):
+        raise ValueError(f"every record must have {len(RECORD_FIELDS)} fields: {RECORD_FIELDS}")
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if (
+            dist.is_initialized() and dist.get_backend() == "nccl") else torch.device("cpu")
+    tab = torch.tensor(rows, dtype=torch.float32, device=device).reshape(len(rows), len(RECORD_FIELDS))
+    if world == 1:
+        return tab
+    out = [torch.empty_like(tab) for _ in range(world)]
+    dist.all_gather(out, tab)
+    return torch.cat(out)
+
+
 def summary_table(records: torch.Tensor) -> str:
     """`scripts/summarize_dl3dv.py`-style table of the gathered records."""
     rows = ["  ".join(f"{f:>18s}" for f in RECORD_FIELDS)]

@@ -195,7 +195,7 @@ class StableVideoDiffusionPipeline:
         weight_fw = torch.linspace(1, 0, F)[None, :, None, None, None].to(device=dev, dtype=latents.dtype)
         step = self._pass_post if self.variant == "post" else self._pass_replace
         mask = mask.to(dev)
-        lambda_ts = lambda_ts.to(dev)
+        lambda_ts = lambda_ts.detach().to("cpu", torch.float64)     # read on the host, one row per step: never a device sync
         cond_bw, mask_bw, lam_bw = temp_cond_latents.flip(dims=[1]), mask.flip(dims=[1]), lambda_ts.flip(dims=[1])
         for i, t in enumerate(timesteps):
             fw = step(i, t, latents, image_latent_start, emb_start, added_time_ids, temp_cond_latents, mask, lambda_ts,

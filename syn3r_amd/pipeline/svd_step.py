@@ -24,9 +24,9 @@ def cfg_combine(noise_pred: torch.Tensor, guidance_scale: torch.Tensor) -> torch
 
 
 class SvdStepBench:
-    def __init__(self, frames: int, dev: torch.device, seed: int = 1234, h: int = 72, w: int = 128):
+    def __init__(self, frames: int, dev: torch.device, seed: int = 1234, h: int = 72, w: int = 128, unet=None):
         self.F, self.h, self.w, self.dev = frames, h, w, dev
-        self.unet = UNetSpatioTemporalConditionModel().init_random(dev, seed=seed)
+        self.unet = unet if unet is not None else UNetSpatioTemporalConditionModel().init_random(dev, seed=seed)
         self.sch = EulerDiscreteScheduler(**SVD_XT_SCHEDULER_CONFIG)
         self.sch.set_timesteps(100)
         g = torch.Generator(device=dev).manual_seed(seed)
@@ -41,7 +41,7 @@ class SvdStepBench:
         self.added = torch.tensor([[6.0, 127.0, 0.02]] * 2, device=dev).half()
         m = torch.rand(1, F - 2, 1, h, w, generator=g, device=dev)
         self.mask = m.expand(1, F - 2, 4, h, w).contiguous()
-        self.lambda_ts = (torch.rand(100, F, generator=g, device=dev) > 0.5).double()
+        self.lambda_ts = (torch.rand(100, F, generator=g, device=dev) > 0.5).double().cpu()     # host-side schedule, as the pipeline keeps it
         self.guidance = torch.linspace(1.0, 3.0, F, device=dev).half()[None, :, None, None, None]
         self.i = 0
         self.flops_per_unit = None
@@ -58,6 +58,19 @@ class SvdStepBench:
         out = self.sch.step_interp_prob_uncertain(noise_pred, t, self.latents, self.temp_cond, self.mask,
                                                   self.lambda_ts, step_i=i)
         return out.prev_sample
+
+    def step_pass_post(self) -> torch.Tensor:
+        """One (step, pass) unit of the "Post" variant (model/SVD_2pass_prob_uncertain_post.py:700-800): the four
+        guidance-tile forwards + gradient step, then the CFG forward and the plain Euler step — the variant
+        `bash_scripts/batch_llff_train.sh:39` runs (at F = 25)."""
+        from .svd_2pass import StableVideoDiffusionPipeline
+        if getattr(self, "_post_pipe", None) is None:
+            self._post_pipe = StableVideoDiffusionPipeline(None, None, self.unet, self.sch, variant="post", device=self.dev)
+            self._post_pipe._guidance_scale = self.guidance
+        i = self.i % 100
+        self.i += 1
+        return self._post_pipe._pass_post(i, self.sch.timesteps[i], self.latents, self.image_latents, self.ehs, self.added,
+                                          self.temp_cond, self.mask, self.lambda_ts, True)
 
     def count_flops(self) -> dict:
         """Algorithmic FLOPs of one unit, counted from the launched contractions (2*M*N*K)."""
@@ -94,19 +107,41 @@ class SvdStepBench:
                     avg_ms=round(ms / calls, 4), calls=calls, algorithmic_flops_per_unit=self.flops_per_unit)
 
 
+def source_id() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources the running library was built from (csrc/*.hip, *.h and the
+    C-ABI header): identifies WHICH build a committed PMC pass measured."""
+    import hashlib
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    h = hashlib.sha256()
+    for f in sorted(list((root / "csrc").glob("*.hip")) + list((root / "csrc").glob("*.h")) + list((root.parent / "include").glob("*.h"))):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def _pmc_traffic(kernel: str):
     """(HBM bytes per launch of `kernel`, where the number comes from) out of the committed rocprofv3 PMC passes
-    (profiles/*/traffic.json; bench.py cannot run the profiler on itself).  (None, None) if no profile of this
-    kernel is committed."""
+    (profiles/*/traffic.json; bench.py cannot run the profiler on itself).  The file records the `source_id` of the
+    kernel sources it profiled: if that differs from the running build the number is STALE and (None, reason) is
+    returned — `traffic: null` in the bench line rather than a silently outdated figure."""
     import json
     from pathlib import Path
     root = Path(__file__).resolve().parents[2] / "profiles"
+    cur = source_id()
+    stale = None
     for f in sorted(root.glob("r*/traffic.json"), reverse=True):
         try:
-            rec = json.loads(f.read_text()).get(kernel)
+            doc = json.loads(f.read_text())
         except (OSError, ValueError):
             continue
-        if rec:
-            return rec["hbm_bytes_per_launch"], (f"{f.relative_to(root.parent)}: PMC FETCH_SIZE x2 (gfx950 correction) + "
-                                                 "WRITE_SIZE, averaged over the launches of the profiled run")
-    return None, None
+        rec = doc.get(kernel)
+        if not rec:
+            continue
+        if doc.get("_source_id") != cur:
+            stale = stale or (f"{f.relative_to(root.parent)} was measured on kernel sources {doc.get('_source_id', 'unrecorded')}, "
+                              f"the running build is {cur}: not reported")
+            continue
+        return rec["hbm_bytes_per_launch"], (f"{f.relative_to(root.parent)} (sources {cur}): PMC FETCH_SIZE x2 (gfx950 correction) + "
+                                             "WRITE_SIZE, averaged over the launches of the profiled run")
+    return None, stale

@@ -203,12 +203,29 @@ class EulerDiscreteScheduler:
             b, cond_len, c2, h2, w2 = temp_cond_latents.shape
             if (cond_len, c2, h2, w2) != (F, Cc, h, w) or b < 2:
                 raise ValueError(f"temp_cond_latents {tuple(temp_cond_latents.shape)} does not match the sample")
-            cond = temp_cond_latents[1].detach().to(device=dev, dtype=torch.float32).contiguous()
-            msk = mask.detach().to(device=dev, dtype=torch.float32)
-            msk = msk.expand(1, F - 2, Cc, h, w).contiguous()
-            lam_row = lambda_ts[self.step_index]
-            lam = L.host_f64(lam_row.detach().to("cpu", torch.float64).tolist())
+            # the conditioning latents, the mask and the lambda schedule are the same objects at every step of a pass:
+            # their kernel-side forms (fp32 cond slice, expanded mask, HOST copy of lambda_ts) are prepared once per
+            # object, not once per call — a device-resident lambda_ts used to cost a blocking device->host copy per call
+            cond = self._prepared("cond", temp_cond_latents,
+                                  lambda t: t[1].detach().to(device=dev, dtype=torch.float32).contiguous())
+            msk = self._prepared("mask", mask, lambda t: t.detach().to(device=dev, dtype=torch.float32)
+                                 .expand(1, F - 2, Cc, h, w).contiguous())
+            lam_host = self._prepared("lambda", lambda_ts, lambda t: t.detach().to("cpu", torch.float64).numpy().copy())
+            lam = L.host_f64(lam_host[self.step_index].tolist())
         return dev, v, x, cond, msk, lam, (F, Cc, h, w)
+
+    def _prepared(self, slot: str, src: torch.Tensor, make):
+        """Per-object cache (identity + in-place version counter; the entry keeps `src` alive, so its address cannot be
+        handed to another tensor meanwhile).  A few entries per slot: the forward and the time-flipped backward pass
+        alternate two sets of objects."""
+        cache = self.__dict__.setdefault("_prep_cache", {}).setdefault(slot, [])
+        for ent in cache:
+            if ent[0] is src and ent[1] == src._version:
+                return ent[2]
+        val = make(src)
+        cache.insert(0, (src, src._version, val))
+        del cache[4:]
+        return val
 
     def step_interp(self, model_output, timestep, sample, temp_cond_latents=None, mask=None, lambda_ts=None,
                     step_i=None, lr=None, compute_grad=False, return_dict: bool = True):

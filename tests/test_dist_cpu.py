@@ -23,6 +23,8 @@ WORKER = textwrap.dedent("""
     assert allrec.shape == (world, len(D.RECORD_FIELDS))
     assert allrec[:, 0].tolist() == [float(r) for r in range(world)]
     assert torch.isnan(allrec[1, 1]) and allrec[0, 1] == 20.0
+    tab = D.gather_record_table([rec, [math.nan] * 7 + [0.0]])
+    assert tab.shape == (2 * world, len(D.RECORD_FIELDS)) and tab[2 * rank, 0] == float(rank) and tab[2 * rank + 1, -1] == 0.0
     if rank == 0:
         table = D.summary_table(allrec)
         assert "mean over finished scenes" in table
@@ -57,3 +59,17 @@ def test_single_process_gather():
     rec = D.gather_records([0, 30.0, 0.9, 0.1, 100.0, 5.0, 1.0, 1.0], device=__import__("torch").device("cpu"))
     assert rec.shape == (1, 8)
     assert D.assign_scenes(list("abcdefghij"), 1, 8) == ["b", "j"]
+
+
+def test_launcher_arguments_and_assignment():
+    """the launcher keeps scripts/train.py's hot-path flags (:50-66) and deals scenes round-robin"""
+    from syn3r_amd import dist as D
+    from syn3r_amd import launch
+    a = launch.parse(["--scenes", "fern,flower,fortress", "--diffusion_type", "2PassProbUncertain", "--interp_type", "backward_warp",
+                      "--densify_type", "interpolate_loop0_gs", "--refine_cycle_num", "2", "--cam_confidence", "0.05",
+                      "--pseudo_cam_sampling_rate", "0.02", "--num_views_for_pcd_densification", "1", "--dataset", "dtu"])
+    assert a.refine_cycle_num == 2 and a.densify_type == "interpolate_loop0_gs" and a.cam_confidence == 0.05
+    assert D.assign_scenes(a.scenes.split(","), 1, 2) == ["flower"]
+    import pytest
+    with pytest.raises(SystemExit):
+        launch.parse(["--scenes", "x", "--interp_type", "sideways"])

@@ -10,6 +10,10 @@ import collections
 import csv
 import json
 import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from syn3r_amd.pipeline.svd_step import source_id  # noqa: E402
 
 FAMILIES = {"k_gemm": "k_gemm", "k_attn_spatial": "k_attn_spatial", "k_render(": "k_render", "k_render_bwd": "k_render_bwd",
             "k_scatter": "k_scatter", "k_preprocess_bwd": "k_preprocess_bwd"}
@@ -32,7 +36,8 @@ fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_S
 out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on "
                "`python3 bench.py --steps 1 --warmup 0 --raster-iters 5 --no-cpu-baseline --no-kernel-trace`; counters are KB; FETCH_SIZE "
                "doubled (gfx950 tallies the 128-B requests of 16 B/lane streams at 64 B, MI355X_MICROARCH.md HBM); "
-               "WRITE_SIZE as read; per-launch averages over every launch of the kernel family"}
+               "WRITE_SIZE as read; per-launch averages over every launch of the kernel family",
+       "_source_id": source_id()}      # the kernel sources this pass profiled: bench.py reports the traffic only for that build
 for fam in sorted(set(fetch) | set(write)):
     n = max(fetch[fam][0], write[fam][0], 1)
     f_kb, w_kb = fetch[fam][1] / max(fetch[fam][0], 1), write[fam][1] / max(write[fam][0], 1)
