@@ -10,7 +10,11 @@ from pathlib import Path
 
 import torch
 
+import os as _os
+
 _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libsyn3r_hip.so"
+if _os.environ.get("SYN3R_LIB_OVERRIDE"):          # developer A/B runs against another BUILD of the same library (tools/)
+    _LIB_PATH = Path(_os.environ["SYN3R_LIB_OVERRIDE"]).resolve()
 _lib = None
 
 c_f = C.c_float

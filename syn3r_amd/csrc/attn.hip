@@ -111,22 +111,33 @@ __global__ void __launch_bounds__(ATHREADS, 2) k_attn_spatial(AttnParams p) {
         }
     }
 
-    // staging assignment: 64 keys x 8 chunks = 512 chunks, 2 per thread
+    // staging assignment: 64 keys x 8 chunks = 512 chunks, 2 per thread.  The two K and two V source pointers of a
+    // thread advance by one tile (64 rows) per call: no per-tile 64-bit address arithmetic, and the row-in-range test
+    // is wave-uniform (only a sequence's last, partial tile takes the checked path).
     const int s_chunk = tid & 7;
     const int s_key0 = tid >> 3;   // keys s_key0 and s_key0 + 32
     uint4 rk[2], rv[2];
+    const __half* kptr = kp + (row0 + s_key0) * p.ld + s_chunk * 8;
+    const __half* vptr = vp + (row0 + s_key0) * p.ld + s_chunk * 8;
+    const long long half_tile = 32 * p.ld, tile_step = (long long)BKV * p.ld;
     auto load_kv = [&](int kv0) {
+        if (kv0 + BKV <= p.S) {
+            rk[0] = *(const uint4*)kptr; rk[1] = *(const uint4*)(kptr + half_tile);
+            rv[0] = *(const uint4*)vptr; rv[1] = *(const uint4*)(vptr + half_tile);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int key = kv0 + s_key0 + 32 * i;
-            if (key < p.S) {
-                rk[i] = *(const uint4*)(kp + (row0 + key) * p.ld + s_chunk * 8);
-                rv[i] = *(const uint4*)(vp + (row0 + key) * p.ld + s_chunk * 8);
-            } else {
-                rk[i] = make_uint4(0, 0, 0, 0);
-                rv[i] = make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < 2; ++i) {
+                if (kv0 + s_key0 + 32 * i < p.S) {
+                    rk[i] = *(const uint4*)(kptr + i * half_tile);
+                    rv[i] = *(const uint4*)(vptr + i * half_tile);
+                } else {
+                    rk[i] = make_uint4(0, 0, 0, 0);
+                    rv[i] = make_uint4(0, 0, 0, 0);
+                }
             }
         }
+        kptr += tile_step;
+        vptr += tile_step;
     };
     auto store_kv = [&](int buf) {
 #pragma unroll
@@ -163,15 +174,15 @@ __global__ void __launch_bounds__(ATHREADS, 2) k_attn_spatial(AttnParams p) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) kf[g][ks] = *(const half8*)(&Ks[cur][k_off(g * 32 + lq, ks * 2 + h)]);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[g][r] = 0.f;
         // The QK^T MFMAs issue at raised priority: VALU arbitration between the waves of a SIMD is by priority, then
         // age, and at equal priority the other waves' softmax VALU starves this wave's matrix issue (+5 %).
+        // The first MFMA of each chain takes the constant 0 as its C operand: no zeroing of 32 accumulator registers.
+        const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int g = 0; g < 2; ++g) st[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[g][0], qf[0], zero16, 0, 0, 0);
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks)
 #pragma unroll
             for (int g = 0; g < 2; ++g) st[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[g][ks], qf[ks], st[g], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
