@@ -550,6 +550,17 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
     const unsigned b_row = (unsigned)(DMA_A_BYTES + (wn * WN + fr) * 128);
     const unsigned sw0 = (unsigned)(((0 + fq) ^ (fr & 7)) << 4), sw1 = (unsigned)(((4 + fq) ^ (fr & 7)) << 4);
 
+    // BM = 256 (two wavefronts per SIMD behind one barrier): wavefronts 4-7 defer every stage's second MFMA group past
+    // the next barrier (stagger, see k_gemm_wide): they multiply while their SIMD partners issue DMA and read fragments.
+    half8 a0[TM], b0[TN], a1[TM], b1[TN];
+    const bool defer = (BM == 256) && wv >= 4;
+    auto mma1 = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
     int buf = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         if constexpr (DMA_STAGES == 3) {
@@ -562,6 +573,7 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
+        if (defer && kt > 0) mma1();             // second k-half of stage kt-1 (fragments read before the barrier)
         if constexpr (DMA_STAGES == 3) {
             if (kt + 2 < nkt) {
                 int nbuf = buf + 2; if (nbuf >= DMA_STAGES) nbuf -= DMA_STAGES;
@@ -571,7 +583,6 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
             if (kt >= 1 && kt + 1 < nkt) issue_stage(kt + 1, buf ^ 1);   // the slot read in iteration kt-1
         }
         const unsigned sb = lds0 + (unsigned)buf * DMA_STAGE_BYTES;
-        half8 a0[TM], b0[TN], a1[TM], b1[TN];
         {
             const unsigned aa = sb + a_row + sw0, ba = sb + b_row + sw0;
             DS_READ128(a0[0], aa, 0); DS_READ128(a0[1], aa, 2048); DS_READ128(a0[2], aa, 4096); DS_READ128(a0[3], aa, 6144);
@@ -593,12 +604,10 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);   // keep the second wait behind the first MFMA group
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]), "+v"(b1[4]));
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+        if (!defer) mma1();
         if (++buf == DMA_STAGES) buf = 0;
     }
+    if (defer) mma1();
     __syncthreads();   // every wavefront is done reading the ring before the epilogue reuses it
     gemm_epilogue(p, acc, smem_raw, lane, wv, wm, wn, m0, n0, tile_n);
 }
@@ -742,6 +751,32 @@ __global__ void __launch_bounds__(512, 2) k_gemm_wide(GemmParams p) {
 #else
 #define TMARK(i)
 #endif
+    // Stagger (MI355X_MICROARCH.md, "Two waves per SIMD", item 9): wavefronts w and w + 4 share a SIMD and run this
+    // same loop behind the same barrier, so unstaggered they issue their LDS-DMA, read their fragments and want the
+    // matrix pipe at the same moments (measured: ~700 of ~3500 cycles per k-tile with the pipe idle).  Wavefronts 4-7
+    // DEFER the second k-half's MFMAs of every stage past the next barrier (its fragments are in registers by then, so
+    // the slot is free as before): after a barrier they multiply while their partners issue DMA and read, and they
+    // issue DMA and read while the partners multiply.  Same arithmetic in the same order: results bit for bit unchanged.
+    half8 af[TM], bf[WTN];
+    const bool defer = wv >= 4;
+    auto read_half = [&](unsigned sb, int kh) {
+        const unsigned aa = sb + a_row + swz[kh], ba = sb + b_row + swz[kh];
+        DS_READ128(af[0], aa, 0); DS_READ128(af[1], aa, 2048); DS_READ128(af[2], aa, 4096); DS_READ128(af[3], aa, 6144);
+        DS_READ128(bf[0], ba, 0); DS_READ128(bf[1], ba, 2048); DS_READ128(bf[2], ba, 4096); DS_READ128(bf[3], ba, 6144);
+        DS_READ128(bf[4], ba, 8192); DS_READ128(bf[5], ba, 10240); DS_READ128(bf[6], ba, 12288); DS_READ128(bf[7], ba, 14336);
+        DS_READ128(bf[8], ba, 16384); DS_READ128(bf[9], ba, 18432);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]),
+                       "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7]), "+v"(bf[8]), "+v"(bf[9]));
+    };
+    auto mma = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+                acc[j / TN][i][j % TN] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[j / TN][i][j % TN], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // the next reads reuse af / bf: keep them behind these MFMAs
+    };
     issue_stage(0);
     int buf = 0;
     for (int kt = 0; kt < nkt; ++kt) {
@@ -749,31 +784,21 @@ __global__ void __launch_bounds__(512, 2) k_gemm_wide(GemmParams p) {
         TMARK(0);
         __builtin_amdgcn_s_barrier();
         TMARK(1);
+        if (defer && kt > 0) mma();                          // second k-half of stage kt-1 (deferred wavefronts)
         if (kt + 1 < nkt) issue_stage(buf ^ 1);              // the slot every wavefront finished reading in iteration kt-1
         TMARK(2);
         const unsigned sb = lds0 + (unsigned)buf * W_STAGE;
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            half8 af[TM], bf[WTN];
-            const unsigned aa = sb + a_row + swz[kh], ba = sb + b_row + swz[kh];
-            DS_READ128(af[0], aa, 0); DS_READ128(af[1], aa, 2048); DS_READ128(af[2], aa, 4096); DS_READ128(af[3], aa, 6144);
-            DS_READ128(bf[0], ba, 0); DS_READ128(bf[1], ba, 2048); DS_READ128(bf[2], ba, 4096); DS_READ128(bf[3], ba, 6144);
-            DS_READ128(bf[4], ba, 8192); DS_READ128(bf[5], ba, 10240); DS_READ128(bf[6], ba, 12288); DS_READ128(bf[7], ba, 14336);
-            DS_READ128(bf[8], ba, 16384); DS_READ128(bf[9], ba, 18432);
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]),
-                           "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7]), "+v"(bf[8]), "+v"(bf[9]));
-            TMARK(3 + 2 * kh);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < WTN; ++j)
-                    acc[j / TN][i][j % TN] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[j / TN][i][j % TN], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);   // the next half's reads reuse af / bf: keep them behind these MFMAs
-            TMARK(4 + 2 * kh);
-        }
+        read_half(sb, 0);
+        TMARK(3);
+        mma();
+        TMARK(4);
+        read_half(sb, 1);
+        TMARK(5);
+        if (!defer) mma();
+        TMARK(6);
         buf ^= 1;
     }
+    if (defer) mma();
 #ifdef SYN3R_TIMING
     if (blockIdx.x == gridDim.x / 2 && lane == 0)
         for (int i = 0; i < 8; ++i) g_wide_timing[wv * 8 + i] = tsum[i];
@@ -1283,9 +1308,13 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
             return launch_wide<MODE>(p, stream);
         }
     }
-    // measured on MI355X (tools/gemm_bench.py): two 128-row blocks per CU win on every UNet shape except the
-    // wide feed-forward expansions at C = 1280, where re-reading the 160-column B tile per 128 rows costs more
-    int bm = g_dma_bm > 0 ? g_dma_bm : ((p.N >= 5120 && p.K >= 1280) ? 256 : 128);
+    // 256-row blocks (eight wavefronts, wavefronts 4-7 staggered by half a k-tile against their SIMD partners) against
+    // two independent 128-row blocks per CU, measured inside the UNet unit on MI355X (tools/unet_breakdown.py with
+    // SYN3R_SET_TILE=-256, round 2): every implicit-GEMM convolution and temporal convolution -1..-10 % (-3.7 % on their
+    // sum), the residual-add projections -5..-6 %; only grids that leave CUs without a 256-row block (dense, M = 4032)
+    // stay with the 128-row blocks.  (Before the stagger the 128-row pairs won everywhere but N >= 5120.)
+    const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+    int bm = g_dma_bm > 0 ? g_dma_bm : ((MODE != MODE_DENSE || tiles256 >= 256) ? 256 : 128);
     return bm == 128 ? launch_dma_bm<MODE, 128>(p, stream) : launch_dma_bm<MODE, 256>(p, stream);
 }
 

@@ -8,6 +8,8 @@ import os
 if os.environ.get("SYN3R_LIB_OVERRIDE"):      # A/B against another build of the library
     L._LIB_PATH = Path(os.environ["SYN3R_LIB_OVERRIDE"]).resolve()
 from syn3r_amd.pipeline.svd_step import SvdStepBench
+if os.environ.get("SYN3R_SET_TILE"):          # force a contraction kernel family (syn3r_gemm_set_tile), tuning runs
+    L.load().syn3r_gemm_set_tile(int(os.environ["SYN3R_SET_TILE"]))
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 14
 b = SvdStepBench(F, torch.device("cuda", 0))
 b.step_pass(); torch.cuda.synchronize()
