@@ -97,8 +97,10 @@ class RasterLoop:
         iterations per second.  Runs on copies of the parameters (the headline loop's inputs stay fixed)."""
         from syn3r_amd.gs.train_ops import FusedAdam, photometric_loss
         ps = {k: v.detach().clone().requires_grad_(True) for k, v in self.p.items()}
-        opt = FusedAdam([{"params": [ps["m"]], "lr": 1.6e-4}, {"params": [ps["sh"]], "lr": 2.5e-3}, {"params": [ps["o"]], "lr": 5e-2},
-                         {"params": [ps["s"]], "lr": 5e-3}, {"params": [ps["q"]], "lr": 1e-3}], eps=1e-15)
+        # FSGS's learning rates x 1e-3: the synthetic target is noise, at full rates the Gaussians swell and the pair count
+        # (the work per iteration) triples within 50 steps - the timing should be of a steady scene
+        opt = FusedAdam([{"params": [ps["m"]], "lr": 1.6e-7}, {"params": [ps["sh"]], "lr": 2.5e-6}, {"params": [ps["o"]], "lr": 5e-5},
+                         {"params": [ps["s"]], "lr": 5e-6}, {"params": [ps["q"]], "lr": 1e-6}], eps=1e-15)
 
         def one():
             color, _, _, _ = self.rast(ps["m"], self.m2, ps["o"], shs=ps["sh"], scales=ps["s"], rotations=ps["q"])

@@ -18,6 +18,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
+from .. import _lib as L
 from ..raster import GaussianRasterizationSettings, GaussianRasterizer
 from .train_ops import FusedAdam, image_metrics, l1_loss, photometric_loss
 
@@ -210,6 +211,7 @@ class GSTrainer:
         self.dust3r = None
         self.checkpoint_iterations: List[int] = list(checkpoint_iterations or [])
         self.iteration = 0
+        self.truncated_renders = 0        # renders whose (Gaussian, tile) pair list outgrew the async capacity (see _loop)
         self.background = torch.tensor(background, dtype=torch.float32, device=gaussians._xyz.device)
         self._rng = np.random.default_rng(self.opt.seed)
         self.reset_optimizers()
@@ -364,8 +366,18 @@ class GSTrainer:
         last = None
         try:
             for _ in range(first_iter, n):
-                last = self.train_step()
-            raster.flush_pair_checks()               # every render's pair list was complete (raises otherwise)
+                try:
+                    last = self.train_step()
+                except L.Syn3rError as e:            # an EARLIER render outgrew its pair capacity (reported late, see raster):
+                    if "async pair-count" not in str(e):
+                        raise
+                    self.truncated_renders += 1      # that one step saw a truncated image; capacity has been raised - go on
+            try:
+                raster.flush_pair_checks()           # every remaining render's pair list was complete
+            except L.Syn3rError as e:
+                if "async pair-count" not in str(e):
+                    raise
+                self.truncated_renders += 1
         finally:
             raster.set_pair_count_mode(prev)
         return float(last) if last is not None else 0.0     # ONE synchronisation, at the end of the loop

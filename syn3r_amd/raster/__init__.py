@@ -57,10 +57,11 @@ def _host16(m: torch.Tensor):
 # ---- pair-count mode ------------------------------------------------------------------------------------
 # "sync"  (default): read the exact number of (Gaussian, tile) pairs back after the projection stage, as the
 #                    published implementation does, and size the binning buffer exactly.
-# "async" (opt-in, training loops): size the binning buffer from the previous call of the same shape (x1.5),
+# "async" (opt-in, training loops): size the binning buffer from the previous calls of the same shape (x2),
 #                    let the kernels read the live count on the device, and check the overflow flag of call k
 #                    at call k+1 (or at `flush_pair_checks()`): a call that overflowed raises then — its image
 #                    was built from a truncated pair list.  Removes the one host<->device round trip per render.
+_HEADROOM = 2.0          # async capacity = 2 x the largest pair count seen for the shape (24 B per pair: ~125 MB at 2.6 M pairs)
 _pair_mode = "sync"
 _capacity: dict = {}
 _pending: dict = {}
@@ -88,7 +89,7 @@ def _check_pending(key, wait: bool):
         evt.synchronize()
         queue.pop(0)
         P, overflow = int(host[0]), int(host[1])
-        _capacity[key] = max(_capacity.get(key, 0), int(P * 1.5) + 4096)
+        _capacity[key] = max(_capacity.get(key, 0), int(P * _HEADROOM) + 4096)
         if overflow or P > cap:
             queue.clear()
             raise L.Syn3rError(f"rasteriser (async pair-count mode): a previous render needed {P} pairs but the binning "
@@ -142,7 +143,7 @@ class _Rasterize(torch.autograd.Function):
             P = _capacity[key]                          # capacity; the kernels read the live count on the device
         else:
             P = int(P.value)
-            _capacity[key] = max(_capacity.get(key, 0), int(P * 1.5) + 4096)
+            _capacity[key] = max(_capacity.get(key, 0), int(P * _HEADROOM) + 4096)
         binning = torch.empty(lib.syn3r_raster_binning_bytes(P), dtype=torch.uint8, device=dev)
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
