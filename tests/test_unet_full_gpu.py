@@ -6,8 +6,9 @@ with the DEFAULT kernel dispatch — the contraction / attention variants bench.
     launch: [2,14,8,72,128] (bench unit), [1,25,8,40,72] / [1,25,8,48,72] (Post guidance tiles), [2,25,8,72,128];
   * oracle/unet_oracle.py (pinned by unet_small.npz) at a small shape, run live.
 
-Tolerance: fp16 storage / fp32 accumulate through ~300 layers against fp32: 3e-2 max, 3e-3 mean of the output scale
-(the same bar as the small-configuration golden test)."""
+Tolerance: fp16 storage / fp32 accumulate through ~300 layers against fp32.  Measured on MI355X (round 2): max 1.2-1.8e-3,
+mean 2.0-3.3e-4 of the output scale over the four shapes; the bar is 1e-2 max / 1.5e-3 mean (5x the measurement, a third
+of the small-configuration test's bar)."""
 import numpy as np
 import pytest
 import torch
@@ -31,7 +32,7 @@ def full_unet(gpu):
 def _compare(y, ref, what):
     scale = float(np.abs(ref).max())
     err = np.abs(y - ref)
-    assert err.max() < 3e-2 * scale and err.mean() < 3e-3 * scale, (what, float(err.max()), float(err.mean()), scale)
+    assert err.max() < 1e-2 * scale and err.mean() < 1.5e-3 * scale, (what, float(err.max()), float(err.mean()), scale)
     return float(err.max()) / scale, float(err.mean()) / scale
 
 

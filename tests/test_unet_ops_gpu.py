@@ -98,9 +98,8 @@ def test_tconv3(B, F, HW, Cin, Cout, gpu):
     close(out, 0.6 * ref + res.float())
 
 
-# S >= 512 runs the 8-wavefront alternating kernel (256-query blocks, 64-key tiles): sizes with a partial last query block
-# (520, 700, 1000), a partial last key tile (520, 700, 1000), one full tile row (512), odd tile counts (576 = 9 tiles), and
-# a long sequence; below 512 the 4-wavefront kernel
+# 128-query blocks, 64-key tiles: sizes with a partial last query block and a partial last key tile (45, 130, 216, 520, 700,
+# 1000), whole tiles only (128, 512, 576, 2304) and the benchmark's sequence length (9216)
 @pytest.mark.parametrize("nseq,S,heads", [(2, 128, 1), (3, 576, 2), (1, 2304, 5), (2, 45, 2), (2, 216, 1), (1, 130, 3),
                                           (2, 512, 1), (1, 520, 2), (2, 700, 1), (1, 1000, 3), (1, 9216, 1)])
 def test_attention_spatial(nseq, S, heads, gpu):
