@@ -34,7 +34,7 @@ def collect(path, counter):
 
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
 out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on "
-               "`python3 bench.py --steps 1 --warmup 0 --raster-iters 5 --no-cpu-baseline --no-kernel-trace`; counters are KB; FETCH_SIZE "
+               "`python3 bench.py --steps 1 --warmup 0 --raster-iters 5 --no-cpu-baseline --no-sub-benchmarks --no-kernel-trace`; counters are KB; FETCH_SIZE "
                "doubled (gfx950 tallies the 128-B requests of 16 B/lane streams at 64 B, MI355X_MICROARCH.md HBM); "
                "WRITE_SIZE as read; per-launch averages over every launch of the kernel family",
        "_source_id": source_id()}      # the kernel sources this pass profiled: bench.py reports the traffic only for that build
