@@ -270,6 +270,7 @@ class UNetSpatioTemporalConditionModel:
     def _pack(self):
         """Kernel-side layouts: OHWI conv weights, fused QKV, (3,1,1) convs as [Cout,3,Cin]."""
         self._pos_cache = {}        # frame-position embeddings: functions of the weights, F and B only
+        self._ctx_store = {}        # folded cross-attention vectors per context (see _context_cache)
         p, pk = self.p, {}
         for k, t in p.t.items():
             if k.endswith(".weight") and t.dim() == 4 and t.shape[-1] == 3:          # Conv2d 3x3
@@ -300,6 +301,17 @@ class UNetSpatioTemporalConditionModel:
                 else:
                     wp, bp, D = ops.pack_geglu(p.t[k], p.t[pre + "bias"])
                     pk[pre + "geglu_w"], pk[pre + "geglu_b"] = wp, bp
+        # every resnet's time_emb_proj (44 Linear(1280 -> Cout) on the SAME [B,1280] vector, resnet.py:352,630) as ONE
+        # contraction per forward: weights / biases stacked once, each block reads its column slice
+        names = [k[: -len(".weight")] for k in p.t if k.endswith("time_emb_proj.weight")]
+        self._temb_slices, off = {}, 0
+        for nme in names:
+            n_out = p.t[nme + ".weight"].shape[0]
+            self._temb_slices[nme] = (off, off + n_out)
+            off += n_out
+        if names:
+            pk["time_emb_proj.all.weight"] = torch.cat([p.t[nme + ".weight"] for nme in names], 0).contiguous()
+            pk["time_emb_proj.all.bias"] = torch.cat([p.t[nme + ".bias"] for nme in names], 0).contiguous()
         self.packed = pk
         # AlphaBlender scales as host floats, computed ONCE (reading a device scalar per block would drain the
         # launch queue 60 times per forward): alpha in fp16 as `alpha.to(x_spatial.dtype)` (resnet.py:797), and
@@ -309,6 +321,19 @@ class UNetSpatioTemporalConditionModel:
             if k.endswith("mix_factor"):
                 a = torch.sigmoid(t.float()).to(H)
                 self.alpha[k] = (float(a), float((1.0 - a).to(H)))
+
+    def _context_cache(self, ehs: torch.Tensor, shared: bool) -> dict:
+        """Per-context store of the folded cross-attention vectors.  Keyed on the storage the caller's tensor views
+        (address, offset, shape, strides, in-place version); the entry holds the tensor, so the address cannot be handed
+        to other data while the entry lives.  A handful of contexts (start / end image, their guidance-tile views)."""
+        key = (ehs.untyped_storage().data_ptr(), ehs.storage_offset(), tuple(ehs.shape), tuple(ehs.stride()), ehs._version, shared)
+        store = self.__dict__.setdefault("_ctx_store", {})
+        ent = store.get(key)
+        if ent is None:
+            if len(store) >= 8:
+                store.pop(next(iter(store)))
+            ent = store[key] = (ehs, {})
+        return ent[1]
 
     def w(self, name: str) -> torch.Tensor:
         return self.packed.get(name, self.p.t.get(name))
@@ -323,7 +348,8 @@ class UNetSpatioTemporalConditionModel:
         s, t = pre + ".spatial_res_block", pre + ".temporal_res_block"
         W = self.w
         # spatial ResnetBlock2D (resnet.py:325-378)
-        tp_s = ops.linear(st["temb_act"], W(s + ".time_emb_proj.weight"), W(s + ".time_emb_proj.bias"))    # [B, cout]
+        a0, a1 = self._temb_slices[s + ".time_emb_proj"]
+        tp_s = st["temb_all"][:, a0:a1]                                   # [B, cout], a column slice of the stacked projection
         hcur = ops.groupnorm(x, W(s + ".norm1.weight"), W(s + ".norm1.bias"), B * F, 1e-5, True)
         hcur = ops.conv3x3(hcur.view(B * F, h, w_, cin), W(s + ".conv1.weight"), W(s + ".conv1.bias"),
                            rowvec=tp_s, rows_per_vec=F * HW).view(-1, cout)
@@ -334,7 +360,8 @@ class UNetSpatioTemporalConditionModel:
         xs = ops.conv3x3(hcur.view(B * F, h, w_, cout), W(s + ".conv2.weight"), W(s + ".conv2.bias"),
                          residual=skip).view(-1, cout)
         # TemporalResnetBlock (resnet.py:613-636) + AlphaBlender (:789-802)
-        tp_t = ops.linear(st["temb_act"], W(t + ".time_emb_proj.weight"), W(t + ".time_emb_proj.bias"))
+        a0, a1 = self._temb_slices[t + ".time_emb_proj"]
+        tp_t = st["temb_all"][:, a0:a1]
         hcur = ops.groupnorm(xs, W(t + ".norm1.weight"), W(t + ".norm1.bias"), B, 1e-5, True)
         hcur = ops.tconv3(hcur, W(t + ".conv1.weight"), W(t + ".conv1.bias"), B, F, HW, rowvec=tp_t, rows_per_vec=F * HW)
         hcur = ops.groupnorm(hcur, W(t + ".norm2.weight"), W(t + ".norm2.bias"), B, 1e-5, True)
@@ -343,10 +370,17 @@ class UNetSpatioTemporalConditionModel:
         return ops.tconv3(hcur, W(t + ".conv2.weight"), W(t + ".conv2.bias"), B, F, HW, residual=xs, s_acc=om,
                           s_res=a + om)
 
-    def _cross_vec(self, pre: str, ehs: torch.Tensor) -> torch.Tensor:
-        """attn2 with a single key: to_out(to_v(ctx)) per batch item -> [B, C]."""
+    def _cross_vec(self, pre: str, ehs: torch.Tensor, cache: Optional[dict] = None) -> torch.Tensor:
+        """attn2 with a single key: to_out(to_v(ctx)) per batch item -> [B, C].  A function of the context alone: the
+        32 vectors of a forward are kept per context (`forward` keys them on the caller's encoder_hidden_states), so the
+        200 UNet calls of a denoising run compute them once instead of reading ~100 MB of to_v / to_out weights each time."""
+        if cache is not None and pre in cache:
+            return cache[pre]
         v = ops.linear(ehs, self.w(pre + ".to_v.weight"))
-        return ops.linear(v, self.w(pre + ".to_out.0.weight"), self.w(pre + ".to_out.0.bias"))
+        out = ops.linear(v, self.w(pre + ".to_out.0.weight"), self.w(pre + ".to_out.0.bias"))
+        if cache is not None:
+            cache[pre] = out
+        return out
 
     def _ff(self, pre: str, x: torch.Tensor, **epilogue) -> torch.Tensor:
         D = self.p.shapes[pre + ".net.0.proj.weight"][0] // 2
@@ -383,7 +417,7 @@ class UNetSpatioTemporalConditionModel:
         n1 = ops.layernorm(hs, W(b + ".norm1.weight"), W(b + ".norm1.bias"))
         a1 = ops.attention(ops.linear(n1, W(b + ".attn1.qkv")), B * F, HW, heads)
         hs = ops.linear(a1, W(b + ".attn1.to_out.0.weight"), W(b + ".attn1.to_out.0.bias"), residual=hs,
-                        rowvec=self._cross_vec(b + ".attn2", ehs), rows_per_vec=(B if st["shared_ctx"] else 1) * F * HW)
+                        rowvec=self._cross_vec(b + ".attn2", ehs, st["ctx_cache"]), rows_per_vec=(B if st["shared_ctx"] else 1) * F * HW)
         n3 = ops.layernorm(hs, W(b + ".norm3.weight"), W(b + ".norm3.bias"))
         hs = self._ff(b + ".ff", n3, residual=hs)
         # TemporalBasicTransformerBlock (attention.py:478-533) on hs + emb
@@ -401,7 +435,7 @@ class UNetSpatioTemporalConditionModel:
             raise NotImplementedError("temporal cross-attention context interleave needs h*w divisible by the batch "
                                       "size (or one context shared by the batch: pass it expanded, stride 0)")
         tt = ops.linear(a1, W(t + ".attn1.to_out.0.weight"), W(t + ".attn1.to_out.0.bias"), residual=tt,
-                        rowvec=self._cross_vec(t + ".attn2", ehs), rows_per_vec=B * F * HW if st["shared_ctx"] else -B)
+                        rowvec=self._cross_vec(t + ".attn2", ehs, st["ctx_cache"]), rows_per_vec=B * F * HW if st["shared_ctx"] else -B)
         n3 = ops.layernorm(tt, W(t + ".norm3.weight"), W(t + ".norm3.bias"))
         a, om = self._blend_scales(pre + ".time_mixer.mix_factor")
         # alpha*hs + (1-alpha)*(ff + tt)
@@ -439,7 +473,8 @@ class UNetSpatioTemporalConditionModel:
         shared_ctx = B == 1 or encoder_hidden_states.stride(0) == 0
         ctx = encoder_hidden_states[:1] if shared_ctx else encoder_hidden_states
         st = dict(B=B, F=F, h=h, w=w_, temb_act=Fn.silu(emb).contiguous(), shared_ctx=shared_ctx,
-                  ehs=ctx.reshape(ctx.shape[0], -1).to(H).contiguous())
+                  ehs=ctx.reshape(ctx.shape[0], -1).to(H).contiguous(), ctx_cache=self._context_cache(encoder_hidden_states, shared_ctx))
+        st["temb_all"] = ops.linear(st["temb_act"], W("time_emb_proj.all.weight"), W("time_emb_proj.all.bias"))
         # 2. conv_in on NHWC with channels padded to 64 (:428)
         x = sample.to(H).flatten(0, 1).permute(0, 2, 3, 1)
         x = Fn.pad(x, (0, 64 - Cin % 64 if Cin % 64 else 0)).contiguous()

@@ -31,6 +31,15 @@ def _chk(*ts):
     return dev
 
 
+def _rowvec(rv: Optional[torch.Tensor]):
+    """(pointer, row stride) of a per-sample row-vector operand: a [V, N] fp16 matrix or a column slice of a wider one."""
+    if rv is None:
+        return None, 0
+    if rv.dtype != H or rv.dim() != 2 or rv.stride(1) != 1 or not rv.is_cuda:
+        raise L.Syn3rError("rowvec must be a 2-D fp16 HIP tensor with unit column stride")
+    return rv.data_ptr(), rv.stride(0)
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
            rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0, residual: Optional[torch.Tensor] = None,
            aux: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0, s_aux: float = 1.0,
@@ -42,12 +51,13 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     N = weight.shape[0]
     if weight.shape[1] != K or x.stride(1) != 1:
         raise ValueError(f"linear: x {tuple(x.shape)} / weight {tuple(weight.shape)} mismatch")
-    _chk(weight, bias, rowvec, residual, aux)
+    _chk(weight, bias, residual, aux)
+    rv_ptr, rv_ld = _rowvec(rowvec)
     if out is None:
         out = torch.empty((M, N), dtype=H, device=dev)
     lib = L.load()
     rc = lib.syn3r_gemm_f16(x.data_ptr(), x.stride(0), L.ptr(weight), out.data_ptr(), out.stride(0), L.ptr(bias),
-                            L.ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0, int(rows_per_vec),
+                            rv_ptr, rv_ld, int(rows_per_vec),
                             residual.data_ptr() if residual is not None else None,
                             residual.stride(0) if residual is not None else 0,
                             aux.data_ptr() if aux is not None else None, aux.stride(0) if aux is not None else 0,
@@ -158,7 +168,8 @@ def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
             pad_lo: int = 1) -> torch.Tensor:
     """x [NB,Hi,Wi,Cin] NHWC, weight [Cout,3,3,Cin] -> [NB,Ho,Wo,Cout].  pad_lo = 0: the (0,1,0,1) padding of the
     VAE encoder's stride-2 Downsample2D(padding=0)."""
-    dev = _chk(x, weight, bias, rowvec, residual)
+    dev = _chk(x, weight, bias, residual)
+    rv_ptr, rv_ld = _rowvec(rowvec)
     NB, Hi, Wi, Cin = x.shape
     Cout = weight.shape[0]
     if tuple(weight.shape[1:]) != (3, 3, Cin):
@@ -167,8 +178,7 @@ def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
     Ho, Wo = (Hg + pad_lo - 2) // stride + 1, (Wg + pad_lo - 2) // stride + 1
     out = torch.empty((NB, Ho, Wo, Cout), dtype=H, device=dev)
     lib = L.load()
-    rc = lib.syn3r_conv2d3x3_f16(L.ptr(x), L.ptr(weight), L.ptr(out), Cout, L.ptr(bias), L.ptr(rowvec),
-                                 rowvec.stride(0) if rowvec is not None else 0, int(rows_per_vec),
+    rc = lib.syn3r_conv2d3x3_f16(L.ptr(x), L.ptr(weight), L.ptr(out), Cout, L.ptr(bias), rv_ptr, rv_ld, int(rows_per_vec),
                                  L.ptr(residual), Cout if residual is not None else 0, float(s_acc), float(s_res),
                                  NB, Hi, Wi, Cin, Cout, int(stride), 1 if upsample else 0, int(pad_lo),
                                  L.stream_ptr(dev))
@@ -181,15 +191,15 @@ def tconv3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
            rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0, residual: Optional[torch.Tensor] = None,
            s_acc: float = 1.0, s_res: float = 1.0) -> torch.Tensor:
     """x [B*F*HW, Cin], weight [Cout,3,Cin] -> [B*F*HW, Cout] (3-tap convolution over frames)."""
-    dev = _chk(x, weight, bias, rowvec, residual)
+    dev = _chk(x, weight, bias, residual)
+    rv_ptr, rv_ld = _rowvec(rowvec)
     M, Cin = x.shape
     Cout = weight.shape[0]
     if M != B * F * HW or tuple(weight.shape[1:]) != (3, Cin):
         raise ValueError("tconv3: shape mismatch")
     out = torch.empty((M, Cout), dtype=H, device=dev)
     lib = L.load()
-    rc = lib.syn3r_tconv3_f16(L.ptr(x), L.ptr(weight), L.ptr(out), Cout, L.ptr(bias), L.ptr(rowvec),
-                              rowvec.stride(0) if rowvec is not None else 0, int(rows_per_vec), L.ptr(residual),
+    rc = lib.syn3r_tconv3_f16(L.ptr(x), L.ptr(weight), L.ptr(out), Cout, L.ptr(bias), rv_ptr, rv_ld, int(rows_per_vec), L.ptr(residual),
                               Cout if residual is not None else 0, float(s_acc), float(s_res), B, F, HW, Cin, Cout,
                               L.stream_ptr(dev))
     L.check(rc, "syn3r_tconv3_f16")
