@@ -254,6 +254,33 @@ def test_every_contraction_kernel_agrees(gpu, every_contraction_kernel):
     every_contraction_kernel(body)
 
 
+@pytest.mark.parametrize("M,N,K", [(5120, 4800, 128), (5000, 4808, 192), (8192, 1920, 256), (66000, 320, 64)])
+def test_gemm_persistent_wide_tile(M, N, K, gpu):
+    """k_gemm_widep (persistent 256 x 320 tile) with MORE tiles than CUs, so blocks walk several tiles: even k-tile counts
+    (next tile's stage 0 prefetched during the last k-tile, epilogue staged behind ring slot 0) and odd ones, ragged
+    M / N (multiples of 8), a narrow last column band, bias / scale / residual / aux epilogues and the GEGLU gate."""
+    from syn3r_amd.unet import ops
+    from syn3r_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = rnd(g, M, K, dev=gpu), rnd(g, N, K, scale=K ** -0.5, dev=gpu), rnd(g, N, dev=gpu)
+    res, aux = rnd(g, M, N, dev=gpu), rnd(g, M, N, dev=gpu)
+    y = x.float() @ w.float().T
+    try:
+        _lib.check(lib.syn3r_gemm_set_tile(-320), "set_tile")
+        close(ops.linear(x, w), y)
+        close(ops.linear(x, w, b, s_acc=0.5), 0.5 * (y + b.float()))
+        close(ops.linear(x, w, b, residual=res), y + b.float() + res.float())
+        close(ops.linear(x, w, b, residual=res, aux=aux, s_acc=0.3, s_res=1.0, s_aux=0.7), 0.3 * (y + b.float()) + res.float() + 0.7 * aux.float())
+        if N % 16 == 0:
+            D = N // 2
+            wp, bp, _ = ops.pack_geglu(w, b)
+            yh = (y + b.float()).half().float()
+            close(ops.linear_geglu(x, wp, bp, D), yh[:, :D] * Fn.gelu(yh[:, D:]), tol=4e-3)
+    finally:
+        lib.syn3r_gemm_set_tile(0)
+
+
 @pytest.mark.parametrize("M,C,D", [(700, 320, 1280), (129, 64, 128), (1000, 640, 2560), (4032, 1280, 5120), (77, 128, 192)])
 def test_feedforward_tiled_intermediate(M, C, D, gpu):
     """`feedforward` (gated hidden activation in the tiled workspace) equals the two separate launches with the

@@ -33,5 +33,35 @@ def run(M, N, K):
         print(f"  wave {wv}: " + "  ".join(f"{n}={x:7.1f}" for n, x in zip(NAMES, v)) + f"  total={sum(v):8.1f}")
 
 
-for shape in [(16128, 1280, 5120), (64512, 5120, 640), (258048, 2560, 320)]:
-    run(*shape)
+def run_persistent(M, N, K, geglu):
+    """k_gemm_widep: ticks per tile of (top: setup + first wait), (k-loop), (epilogue), and the in-kernel clock."""
+    _lib.load().syn3r_gemm_set_tile(0)
+    x = torch.randn(M, K, device=dev).to(H)
+    w = (torch.randn(N, K, device=dev) * 0.02).to(H)
+    b = torch.zeros(N, device=dev, dtype=H)
+    if geglu:
+        wp, bp, _D = ops.pack_geglu(w, b)
+        f = lambda: ops.linear_geglu(x, wp, bp, N // 2)
+    else:
+        f = lambda: ops.linear(x, w)
+    for _ in range(200):
+        f()
+    torch.cuda.synchronize()
+    out = (ctypes.c_ulonglong * 64)()
+    lib.syn3r_debug_wide_timing(out)
+    print(f"persistent M{M} N{N} K{K} geglu={geglu}")
+    for wv in (0, 4):
+        top, loop, epi, nt, mt, rt, k0, k1 = [out[wv * 8 + i] for i in range(8)]
+        nt = max(nt, 1)
+        nkt = K // 64
+        print(f"           k-tile 0: {k0 / nt:7.0f}  k-tile 1: {k1 / nt:7.0f}  k-tiles 2..: {(loop - k0 - k1) / nt / max(nkt - 2, 1):7.0f} each")
+        print(f"  wave {wv}: tiles {nt}  per tile: top {top / nt:8.0f}  k-loop {loop / nt:8.0f}  epilogue {epi / nt:8.0f} ticks;"
+              f"  clock {mt / max(rt, 1) * 100:.0f} MHz ({mt} memtime / {rt} realtime ticks)")
+
+
+if "--persistent" in sys.argv:
+    for M, N, K, g in [(64512, 5120, 640, True), (64512, 1920, 640, False), (16128, 10240, 1280, True), (16128, 1280, 5120, False)]:
+        run_persistent(M, N, K, g)
+else:
+    for shape in [(16128, 1280, 5120), (64512, 5120, 640), (258048, 2560, 320)]:
+        run(*shape)
