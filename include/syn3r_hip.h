@@ -437,6 +437,15 @@ int syn3r_photo_loss_backward(const float* image, const float* target, int C, in
 int syn3r_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                     float beta1, float beta2, float eps, int step, void* stream);
 
+/* out[i] = mean of the three smallest squared Euclidean distances from point i to the OTHER points of the cloud
+ * (points [n,3] fp32, n >= 4): the quantity FSGS' GaussianModel.create_from_pcd takes from `distCUDA2` of the
+ * simple-knn CUDA extension to initialise the Gaussian scales (reached from reset_gaussians_from_pcd,
+ * model/diffusionGS.py:1685-1687; the extension is an un-vendored submodule).  Exact search (Morton
+ * order + bounding-box pruning), d2 = (dx*dx + dy*dy) + dz*dz without fused multiply-add, sum (b0 + b1) + b2 ascending.
+ * ws: syn3r_knn3_workspace_bytes(n) bytes of 256-byte aligned device scratch. */
+size_t syn3r_knn3_workspace_bytes(int n);
+int syn3r_knn3_mean_dist2(const float* points, int n, float* out, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,7 @@ COMMON_FLAGS = [
     "-fno-gpu-rdc",
 ]
 # files whose arithmetic mirrors torch/numpy elementwise op order: no fma contraction
-STRICT_FP = {"warp.hip", "sched.hip", "train.hip"}
+STRICT_FP = {"warp.hip", "sched.hip", "train.hip", "knn.hip"}
 
 
 def _hipcc() -> str:

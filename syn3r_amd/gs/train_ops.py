@@ -105,6 +105,22 @@ def image_metrics(image: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     return torch.stack([psnr, parts[2]])
 
 
+def knn3_mean_dist2(points: torch.Tensor) -> torch.Tensor:
+    """Mean squared distance of every point of a [n,3] fp32 cloud (n >= 4) to its three nearest neighbours:
+    `distCUDA2` of the simple-knn extension, which FSGS' create_from_pcd turns into the initial Gaussian scales
+    (model/diffusionGS.py:1685-1687 -> reset_gaussians_from_pcd).  Exact search on the device (csrc/knn.hip)."""
+    L.require_gpu(points)
+    if points.dim() != 2 or points.shape[1] != 3 or points.dtype != torch.float32:
+        raise ValueError("knn3_mean_dist2: points must be a float32 [n,3] tensor")
+    pts = points.detach().contiguous()
+    n = pts.shape[0]
+    lib = L.load()
+    out = torch.empty(n, dtype=torch.float32, device=pts.device)
+    ws = L.workspace(pts.device, lib.syn3r_knn3_workspace_bytes(n), "knn3")
+    L.check(lib.syn3r_knn3_mean_dist2(L.ptr(pts), n, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr(pts.device)), "knn3_mean_dist2")
+    return out
+
+
 class FusedAdam:
     """`torch.optim.Adam(param_groups, eps=...)` (no weight decay / amsgrad) with one kernel per parameter tensor.
     Keeps torch's `param_groups` / `state` layout so checkpoints and lr schedules written for the torch optimiser

@@ -20,7 +20,7 @@ import torch
 
 from .. import _lib as L
 from ..raster import GaussianRasterizationSettings, GaussianRasterizer
-from .train_ops import FusedAdam, image_metrics, l1_loss, photometric_loss
+from .train_ops import FusedAdam, image_metrics, knn3_mean_dist2, l1_loss, photometric_loss
 
 SH_C0 = 0.28209479177387814
 
@@ -132,18 +132,18 @@ class GaussianModel:
     def set_from_pcd(self, points: np.ndarray, colors: np.ndarray, append: bool):
         """Published 3DGS `create_from_pcd`: DC colour = (rgb - 0.5) / C0, higher SH zero, isotropic scale =
         sqrt(mean squared distance to the 3 nearest neighbours), identity rotation, opacity 0.1.  The reference does this
-        inside FSGS (`simple-knn` CUDA extension, absent); the k-NN here is a chunked `torch.cdist` on the device."""
+        inside FSGS (`simple-knn` CUDA extension, absent); the exact 3-NN search is `csrc/knn.hip` (`train_ops.knn3_mean_dist2`)."""
         dev = self._xyz.device
         pts = torch.as_tensor(np.asarray(points), dtype=torch.float32, device=dev)
         rgb = torch.as_tensor(np.asarray(colors), dtype=torch.float32, device=dev)
         if pts.dim() != 2 or pts.shape[1] != 3 or rgb.shape != pts.shape:
             raise ValueError("reset_gaussians_from_pcd: points and colours must both be [n,3]")
         n = pts.shape[0]
-        d2 = torch.empty(n, device=dev)
-        for s0 in range(0, n, 4096):
-            d = torch.cdist(pts[s0:s0 + 4096], pts) ** 2
-            k = min(4, n)
-            d2[s0:s0 + 4096] = d.topk(k, dim=1, largest=False).values[:, 1:].mean(1) if k > 1 else 1e-4
+        if n >= 4:
+            d2 = knn3_mean_dist2(pts)                 # HIP: exact 3-NN (csrc/knn.hip), the simple-knn quantity
+        else:                                         # degenerate clouds (fewer than 3 neighbours): mean over what there is
+            d = torch.cdist(pts, pts) ** 2
+            d2 = d.topk(n, dim=1, largest=False).values[:, 1:].mean(1) if n > 1 else torch.full((n,), 1e-4, device=dev)
         scales = torch.log(torch.sqrt(d2.clamp_min(1e-7)))[:, None].repeat(1, 3)
         M = self._features.shape[1]
         feats = torch.zeros(n, M, 3, device=dev)

@@ -97,3 +97,14 @@ def test_oracle_resize_semantics():
     assert np.allclose(up[0, 1:-1], (np.arange(16)[1:-1] + 0.5) * 0.5 - 0.5)
     assert np.array_equal(OO.resize_nearest(ramp, 4, 16)[0], np.arange(16) // 2)
     assert np.array_equal(OO.resize_nearest(ramp, 2, 4)[0], np.array([0, 2, 4, 6], dtype=np.float32))
+
+
+def test_knn_oracle_bruteforce_agrees_with_kdtree():
+    """oracle/knn_oracle.py: the fp32 brute-force restatement (what the HIP kernel must match bit for bit) against
+    scipy's k-d tree in float64 (independent algorithm), including duplicate points."""
+    from oracle import knn_oracle as KO
+    g = np.random.default_rng(0)
+    p = g.random((1500, 3), dtype=np.float32)
+    p[:50] = p[50:100]
+    a, b = KO.mean_dist2_bruteforce(p), KO.mean_dist2_kdtree(p)
+    assert np.allclose(a, b, rtol=2e-5, atol=1e-9)
