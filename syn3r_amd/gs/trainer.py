@@ -89,6 +89,17 @@ class Camera:
         return K, self.world_view_transform.transpose(0, 1).cpu()
 
 
+def build_rotation(q: torch.Tensor) -> torch.Tensor:
+    """Rotation matrices [n,3,3] of (w, x, y, z) quaternions, normalised first (published 3DGS general_utils)."""
+    q = q / torch.norm(q, dim=1, keepdim=True)
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.empty((q.shape[0], 3, 3), dtype=q.dtype, device=q.device)
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - r * z); R[:, 0, 2] = 2 * (x * z + r * y)
+    R[:, 1, 0] = 2 * (x * y + r * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - r * x)
+    R[:, 2, 0] = 2 * (x * z - r * y); R[:, 2, 1] = 2 * (y * z + r * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
 class GaussianModel:
     """Trainable Gaussian parameters with the published activations (exp scale, sigmoid opacity, unit quaternion)."""
 
@@ -113,6 +124,24 @@ class GaussianModel:
     def get_opacity(self): return torch.sigmoid(self._opacity)
     @property
     def get_features(self): return self._features
+
+    # ---- densification statistics (published 3DGS GaussianModel: xyz_gradient_accum / denom / max_radii2D)
+    def ensure_stats(self):
+        n, dev = self._xyz.shape[0], self._xyz.device
+        if getattr(self, "xyz_gradient_accum", None) is None or self.xyz_gradient_accum.shape[0] != n:
+            self.xyz_gradient_accum = torch.zeros(n, 1, device=dev)
+            self.denom = torch.zeros(n, 1, device=dev)
+            self.max_radii2D = torch.zeros(n, device=dev)
+
+    @torch.no_grad()
+    def add_densification_stats(self, viewspace_grad: torch.Tensor, update_filter: torch.Tensor, radii: Optional[torch.Tensor] = None):
+        """Accumulate the norm of the screen-space positional gradient of the visible Gaussians (3DGS section 5.2: the
+        quantity the clone / split decision thresholds) and their largest screen radius."""
+        self.ensure_stats()
+        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_grad[update_filter, :2], dim=-1, keepdim=True)
+        self.denom[update_filter] += 1
+        if radii is not None:
+            self.max_radii2D[update_filter] = torch.max(self.max_radii2D[update_filter], radii[update_filter].to(self.max_radii2D.dtype))
 
     def capture(self) -> dict:
         """Parameter tensors of a checkpoint (published 3DGS `GaussianModel.capture`, reduced to what this model holds)."""
@@ -183,6 +212,16 @@ class OptimizationParams:
     seed: int = 0
     use_lpips_loss: bool = False       # toggled by DiffusionGS.run (diffusionGS.py:1690,1697); see GSTrainer.train_step
     lpips_weight: float = 0.0
+    # adaptive density control, published 3DGS defaults (Kerbl et al. 2023 section 5.2 and its released arguments); used when
+    # training()/finetune() run with disable_densification=False
+    percent_dense: float = 0.01
+    densify_from_iter: int = 500
+    densify_until_iter: int = 15_000
+    densification_interval: int = 100
+    opacity_reset_interval: int = 3000
+    densify_grad_threshold: float = 0.0002
+    prune_min_opacity: float = 0.005
+    prune_screen_size: float = 20.0
 
 
 class _Scene:
@@ -211,6 +250,7 @@ class GSTrainer:
         self.dust3r = None
         self.checkpoint_iterations: List[int] = list(checkpoint_iterations or [])
         self.iteration = 0
+        self.densify = False              # adaptive density control inside train_step (training / finetune set it)
         self.truncated_renders = 0        # renders whose (Gaussian, tile) pair list outgrew the async capacity (see _loop)
         self.background = torch.tensor(background, dtype=torch.float32, device=gaussians._xyz.device)
         self._rng = np.random.default_rng(self.opt.seed)
@@ -313,6 +353,128 @@ class GSTrainer:
         p, s_ = torch.stack(ps).mean(), torch.stack(ss).mean()
         return {"psnr": float(p), "ssim": float(s_), "lpips": float("nan"), "n": len(cams)}
 
+    # ------------------------------------------------------------------ adaptive density control
+    # FSGS' training loop (un-vendored) densifies with the published 3DGS clone / split / prune rules plus its own
+    # proximity-guided unpooling; the published rules are restated here (Kerbl et al. 2023 section 5.2, UNPINNED: checked
+    # against oracle/densify_oracle.py), the FSGS-specific unpooling is not (no source, no description of its constants
+    # in /root/reference).  Everything runs on the device; the optimiser moments follow the Gaussians.
+    _PARAM_ATTRS = ("_xyz", "_features", "_opacity", "_scaling", "_rotation")     # = order of the optimiser groups
+
+    def cameras_extent(self) -> float:
+        """Radius of the training cameras around their centroid x 1.1 (published `getNerfppNorm`)."""
+        cams = self.scene.getTrainCameras()
+        if not cams:
+            return 1.0
+        c = torch.stack([cam.camera_center.detach().float().cpu() for cam in cams])
+        return float((c - c.mean(0, keepdim=True)).norm(dim=1).max() * 1.1) or 1.0
+
+    def _swap_param(self, attr: str, tensor: torch.Tensor, moments=None):
+        """Replace parameter `attr` by `tensor` in the model and in its optimiser group; `moments` maps the old
+        (exp_avg, exp_avg_sq) to the new ones (None: start from zero, as a fresh parameter)."""
+        g = self.gaussians
+        old = getattr(g, attr)
+        new = torch.nn.Parameter(tensor.contiguous())
+        grp = self.optimizer.param_groups[self._PARAM_ATTRS.index(attr)]
+        st = self.optimizer.state.pop(old, None)
+        if st is not None and moments is not None:
+            st["exp_avg"], st["exp_avg_sq"] = moments(st["exp_avg"]).contiguous(), moments(st["exp_avg_sq"]).contiguous()
+            self.optimizer.state[new] = st
+        grp["params"] = [new]
+        setattr(g, attr, new)
+
+    @torch.no_grad()
+    def _append_gaussians(self, ext: dict, confidence: torch.Tensor):
+        g = self.gaussians
+        for attr in self._PARAM_ATTRS:
+            e = ext[attr]
+            self._swap_param(attr, torch.cat([getattr(g, attr).detach(), e]),
+                             moments=lambda m, e=e: torch.cat([m, torch.zeros_like(e)]))
+        g.confidence = torch.cat([g.confidence, confidence])
+        g.xyz_gradient_accum = None           # statistics restart after every change of the set (published postfix)
+        g.ensure_stats()
+
+    @torch.no_grad()
+    def _keep_gaussians(self, keep: torch.Tensor):
+        g = self.gaussians
+        g.ensure_stats()
+        for attr in self._PARAM_ATTRS:
+            self._swap_param(attr, getattr(g, attr).detach()[keep], moments=lambda m: m[keep])
+        g.confidence = g.confidence[keep]
+        g.xyz_gradient_accum, g.denom, g.max_radii2D = g.xyz_gradient_accum[keep], g.denom[keep], g.max_radii2D[keep]
+
+    def _split_noise(self, n: int) -> torch.Tensor:
+        """Standard-normal draws [n,3] for the split positions (seeded per trainer: runs are reproducible)."""
+        dev = self.gaussians._xyz.device
+        if getattr(self, "_noise_gen", None) is None:
+            self._noise_gen = torch.Generator(device=dev)
+            self._noise_gen.manual_seed(int(self.opt.seed) + 12345)
+        return torch.randn((n, 3), generator=self._noise_gen, device=dev)
+
+    @torch.no_grad()
+    def densify_and_prune(self, max_grad: float, min_opacity: float, extent: float, max_screen_size: Optional[float]):
+        """Published 3DGS `densify_and_prune`: clone small Gaussians with a large view-space gradient, split large ones
+        into two (positions sampled from the Gaussian, scales / 1.6), then prune transparent, screen-filling and
+        world-huge ones.  Returns (cloned, split, pruned)."""
+        g, o = self.gaussians, self.opt
+        g.ensure_stats()
+        grads = g.xyz_gradient_accum / g.denom
+        grads[grads.isnan()] = 0.0
+        max_radii = g.max_radii2D.clone()
+        # ---- clone
+        sel = (torch.norm(grads, dim=-1) >= max_grad) & (g.get_scaling.max(dim=1).values <= o.percent_dense * extent)
+        n_clone = int(sel.sum())
+        self._append_gaussians({a: getattr(g, a).detach()[sel] for a in self._PARAM_ATTRS}, g.confidence[sel])
+        max_radii = torch.cat([max_radii, torch.zeros(n_clone, device=max_radii.device)])
+        # ---- split (the clones carry a zero gradient)
+        n_now = g._xyz.shape[0]
+        padded = torch.zeros(n_now, device=g._xyz.device)
+        padded[:grads.shape[0]] = grads.squeeze(-1)
+        sel = (padded >= max_grad) & (g.get_scaling.max(dim=1).values > o.percent_dense * extent)
+        n_split = int(sel.sum())
+        N = 2
+        stds = g.get_scaling[sel].repeat(N, 1)
+        samples = self._split_noise(N * n_split) * stds
+        rots = build_rotation(g._rotation.detach()[sel]).repeat(N, 1, 1)
+        ext = {"_xyz": torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + g._xyz.detach()[sel].repeat(N, 1),
+               "_scaling": torch.log(g.get_scaling[sel].repeat(N, 1) / (0.8 * N)),
+               "_rotation": g._rotation.detach()[sel].repeat(N, 1),
+               "_features": g._features.detach()[sel].repeat(N, 1, 1),
+               "_opacity": g._opacity.detach()[sel].repeat(N)}
+        self._append_gaussians(ext, g.confidence[sel].repeat(N))
+        max_radii = torch.cat([max_radii, torch.zeros(N * n_split, device=max_radii.device)])
+        keep = ~torch.cat([sel, torch.zeros(N * n_split, dtype=torch.bool, device=sel.device)])
+        self._keep_gaussians(keep)
+        max_radii = max_radii[keep]
+        # ---- prune
+        prune = g.get_opacity < min_opacity
+        if max_screen_size:
+            prune = prune | (max_radii > max_screen_size) | (g.get_scaling.max(dim=1).values > 0.1 * extent)
+        n_prune = int(prune.sum())
+        self._keep_gaussians(~prune)
+        g.xyz_gradient_accum = None
+        g.ensure_stats()
+        return n_clone, n_split, n_prune
+
+    @torch.no_grad()
+    def reset_opacity(self):
+        """Published `reset_opacity`: opacity <- min(opacity, 0.01), Adam moments of the opacity restart."""
+        g = self.gaussians
+        o = torch.min(g.get_opacity, torch.full_like(g.get_opacity, 0.01))
+        self._swap_param("_opacity", torch.log(o / (1 - o)), moments=lambda m: torch.zeros_like(m))
+
+    def _density_control(self, out: dict):
+        """The per-iteration hook of the published training loop (after backward, before the optimiser step)."""
+        g, o, it = self.gaussians, self.opt, self.iteration + 1
+        if it >= o.densify_until_iter:
+            return
+        vis = out["visibility_filter"]
+        g.add_densification_stats(out["viewspace_points"].grad, vis, out["radii"])
+        if it > o.densify_from_iter and it % o.densification_interval == 0:
+            size = o.prune_screen_size if it > o.opacity_reset_interval else None
+            self.densify_and_prune(o.densify_grad_threshold, o.prune_min_opacity, self.cameras_extent(), size)
+        if it % o.opacity_reset_interval == 0:
+            self.reset_opacity()
+
     def render_view(self, cam: Camera, scaling_modifier: float = 1.0):
         """-> {'render' [3,H,W], 'depth' [1,H,W], 'alpha' [1,H,W], ...} (diffusionGS.py:154-172)."""
         g = self.gaussians
@@ -348,7 +510,13 @@ class GSTrainer:
             loss = l1_loss(out["render"], cam.original_image, weight=float(cam.cam_confidence))
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        self.optimizer.step()
+        changed = False
+        if self.densify:
+            n0 = self.gaussians._xyz.shape[0]
+            self._density_control(out)
+            changed = self.gaussians._xyz.shape[0] != n0
+        if not changed:                       # (the gradients of this step belong to the old set of Gaussians)
+            self.optimizer.step()
         self.iteration += 1
         return loss.detach()
 
@@ -363,6 +531,7 @@ class GSTrainer:
                 for cam in self.scene.train_cameras[1.0]:
                     self.render_view(cam)
         raster.set_pair_count_mode("async")          # no host round trip per render inside the loop
+        self.iteration = first_iter                  # the density-control schedule counts from the start of this loop
         last = None
         try:
             for _ in range(first_iter, n):
@@ -382,11 +551,15 @@ class GSTrainer:
             raster.set_pair_count_mode(prev)
         return float(last) if last is not None else 0.0     # ONE synchronisation, at the end of the loop
 
-    def training(self, first_iter: int = 0, epoch_indicator: int = 0, iterations: Optional[int] = None):
-        """HOT LOOP A (diffusionGS.py:139): `opt.iterations` optimisation steps, then the checkpoints the
-        orchestrator's refine_GS looks for (`chkpnt{N}.pth` for the configured checkpoint iterations, else
-        `chkpnt_latest.pth`, diffusionGS.py:1620-1624) when `scene.model_path` is set."""
+    def training(self, first_iter: int = 0, epoch_indicator: int = 0, iterations: Optional[int] = None,
+                 disable_densification: bool = False):
+        """HOT LOOP A (diffusionGS.py:139): `opt.iterations` optimisation steps with the published adaptive density
+        control (clone / split / prune every `densification_interval` iterations from `densify_from_iter` on, opacity
+        reset every `opacity_reset_interval`), then the checkpoints the orchestrator's refine_GS looks for
+        (`chkpnt{N}.pth` for the configured checkpoint iterations, else `chkpnt_latest.pth`, diffusionGS.py:1620-1624)
+        when `scene.model_path` is set."""
         n = iterations if iterations is not None else self.opt.iterations
+        self.densify = not disable_densification
         last = self._loop(first_iter, n)
         if self.scene.model_path:
             if n in self.checkpoint_iterations:
@@ -394,13 +567,15 @@ class GSTrainer:
             self.save_checkpoint(n, latest=True)
         return last
 
-    def finetune(self, first_iter: int = 0, refine_epoch: int = 0, disable_densification: bool = True,
+    def finetune(self, first_iter: int = 0, refine_epoch: int = 0, disable_densification: bool = False,
                  pseudo_cam_sampling_rate: Optional[float] = None, iterations: Optional[int] = None):
-        """diffusionGS.py:1640 — same loop, now also sampling the confidence-weighted pseudo-views; writes
+        """diffusionGS.py:1640 — same loop (density control unless `disable_densification`, the flag refine_GS forwards,
+        :1610), now also sampling the confidence-weighted pseudo-views; writes
         `refine_{epoch}_chkpnt{N}.pth` (the file the next cycle's refine_GS reloads, :1611-1618)."""
         if pseudo_cam_sampling_rate is not None:
             self.opt.pseudo_cam_sampling_rate = pseudo_cam_sampling_rate
         n = iterations if iterations is not None else self.opt.iterations
+        self.densify = not disable_densification
         last = self._loop(first_iter, n)
         if self.scene.model_path:
             self.save_checkpoint(n, refine_epoch=refine_epoch)

@@ -120,3 +120,35 @@ def test_checkpoints_pcd_reset_metrics_and_neighbours(gpu, tmp_path):
     tr.train_step(cams[0])                                   # the optimiser was rebuilt for the new tensors
     nn = tr.find_nearest_cam([cams[0]], cams, multi_view_max_angle=30, multi_view_min_dis=0.01, multi_view_max_dis=1.5)
     assert nn == [[1]] and cams[0].nearest_id == [1]
+
+
+def test_training_with_density_control_changes_the_set_and_keeps_fitting(gpu):
+    """training() with the adaptive density control on a compressed schedule: the Gaussian count changes (clone / split /
+    prune on the device, optimiser moments carried over), the rasteriser re-sizes its pair buffer for every new count
+    (first render of a new N is exact, then asynchronous again), and the loss still goes down."""
+    from syn3r_amd.gs import Camera, GSTrainer, OptimizationParams
+    N, H, W = 1500, 64, 96
+    gt, K = make_scene(N, H, W, 11, gpu)
+    cam0 = Camera.from_w2c(np.eye(4, dtype=np.float32), K, H, W, data_device=gpu)
+    target = GSTrainer(gt, [cam0]).render_view(cam0)["render"].detach()
+    gm, _ = make_scene(N, H, W, 12, gpu)
+    cam = Camera.from_w2c(np.eye(4, dtype=np.float32), K, H, W, image=target, data_device=gpu)
+    opt = OptimizationParams(iterations=120, position_lr=2e-3, densify_from_iter=10, densification_interval=20,
+                             opacity_reset_interval=1000, densify_grad_threshold=3e-4, prune_min_opacity=0.02)
+    tr = GSTrainer(gm, [cam], opt)
+    first = float(tr.train_step(cam))
+    counts = []
+    orig = tr.densify_and_prune
+    tr.densify_and_prune = lambda *a: counts.append(orig(*a)) or counts[-1]
+    last = tr.training(0, 0)
+    assert len(counts) == 6 and sum(c[0] + c[1] for c in counts) > 0 and sum(c[2] for c in counts) > 0, counts
+    n_now = gm._xyz.shape[0]
+    assert n_now != N and gm._features.shape[0] == n_now and gm.confidence.shape[0] == n_now
+    for grp, p in zip(tr.optimizer.param_groups, gm.parameters()):
+        assert grp["params"][0] is p and tr.optimizer.state[p]["exp_avg"].shape == p.shape
+    assert np.isfinite(last) and last < 0.8 * first, (first, last)
+    assert tr.truncated_renders == 0
+    # the flag the orchestrator forwards (refine_GS, diffusionGS.py:1610,1640) switches it off
+    counts.clear()
+    tr.finetune(0, 1, iterations=40, disable_densification=True)
+    assert counts == [] and gm._xyz.shape[0] == n_now
