@@ -285,6 +285,14 @@ int syn3r_gemm_f16(const void* A, long long lda, const void* W, void* out, long 
                    const void* aux, long long ldaux, float s_acc, float s_res, float s_aux, int M, int N, int K,
                    void* stream);
 
+/* out[M,N] = [A1 | A2][M, K1+K2] . W[N, K1+K2]^T + bias: the contraction reads the two halves of a channel concatenation
+ * in place (resnet.py:316 conv_shortcut applied to torch.cat([hidden, skip], dim=1), unet_3d_blocks.py up blocks), so the
+ * concatenated tensor is never written.  K1, K2 % 64 == 0; served by the persistent 256 x 320 kernel only:
+ * syn3r_gemm_2src_supported() != 0 is the admission test (otherwise concatenate and call syn3r_gemm_f16). */
+int syn3r_gemm_2src_supported(int M, int N, int K1, int K2, long long lda1, long long lda2);
+int syn3r_gemm_2src_f16(const void* A1, long long lda1, int K1, const void* A2, long long lda2, int K2, const void* W,
+                        void* out, long long ldc, const void* bias, int M, int N, void* stream);
+
 /* Tuning / test hook: 0 = library default (kernel chosen per shape); 128 / 256 = register-staged kernel of that
  * block height; -128 / -256 = LDS-DMA kernel of that block height; -320 = the 256 x 320 wide-tile LDS-DMA kernel;
  * -321 = its 128 x 320 two-blocks-per-CU variant (dense contractions; the convolutions keep the default). */
@@ -373,6 +381,11 @@ int syn3r_attention_temporal_f16(const void* q, const void* k, const void* v, lo
 size_t syn3r_groupnorm_workspace_bytes(int samples, int rows);
 int syn3r_groupnorm_f16(const void* x, void* y, int samples, int rows, int C, const void* gamma, const void* beta,
                         float eps, int silu, void* workspace, size_t workspace_bytes, void* stream);
+/* The same on the channel concatenation [x1 (C1 channels) | x2 (C2 channels)] read in place (the norm1 of an up block's
+ * resnet, resnet.py:272 on torch.cat([hidden, skip], dim=1)); y is [samples, rows, C1 + C2].  C1, C2 % 8 == 0. */
+int syn3r_groupnorm_2src_f16(const void* x1, int C1, const void* x2, int C2, void* y, int samples, int rows,
+                             const void* gamma, const void* beta, float eps, int silu, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /*
  * LayerNorm over C of [M, C] fp16.  If addvec != NULL, addvec[m / rows_per_vec, :] is added first

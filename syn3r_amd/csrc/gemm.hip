@@ -66,6 +66,9 @@ struct GemmParams {
     int out_tiled;                        // the kernel writes `out` in that layout (ldc unused)
     int out_nt;                           // non-temporal output stores (see OUT_STORE)
     int a_tiled;                          // the kernel reads A in that layout (lda unused; dense mode only)
+    // Two-source A (k_gemm_widep only): columns [0, K1) of a row come from A (stride lda), columns [K1, K) from A2
+    // (stride lda2) - the channel concatenation [A | A2] the up blocks' shortcut projection reads is never written.
+    const __half* A2; long long lda2; int K1;     // A2 = null: one source
 };
 
 // element offset of (row m, column d) in the A-tiled layout of a matrix with D columns
@@ -964,6 +967,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm_widep(GemmParams p) {
     unsigned oa[4], ob[5];
     int m0 = 0, n0 = 0, tile_n = 0;
     const unsigned a_step = p.a_tiled ? 16384u : 2u * BK;      // bytes per k-tile
+    const char* abase = (const char*)p.A;                      // the A source of the next stage (two-source A: see GemmParams)
+    const int kt_switch = p.A2 ? p.K1 / BK : 0x7fffffff;       // first k-tile read from A2
+    int ks = 0;                                                // k-tile index of the next stage of the tile being staged
     // Tile order: bands of 4 tile columns, row-major inside a band.  The 32 tiles an XCD holds at one time are then
     // 8 rows x 4 columns: per k-tile they pull 8 A slabs (32 KB) + 4 B slabs (40 KB) = 416 KB through that XCD's L2
     // for 2.4 MB of LDS fill, and the band's weight panel (4 x 320 rows x K) is what the XCD keeps re-reading round
@@ -977,6 +983,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_widep(GemmParams p) {
         const int tile_m = (int)(t2 / w);
         tile_n = (int)(b * bw + t2 % w);
         m0 = tile_m * WBM; n0 = tile_n * WBN;
+        ks = 0; abase = (const char*)p.A;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int r = m0 + wv * 32 + i * 8;
@@ -991,13 +998,24 @@ __global__ void __launch_bounds__(512, 2) k_gemm_widep(GemmParams p) {
             ob[j] = 2u * (unsigned)n * (unsigned)p.K;
         }
     };
-    unsigned voff_a = 0, voff_b = 0;      // per-lane byte offset inside a piece (row lane >> 3, swizzled 16-byte chunk)
+    unsigned voff_a = 0, voff_a2 = 0, voff_b = 0;      // per-lane byte offset inside a piece (row lane >> 3, swizzled 16-byte chunk)
     auto issue_stage = [&](int buf, auto LOAD) {      // stages are issued in k order; LOAD = false only advances the offsets
         constexpr bool load = decltype(LOAD)::value;
         char* st = smem_raw + buf * W_STAGE;
+        if (ks == kt_switch) {            // wave-uniform: from here on the A columns come from the second source
+            abase = (const char*)p.A2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int r = m0 + wv * 32 + i * 8;
+                r = r < p.M - 8 ? r : p.M - 8;
+                oa[i] = 2u * (unsigned)r * (unsigned)p.lda2;
+            }
+        }
+        const unsigned va = ks >= kt_switch ? voff_a2 : voff_a;
+        ++ks;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if constexpr (load) __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.A + (size_t)(oa[i] + voff_a)), (lds_void_t*)(st + (wv * 4 + i) * 1024), 16, 0, 0);
+            if constexpr (load) __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase + (size_t)(oa[i] + va)), (lds_void_t*)(st + (wv * 4 + i) * 1024), 16, 0, 0);
             oa[i] += a_step;
         }
 #pragma unroll
@@ -1039,6 +1057,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_widep(GemmParams p) {
             asm volatile("" : "+v"(lo));
             const int prow = lo >> 3, csrc = (lo & 7) ^ prow;
             voff_a = p.a_tiled ? (unsigned)((prow * 64 + csrc * 8) * 2) : (unsigned)(prow * (int)p.lda + csrc * 8) * 2u;
+            voff_a2 = (unsigned)(prow * (int)p.lda2 + csrc * 8) * 2u;
             voff_b = (unsigned)(prow * p.K + csrc * 8) * 2u;
             const int fr = lo & 15, fq = lo >> 4;
             a_row = (unsigned)((wm * WM + fr) * 128);
@@ -1607,7 +1626,8 @@ int launch_wide(const GemmParams& p, hipStream_t stream) {
         if (pers_env == -2) { const char* e = getenv("SYN3R_WIDE_PERSISTENT"); pers_env = e ? atoi(e) : 1; }
         const bool lean = !p.rowvec && (!p.aux || p.residual) && (p.geglu_D <= 0 || (p.geglu_D % 8 == 0 && p.s_acc == 1.0f));
         const bool small = (p.a_tiled ? (long long)((p.M + 127) / 128) * 128 * p.K : (long long)p.M * p.lda) < (1ll << 31) &&
-                           (long long)p.N * p.K < (1ll << 31);      // 32-bit byte offsets inside both operands
+                           (long long)p.N * p.K < (1ll << 31) &&      // 32-bit byte offsets inside the operands
+                           (!p.A2 || (long long)p.M * p.lda2 < (1ll << 31));
         if (pers_env != 0 && lean && small && p.M % 8 == 0 && p.N % 8 == 0 && p.M >= 8 && p.N >= 8) return launch_widep(p, stream);
     }
     constexpr size_t lds = (size_t)2 * W_STAGE;   // 147,456 B
@@ -1737,6 +1757,12 @@ extern "C" int syn3r_gemm_set_tile(int bm) {
     return SYN3R_OK;
 }
 
+extern "C" int syn3r_gemm_2src_supported(int M, int N, int K1, int K2, long long lda1, long long lda2) {
+    if (M < 8 || N < 8 || M % 8 || N % 8 || K1 <= 0 || K2 <= 0 || K1 % BK || K2 % BK) return 0;
+    if ((long long)M * lda1 >= (1ll << 31) || (long long)M * lda2 >= (1ll << 31) || (long long)N * (K1 + K2) >= (1ll << 31)) return 0;
+    return 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Skinny contraction, M <= 16 rows (time-embedding projections [B,1280], the folded Sk = 1 cross-attention
 // context k/v [B,1024], the frame-position MLP [F,C]): ~100 launches per UNet forward whose whole cost is
@@ -1809,6 +1835,22 @@ extern "C" int syn3r_gemm_f16(const void* A, long long lda, const void* W, void*
     if (M <= SKINNY_MAX_M && !p.rowvec && !p.residual && !p.aux && g_tile_bm == 0 && g_dma_bm == 0)
         return launch_skinny(p, (hipStream_t)stream);
     return launch<MODE_DENSE>(p, (hipStream_t)stream);
+}
+
+extern "C" int syn3r_gemm_2src_f16(const void* A1, long long lda1, int K1, const void* A2, long long lda2, int K2, const void* W,
+                                   void* out, long long ldc, const void* bias, int M, int N, void* stream) {
+    GemmParams p{};
+    p.A = (const __half*)A1; p.lda = lda1; p.A2 = (const __half*)A2; p.lda2 = lda2; p.K1 = K1;
+    p.W = (const __half*)W; p.out = (__half*)out; p.ldc = ldc; p.bias = (const __half*)bias;
+    p.s_acc = 1.0f; p.s_res = 1.0f; p.s_aux = 1.0f; p.M = M; p.N = N; p.K = K1 + K2;
+    SYN3R_REQUIRE(A2 != nullptr && K1 > 0 && K2 > 0 && K1 % BK == 0 && K2 % BK == 0, "gemm_2src: K1=%d, K2=%d must be positive multiples of %d", K1, K2, BK);
+    int rc = check_common(p, "gemm_2src_f16");
+    if (rc) return rc;
+    SYN3R_REQUIRE(lda1 % 8 == 0 && lda1 >= K1 && lda2 % 8 == 0 && lda2 >= K2 && ((uintptr_t)A2 % 16) == 0, "gemm_2src: bad strides / alignment");
+    // only the persistent 256 x 320 kernel reads two sources; syn3r_gemm_2src_supported() is its admission test
+    SYN3R_REQUIRE(syn3r_gemm_2src_supported(M, N, K1, K2, lda1, lda2) != 0,
+                  "gemm_2src: shape M=%d N=%d not served by the two-source kernel (concatenate and call syn3r_gemm_f16)", M, N);
+    return launch_widep(p, (hipStream_t)stream);
 }
 
 extern "C" int syn3r_gemm_geglu_f16(const void* A, long long lda, const void* Wpacked, const void* bias_packed, void* out,

@@ -17,7 +17,18 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // ---------------------------------------------------------------- GroupNorm
 // thread t owns channel vector cv = t % cvec (8 channels) of rows (t / cvec) + k * rpb
-__global__ void k_gn_stats(const __half* __restrict__ x, int R, int C, int rows_per_block, float* __restrict__ stats) {
+// Two-source input: channels [0, C1) of a row come from x (row stride C1), channels [C1, C) from x2 (row stride C - C1):
+// the concatenation [x | x2] along the channels that the up blocks normalise (unet_3d_blocks.py: torch.cat of the
+// hidden state and the skip) is never written.  x2 = null (C1 = C): one tensor.
+__device__ __forceinline__ const __half* gn_src(const __half* x, const __half* x2, int C, int C1, int cv, size_t sample_rows,
+                                                int& stride) {
+    if (cv * 8 < C1) { stride = C1; return x + sample_rows * (size_t)C1 + (size_t)cv * 8; }
+    stride = C - C1;
+    return x2 + sample_rows * (size_t)(C - C1) + (size_t)(cv * 8 - C1);
+}
+
+__global__ void k_gn_stats(const __half* __restrict__ x, const __half* __restrict__ x2, int C1, int R, int C, int rows_per_block,
+                           float* __restrict__ stats) {
     extern __shared__ float red[];   // [threads][16]
     const int cvec = C >> 3;
     const int rpb = blockDim.x / cvec;
@@ -25,12 +36,13 @@ __global__ void k_gn_stats(const __half* __restrict__ x, int R, int C, int rows_
     const int sample = blockIdx.y;
     const int r_begin = blockIdx.x * rows_per_block;
     const int r_end = min(R, r_begin + rows_per_block);
-    const __half* base = x + (size_t)sample * R * C + (size_t)cv * 8;
+    int stride;
+    const __half* base = gn_src(x, x2, C, C1, cv, (size_t)sample * R, stride);
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
     for (int r = r_begin + rl; r < r_end; r += rpb) {
-        half8 v = *(const half8*)(base + (size_t)r * C);
+        half8 v = *(const half8*)(base + (size_t)r * stride);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float f = (float)v[e];
@@ -88,7 +100,8 @@ __global__ void __launch_bounds__(1024) k_gn_finalize(const float* __restrict__ 
 }
 
 template <bool SILU>
-__global__ void k_gn_apply(const __half* __restrict__ x, __half* __restrict__ y, int R, int C, int rows_per_block,
+__global__ void k_gn_apply(const __half* __restrict__ x, const __half* __restrict__ x2, int C1, __half* __restrict__ y, int R,
+                           int C, int rows_per_block,
                            const float* __restrict__ stats, const __half* __restrict__ gamma,
                            const __half* __restrict__ beta, float eps) {
     const int cvec = C >> 3;
@@ -110,8 +123,10 @@ __global__ void k_gn_apply(const __half* __restrict__ x, __half* __restrict__ y,
         b[e] = be - mean * rstd * ga;
     }
     const size_t off = (size_t)sample * R * C + (size_t)cv * 8;
+    int stride;
+    const __half* src = gn_src(x, x2, C, C1, cv, (size_t)sample * R, stride);
     for (int r = r_begin + rl; r < r_end; r += rpb) {
-        half8 v = *(const half8*)(x + off + (size_t)r * C);
+        half8 v = *(const half8*)(src + (size_t)r * stride);
         half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -233,12 +248,13 @@ extern "C" size_t syn3r_groupnorm_workspace_bytes(int samples, int rows) {
     return (size_t)samples * chunks * 32 * 2 * sizeof(float) + (size_t)samples * 32 * 2 * sizeof(float);
 }
 
-extern "C" int syn3r_groupnorm_f16(const void* x, void* y, int samples, int rows, int C, const void* gamma,
-                                   const void* beta, float eps, int silu, void* workspace, size_t workspace_bytes,
-                                   void* stream_) {
+namespace {
+int groupnorm_launch(const void* x, const void* x2, int C1, void* y, int samples, int rows, int C, const void* gamma,
+                     const void* beta, float eps, int silu, void* workspace, size_t workspace_bytes, void* stream_) {
     SYN3R_REQUIRE(x && y && gamma && beta, "groupnorm: null tensor");
     SYN3R_REQUIRE(samples > 0 && rows > 0 && C > 0 && C % 32 == 0 && C % 8 == 0, "groupnorm: bad sizes samples=%d rows=%d C=%d",
                   samples, rows, C);
+    SYN3R_REQUIRE(x2 ? (C1 > 0 && C1 < C && C1 % 8 == 0) : C1 == C, "groupnorm: bad channel split C1=%d of C=%d", C1, C);
     int threads = gn_threads(C);
     SYN3R_REQUIRE(threads > 0, "groupnorm: C=%d too large", C);
     size_t need = syn3r_groupnorm_workspace_bytes(samples, rows);
@@ -253,17 +269,32 @@ extern "C" int syn3r_groupnorm_f16(const void* x, void* y, int samples, int rows
     size_t lds = (size_t)threads * 16 * sizeof(float);
     float* partial = (float*)workspace;
     float* meanrstd = partial + (size_t)samples * chunks * 64;
-    SYN3R_LAUNCH(k_gn_stats, grid, dim3(threads), lds, stream, (const __half*)x, rows, C, rows_per_block, partial);
+    SYN3R_LAUNCH(k_gn_stats, grid, dim3(threads), lds, stream, (const __half*)x, (const __half*)x2, C1, rows, C, rows_per_block,
+                 partial);
     SYN3R_LAUNCH(k_gn_finalize, dim3(samples), dim3(1024), 0, stream, (const float*)partial, chunks,
                  1.0f / ((float)rows * (float)(C / 32)), eps, meanrstd);
     if (silu)
-        SYN3R_LAUNCH(k_gn_apply<true>, grid, dim3(threads), 0, stream, (const __half*)x, (__half*)y, rows, C,
-                     rows_per_block, (const float*)meanrstd, (const __half*)gamma, (const __half*)beta, eps);
+        SYN3R_LAUNCH(k_gn_apply<true>, grid, dim3(threads), 0, stream, (const __half*)x, (const __half*)x2, C1, (__half*)y, rows,
+                     C, rows_per_block, (const float*)meanrstd, (const __half*)gamma, (const __half*)beta, eps);
     else
-        SYN3R_LAUNCH(k_gn_apply<false>, grid, dim3(threads), 0, stream, (const __half*)x, (__half*)y, rows, C,
-                     rows_per_block, (const float*)meanrstd, (const __half*)gamma, (const __half*)beta, eps);
+        SYN3R_LAUNCH(k_gn_apply<false>, grid, dim3(threads), 0, stream, (const __half*)x, (const __half*)x2, C1, (__half*)y, rows,
+                     C, rows_per_block, (const float*)meanrstd, (const __half*)gamma, (const __half*)beta, eps);
     SYN3R_LAUNCH_CHECK("groupnorm launch");
     return SYN3R_OK;
+}
+}  // namespace
+
+extern "C" int syn3r_groupnorm_f16(const void* x, void* y, int samples, int rows, int C, const void* gamma,
+                                   const void* beta, float eps, int silu, void* workspace, size_t workspace_bytes,
+                                   void* stream_) {
+    return groupnorm_launch(x, nullptr, C, y, samples, rows, C, gamma, beta, eps, silu, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int syn3r_groupnorm_2src_f16(const void* x1, int C1, const void* x2, int C2, void* y, int samples, int rows,
+                                        const void* gamma, const void* beta, float eps, int silu, void* workspace,
+                                        size_t workspace_bytes, void* stream_) {
+    SYN3R_REQUIRE(x2 != nullptr && C2 > 0, "groupnorm_2src: second source missing");
+    return groupnorm_launch(x1, x2, C1, y, samples, rows, C1 + C2, gamma, beta, eps, silu, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int syn3r_layernorm_f16(const void* x, void* y, void* xsum, const void* addvec, int rows_per_vec,

@@ -342,7 +342,9 @@ class UNetSpatioTemporalConditionModel:
     def _blend_scales(self, name: str):
         return self.alpha[name]
 
-    def _resblock(self, pre: str, x: torch.Tensor, st: dict, cin: int, cout: int) -> torch.Tensor:
+    def _resblock(self, pre: str, x: torch.Tensor, st: dict, cin: int, cout: int, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`x2`: the block input is the channel concatenation [x | x2] (up blocks: hidden state and skip,
+        unet_3d_blocks.py); norm1 and the shortcut projection read the two tensors in place."""
         B, F, h, w_ = st["B"], st["F"], st["h"], st["w"]
         HW = h * w_
         s, t = pre + ".spatial_res_block", pre + ".temporal_res_block"
@@ -350,12 +352,14 @@ class UNetSpatioTemporalConditionModel:
         # spatial ResnetBlock2D (resnet.py:325-378)
         a0, a1 = self._temb_slices[s + ".time_emb_proj"]
         tp_s = st["temb_all"][:, a0:a1]                                   # [B, cout], a column slice of the stacked projection
-        hcur = ops.groupnorm(x, W(s + ".norm1.weight"), W(s + ".norm1.bias"), B * F, 1e-5, True)
+        hcur = ops.groupnorm(x, W(s + ".norm1.weight"), W(s + ".norm1.bias"), B * F, 1e-5, True, x2=x2)
         hcur = ops.conv3x3(hcur.view(B * F, h, w_, cin), W(s + ".conv1.weight"), W(s + ".conv1.bias"),
                            rowvec=tp_s, rows_per_vec=F * HW).view(-1, cout)
         hcur = ops.groupnorm(hcur, W(s + ".norm2.weight"), W(s + ".norm2.bias"), B * F, 1e-5, True)
         skip = x
-        if cin != cout:
+        if x2 is not None:                 # (a concatenated input is always wider than the output: the shortcut exists)
+            skip = ops.linear_cat(x, x2, W(s + ".conv_shortcut.weight"), W(s + ".conv_shortcut.bias"))
+        elif cin != cout:
             skip = ops.linear(x, W(s + ".conv_shortcut.weight"), W(s + ".conv_shortcut.bias"))
         xs = ops.conv3x3(hcur.view(B * F, h, w_, cout), W(s + ".conv2.weight"), W(s + ".conv2.bias"),
                          residual=skip).view(-1, cout)
@@ -505,8 +509,10 @@ class UNetSpatioTemporalConditionModel:
             i = blk["idx"]
             for j, (cin, cout) in enumerate(blk["layers"]):
                 sk, sk_ch = skips.pop()
-                x = torch.cat([x, sk], dim=1)
-                x = self._resblock(f"up_blocks.{i}.resnets.{j}", x, st, cin, cout)
+                if os.environ.get("SYN3R_UNET_CAT") == "1":      # tuning: materialise the concatenation
+                    x = self._resblock(f"up_blocks.{i}.resnets.{j}", torch.cat([x, sk], dim=1), st, cin, cout)
+                else:                                            # the skip is read in place (norm1 + shortcut take two sources)
+                    x = self._resblock(f"up_blocks.{i}.resnets.{j}", x, st, cin, cout, x2=sk)
                 if blk["attn"]:
                     x = self._transformer(f"up_blocks.{i}.attentions.{j}", x, st, cout, blk["heads"])
             if blk["up"]:

@@ -238,19 +238,51 @@ def attention_temporal(qkv: torch.Tensor, B: int, F: int, HW: int, heads: int) -
     return out
 
 
-def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, samples: int, eps: float, silu: bool) -> torch.Tensor:
-    """x [samples*rows, C] -> same shape; 32 groups, statistics per (sample, group)."""
-    dev = _chk(x, gamma, beta)
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, samples: int, eps: float, silu: bool,
+              x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [samples*rows, C] -> same shape; 32 groups, statistics per (sample, group).  With `x2` [samples*rows, C2] the
+    input is the channel concatenation [x | x2], read in place (the result has C + C2 channels)."""
+    dev = _chk(x, gamma, beta, x2)
     M, C = x.shape
     if M % samples:
         raise ValueError("groupnorm: rows not divisible by samples")
-    y = torch.empty_like(x)
     lib = L.load()
     ws = L.workspace(dev, lib.syn3r_groupnorm_workspace_bytes(samples, M // samples), "gn")
+    if x2 is not None:
+        if x2.shape[0] != M:
+            raise ValueError("groupnorm: the two sources must have the same rows")
+        C2 = x2.shape[1]
+        y = torch.empty((M, C + C2), dtype=H, device=dev)
+        rc = lib.syn3r_groupnorm_2src_f16(L.ptr(x), C, L.ptr(x2), C2, L.ptr(y), samples, M // samples, L.ptr(gamma), L.ptr(beta),
+                                          float(eps), 1 if silu else 0, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+        L.check(rc, "syn3r_groupnorm_2src_f16")
+        return y
+    y = torch.empty_like(x)
     rc = lib.syn3r_groupnorm_f16(L.ptr(x), L.ptr(y), samples, M // samples, C, L.ptr(gamma), L.ptr(beta), float(eps),
                                  1 if silu else 0, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
     L.check(rc, "syn3r_groupnorm_f16")
     return y
+
+
+def linear_cat(x1: torch.Tensor, x2: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[x1 | x2] @ weight^T + bias without writing the concatenation (the shortcut projection of an up block's resnet on
+    torch.cat([hidden, skip], dim=1), resnet.py:316).  Shapes the two-source kernel does not serve are concatenated."""
+    dev = L.require_gpu(x1, x2, weight)
+    M, K1 = x1.shape
+    K2 = x2.shape[1]
+    N = weight.shape[0]
+    if x2.shape[0] != M or weight.shape[1] != K1 + K2 or x1.stride(1) != 1 or x2.stride(1) != 1:
+        raise ValueError(f"linear_cat: x1 {tuple(x1.shape)} / x2 {tuple(x2.shape)} / weight {tuple(weight.shape)} mismatch")
+    _chk(weight, bias)
+    lib = L.load()
+    if not lib.syn3r_gemm_2src_supported(M, N, K1, K2, x1.stride(0), x2.stride(0)):
+        return linear(torch.cat([x1, x2], dim=1), weight, bias)
+    out = torch.empty((M, N), dtype=H, device=dev)
+    rc = lib.syn3r_gemm_2src_f16(x1.data_ptr(), x1.stride(0), K1, x2.data_ptr(), x2.stride(0), K2, L.ptr(weight), out.data_ptr(),
+                                 out.stride(0), L.ptr(bias), M, N, L.stream_ptr(dev))
+    L.check(rc, "syn3r_gemm_2src_f16")
+    _count("gemm", 2.0 * M * N * (K1 + K2))
+    return out
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, *,

@@ -361,3 +361,44 @@ def test_feedforward_rejects_bad_input(gpu):
     wp, bp, _ = ops.pack_geglu(w1, b1)
     with pytest.raises(_lib.Syn3rError, match="multiple of 64"):
         ops.feedforward(x, wp, bp, 96, rnd(g, 64, 96, dev=gpu))
+
+
+@pytest.mark.parametrize("M,K1,K2,N", [(5120, 128, 64, 4800), (4032, 1280, 1280, 1280), (1000, 64, 192, 320), (36, 64, 64, 48)])
+def test_linear_cat_two_source(M, K1, K2, N, gpu):
+    """[x1 | x2] @ W^T + b with the concatenation read in place by the persistent kernel (first k-tiles from x1, the rest
+    from x2; tiles that prefetch their successor's first stage switch back to x1), against the concatenated fp32
+    reference and, bit for bit, against the one-source kernel on the materialised concatenation.  (36 rows: not served
+    by the two-source kernel -> the wrapper concatenates.)"""
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(M + N)
+    x1, x2 = rnd(g, M, K1, dev=gpu), rnd(g, M, K2, dev=gpu)
+    w, b = rnd(g, N, K1 + K2, scale=(K1 + K2) ** -0.5, dev=gpu), rnd(g, N, dev=gpu)
+    got = ops.linear_cat(x1, x2, w, b)
+    cat = torch.cat([x1, x2], 1)
+    close(got, cat.float() @ w.float().T + b.float())
+    # strided sources (column slices of wider tensors)
+    wide1, wide2 = rnd(g, M, K1 + 64, dev=gpu), rnd(g, M, K2 + 128, dev=gpu)
+    a, c = wide1[:, 64:], wide2[:, :K2]
+    close(ops.linear_cat(a, c, w, b), torch.cat([a, c], 1).float() @ w.float().T + b.float())
+    if M % 8 == 0:
+        from syn3r_amd import _lib
+        lib = _lib.load()
+        try:                                                    # same kernel, same arithmetic order: identical bits
+            _lib.check(lib.syn3r_gemm_set_tile(-320), "set_tile")
+            assert torch.equal(got, ops.linear(cat, w, b))
+        finally:
+            lib.syn3r_gemm_set_tile(0)
+
+
+@pytest.mark.parametrize("samples,rows,C1,C2,silu", [(4, 100, 64, 64, True), (3, 64, 640, 320, True), (2, 37, 320, 640, False),
+                                                     (2, 50, 1280, 1280, True)])
+def test_groupnorm_two_source(samples, rows, C1, C2, silu, gpu):
+    """GroupNorm over the channel concatenation [x1 | x2] read in place == GroupNorm of the materialised concatenation,
+    bit for bit (640 + 320 channels: a group of 30 channels straddles the boundary between the sources)."""
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(C1 + C2 + rows)
+    x1, x2 = rnd(g, samples * rows, C1, dev=gpu), rnd(g, samples * rows, C2, dev=gpu)
+    ga, be = rnd(g, C1 + C2, dev=gpu), rnd(g, C1 + C2, dev=gpu)
+    got = ops.groupnorm(x1, ga, be, samples, 1e-5, silu, x2=x2)
+    exp = ops.groupnorm(torch.cat([x1, x2], 1), ga, be, samples, 1e-5, silu)
+    assert got.shape == (samples * rows, C1 + C2) and torch.equal(got, exp)
