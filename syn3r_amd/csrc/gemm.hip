@@ -1694,7 +1694,9 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
             // overlaps: 128 x 320 blocks are 6 % faster on the L0 gated projection and 2 % on qkv; from K = 640 on
             // the 256-row tile's weight reuse wins (+1..12 %) (tools/gemm_ab.py SYN3R_GEMM_W128 0 1, same box); on the
             // residual-add projections it loses 7..25 % to the 128 x 160 blocks (no early residual prefetch either)
-            if constexpr (MODE == MODE_DENSE) { if (w128_env == 1 || (w128_env != 0 && p.K <= 320)) return launch_w128(p, stream); }
+            // (round 2, persistent 256-row kernel with the lean epilogue: it now wins the K = 320 shapes of one or two tile
+            // columns by 12..20 % and ties on qkv, N = 960, which stays here)
+            if constexpr (MODE == MODE_DENSE) { if (w128_env == 1 || (w128_env != 0 && p.K <= 320 && p.N > 640)) return launch_w128(p, stream); }
             return launch_wide<MODE>(p, stream);
         }
     }
