@@ -871,6 +871,17 @@ __device__ __forceinline__ void widep_store(const GemmParams& p, float4v (&acc)[
     typedef _Float16 half4e __attribute__((ext_vector_type(4)));
     const int fr = lane & 15, fq = lane >> 4;
     __half* st = (__half*)epi + wv * (WM * EPI_LD);
+    // per-sample row vector (time embedding / folded cross-attention): row m takes rowvec[m / rows_per_vec] (or
+    // rowvec[m mod |rows_per_vec|]); rows past M read vector 0 (their results are never stored)
+    const __half* rv[TM];
+    if (p.rowvec) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = gm0 + i * 16 + fr;
+            const int vi = m < p.M ? (p.rows_per_vec > 0 ? m / p.rows_per_vec : m % (-p.rows_per_vec)) : 0;
+            rv[i] = p.rowvec + (long long)vi * p.ldrv;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = gn0 + j * 16 + fq * 4;
@@ -882,9 +893,15 @@ __device__ __forceinline__ void widep_store(const GemmParams& p, float4v (&acc)[
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float a4[4] = {b4[0], b4[1], b4[2], b4[3]};
+            if (p.rowvec && n < N) {
+                const half4e t = *(const half4e*)(rv[i] + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a4[r] += (float)t[r];
+            }
             half4e o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (_Float16)((acc[i][j][r] + b4[r]) * p.s_acc);
+            for (int r = 0; r < 4; ++r) o[r] = (_Float16)((acc[i][j][r] + a4[r]) * p.s_acc);
             *(half4e*)(st + (i * 16 + fr) * EPI_LD + j * 16 + fq * 4) = o;
         }
     }
@@ -1624,7 +1641,7 @@ int launch_wide(const GemmParams& p, hipStream_t stream) {
     if constexpr (MODE == MODE_DENSE) {
         static int pers_env = -2;       // SYN3R_WIDE_PERSISTENT=0: the one-tile-per-block kernel (tuning)
         if (pers_env == -2) { const char* e = getenv("SYN3R_WIDE_PERSISTENT"); pers_env = e ? atoi(e) : 1; }
-        const bool lean = !p.rowvec && (!p.aux || p.residual) && (p.geglu_D <= 0 || (p.geglu_D % 8 == 0 && p.s_acc == 1.0f));
+        const bool lean = (!p.rowvec || p.geglu_D <= 0) && (!p.aux || p.residual) && (p.geglu_D <= 0 || (p.geglu_D % 8 == 0 && p.s_acc == 1.0f));
         const bool small = (p.a_tiled ? (long long)((p.M + 127) / 128) * 128 * p.K : (long long)p.M * p.lda) < (1ll << 31) &&
                            (long long)p.N * p.K < (1ll << 31) &&      // 32-bit byte offsets inside the operands
                            (!p.A2 || (long long)p.M * p.lda2 < (1ll << 31));
@@ -1683,12 +1700,14 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
     if (g_dma_bm == 0 && wide_env != 0) {
         // measured on MI355X inside the UNet (tools/gemm_ab.py, same box): the 256 x 320 tile is 7..14 % faster on
         // the dense contractions whenever its tiles fill the 256 CUs (last round >= 80 % full), except the
-        // residual-add projections with K <= 1280, whose epilogue misses the early residual prefetch (+2..19 %);
+        // residual-add projections with K <= 320, whose time is their epilogue;
         // the implicit-GEMM convolutions are within 3 % either way and keep the two-blocks-per-CU kernel
         const long long tiles = (long long)((p.M + WBM - 1) / WBM) * ((p.N + WBN - 1) / WBN);
         const long long rounds = (tiles + 255) / 256;
         const bool fills = tiles * 10 >= rounds * 256 * 8;
-        const bool short_residual = p.residual != nullptr && p.K <= 1280;
+        // (round 2: with the persistent kernel's epilogue - row vector, all ten residual requests in flight at once - the
+        // K = 640 / 1280 residual projections are 3..4 % faster on the wide tile; K = 320 stays 4 % slower there)
+        const bool short_residual = p.residual != nullptr && p.K <= 320;
         if (wide_env == 1 || (MODE == MODE_DENSE && fills && !short_residual)) {
             // K <= 320 (5 k-tiles): the tile's time is its gate and store tail, which a second block on the CU
             // overlaps: 128 x 320 blocks are 6 % faster on the L0 gated projection and 2 % on qkv; from K = 640 on

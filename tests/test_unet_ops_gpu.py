@@ -272,6 +272,11 @@ def test_gemm_persistent_wide_tile(M, N, K, gpu):
         close(ops.linear(x, w, b, s_acc=0.5), 0.5 * (y + b.float()))
         close(ops.linear(x, w, b, residual=res), y + b.float() + res.float())
         close(ops.linear(x, w, b, residual=res, aux=aux, s_acc=0.3, s_res=1.0, s_aux=0.7), 0.3 * (y + b.float()) + res.float() + 0.7 * aux.float())
+        rpv = M // 8                                                    # per-sample row vectors, both indexings
+        rv = rnd(g, 8, N, dev=gpu)
+        close(ops.linear(x, w, b, rowvec=rv, rows_per_vec=rpv, residual=res),
+              y + b.float() + rv.float().repeat_interleave(rpv, 0)[:M] + res.float())
+        close(ops.linear(x, w, b, rowvec=rv, rows_per_vec=-8), y + b.float() + rv.float().repeat(M // 8 + 1, 1)[:M])
         if N % 16 == 0:
             D = N // 2
             wp, bp, _ = ops.pack_geglu(w, b)
