@@ -1455,6 +1455,12 @@ __global__ void __launch_bounds__(512, 2) k_ffn320(FfnParams q) {
     const unsigned h_wr = lds0 + F_H + (unsigned)((wm * 64 + fr) * 128) + (unsigned)((((hc >> 3) ^ (fr & 7)) << 4) + (hc & 7) * 2);
     const unsigned bias_rd = lds0 + F_BIAS + (unsigned)(wv * 512 + (wn * 32 + fq * 4) * 2);   // + (j & 1) * 256 ; gate at + 32
 
+#ifdef SYN3R_TIMING      // tools/wide_timing.py --ffn: s_memtime ticks per chunk of [wait, barrier, reads+issue, mfma] of phase 1, gate, P wait+barrier, phase 2
+    unsigned long long ft[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f_a = __builtin_amdgcn_s_memtime();
+#define FSTAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ft[i] += t_ - f_a; f_a = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define FSTAMP(i)
+#endif
     int cslot = 0;
     for (int j = 0; j < nchunks; ++j) {
         float4v S[TM][2];                 // [row tile][0 = hidden tile | 1 = gate tile]
@@ -1469,7 +1475,9 @@ __global__ void __launch_bounds__(512, 2) k_ffn320(FfnParams q) {
             else if (kt < 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if (wv < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            FSTAMP(0);
             __builtin_amdgcn_s_barrier();
+            FSTAMP(1);
             const unsigned xa = x_row + (unsigned)(kt * 16384);
             const unsigned wa = lds0 + F_RING + (unsigned)(cslot * F_SLOT) + w1_row;
             half8 a0[TM], b0[2], a1[TM], b1[2];
@@ -1485,6 +1493,7 @@ __global__ void __launch_bounds__(512, 2) k_ffn320(FfnParams q) {
             // covers the reads' latency instead of preceding it
             issue_next();                 // into the slot every wavefront finished reading before this barrier
             if (kt == 0) issue_next();    // ... and the second slot the previous chunk's phase 2 released
+            FSTAMP(2);
             if (kt == 0) {
                 asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(b0[0]), "+v"(b0[1]));
             } else {
@@ -1508,6 +1517,7 @@ __global__ void __launch_bounds__(512, 2) k_ffn320(FfnParams q) {
                 S[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[1], a1[i], S[i][1], 0, 0, 0);
             }
             if (++cslot == 3) cslot = 0;
+            FSTAMP(3);
         }
         // ---- gate (GEGLU.forward): hidden * gelu(gate) on the fp16-rounded projection outputs (packed fp32 pairs,
         // gelu_pk), written as the k-tile image of the second contraction (same swizzle as the DMA'd tiles)
@@ -1523,8 +1533,10 @@ __global__ void __launch_bounds__(512, 2) k_ffn320(FfnParams q) {
             }
             DS_WRITE64(h_wr + (unsigned)(i * 2048), o);
         }
+        FSTAMP(4);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // both W2 halves have landed, h is written
         __builtin_amdgcn_s_barrier();
+        FSTAMP(5);
         // ---- phase 2: out[64 x 80] += h[64 x 64] . W2[80 x 64]^T ; the wavefront's columns sit in half wn >> 1
         {
             int bslot = cslot + (wn >> 1);
@@ -1555,7 +1567,13 @@ __global__ void __launch_bounds__(512, 2) k_ffn320(FfnParams q) {
         }
         cslot += 2;
         if (cslot >= 3) cslot -= 3;
+        FSTAMP(6);
     }
+#ifdef SYN3R_TIMING
+    if (blockIdx.x == gridDim.x / 2 && lane == 0)
+        for (int i = 0; i < 8; ++i) g_wide_timing[wv * 8 + i] = i < 7 ? ft[i] : (unsigned long long)nchunks;
+#endif
+#undef FSTAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // every wavefront is done with the tiles before the epilogue reuses the LDS
     gemm_epilogue<1>(p, acc, smem_raw, lane, wv, wm, wn, m0, 0, 0);

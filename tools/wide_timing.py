@@ -59,7 +59,28 @@ def run_persistent(M, N, K, geglu):
               f"  clock {mt / max(rt, 1) * 100:.0f} MHz ({mt} memtime / {rt} realtime ticks)")
 
 
-if "--persistent" in sys.argv:
+def run_ffn():
+    """k_ffn320: ticks per 64-wide hidden chunk of each segment (one block, wavefronts 0 and 4)."""
+    M, C, D = 258048, 320, 1280
+    x = torch.randn(M, C, device=dev).to(H)
+    w1 = (torch.randn(2 * D, C, device=dev) * 0.05).to(H); b1 = torch.zeros(2 * D, device=dev, dtype=H)
+    w2 = (torch.randn(C, D, device=dev) * 0.03).to(H); b2 = torch.zeros(C, device=dev, dtype=H)
+    cw, cb = ops.pack_geglu_chunked(w1, b1)[:2]
+    for _ in range(30):
+        ops.feedforward_fused(x, cw, cb, D, w2, b2, residual=x)
+    torch.cuda.synchronize()
+    out = (ctypes.c_ulonglong * 64)()
+    lib.syn3r_debug_wide_timing(out)
+    names = ["p1 wait", "p1 barrier", "p1 reads+issue", "p1 mfma", "gate", "P wait+barrier", "phase 2"]
+    for wv in (0, 4):
+        n = max(out[wv * 8 + 7], 1)
+        v = [out[wv * 8 + i] / n for i in range(7)]
+        print(f"  ffn320 wave {wv}: " + "  ".join(f"{a}={b:7.0f}" for a, b in zip(names, v)) + f"  per chunk total={sum(v):8.0f} (matrix work 3840)")
+
+
+if "--ffn" in sys.argv:
+    run_ffn()
+elif "--persistent" in sys.argv:
     for M, N, K, g in [(64512, 5120, 640, True), (64512, 1920, 640, False), (16128, 10240, 1280, True), (16128, 1280, 5120, False)]:
         run_persistent(M, N, K, g)
 else:
