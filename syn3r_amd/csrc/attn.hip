@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(ATHREADS, 2) k_attn_temporal(AttnParams p, lon
 extern "C" int syn3r_attention_f16(const void* q, const void* k, const void* v, long long ld, void* out, long long ldo,
                                    int nseq, int S, int heads, void* stream) {
     SYN3R_REQUIRE(q && k && v && out, "attention: null tensor");
-    SYN3R_REQUIRE(nseq > 0 && S > 0 && heads > 0, "attention: bad sizes nseq=%d S=%d heads=%d", nseq, S, heads);
+    SYN3R_REQUIRE(SYN3R_DIM_OK(nseq) && SYN3R_DIM_OK(S) && heads > 0 && heads <= 4096, "attention: bad sizes nseq=%d S=%d heads=%d", nseq, S, heads);
     SYN3R_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && ld >= 64 * heads && ldo >= 64 * heads, "attention: bad strides");
     SYN3R_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0, "attention: misaligned tensor");
     AttnParams p{};
@@ -390,7 +390,7 @@ extern "C" int syn3r_attention_f16(const void* q, const void* k, const void* v, 
 extern "C" int syn3r_attention_temporal_f16(const void* q, const void* k, const void* v, long long ld, void* out,
                                             long long ldo, int B, int F, int HW, int heads, void* stream) {
     SYN3R_REQUIRE(q && k && v && out, "attention_temporal: null tensor");
-    SYN3R_REQUIRE(B > 0 && HW > 0 && heads > 0 && F >= 1 && F <= 32, "attention_temporal: bad sizes B=%d F=%d HW=%d heads=%d (F <= 32)",
+    SYN3R_REQUIRE(SYN3R_DIM_OK(B) && SYN3R_DIM_OK(HW) && heads > 0 && heads <= 4096 && F >= 1 && F <= 32, "attention_temporal: bad sizes B=%d F=%d HW=%d heads=%d (F <= 32)",
                   B, F, HW, heads);
     SYN3R_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && ld >= 64 * heads && ldo >= 64 * heads, "attention_temporal: bad strides");
     SYN3R_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0, "attention_temporal: misaligned tensor");

@@ -36,6 +36,14 @@ struct Mat3d { double m[9]; };
 
 }  // namespace syn3r
 
+// Upper bound of every int size argument of the ABI (rows, channels, image sides, Gaussians ...): checked FIRST, so the
+// size arithmetic behind the other checks (products, round-ups) stays inside int / long long whatever the caller passes
+// (tests/test_abi_sanitize.py drives every entry point with INT_MAX and friends under UBSan).
+#define SYN3R_DIM_MAX (1 << 24)
+#define SYN3R_DIM_OK(x) ((x) > 0 && (x) <= SYN3R_DIM_MAX)
+#define SYN3R_SIDE_MAX (1 << 15)                 /* image height / width */
+#define SYN3R_SIDE_OK(x) ((x) > 0 && (x) <= SYN3R_SIDE_MAX)
+
 #define SYN3R_REQUIRE(cond, ...)                 \
     do {                                         \
         if (!(cond)) {                           \

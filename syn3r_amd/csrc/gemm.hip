@@ -1774,7 +1774,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
 
 int check_common(const GemmParams& p, const char* who) {
     SYN3R_REQUIRE(p.A && p.W && p.out, "%s: null operand", who);
-    SYN3R_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "%s: bad sizes M=%d N=%d K=%d", who, p.M, p.N, p.K);
+    SYN3R_REQUIRE(SYN3R_DIM_OK(p.M) && SYN3R_DIM_OK(p.N) && SYN3R_DIM_OK(p.K), "%s: bad sizes M=%d N=%d K=%d", who, p.M, p.N, p.K);
     SYN3R_REQUIRE(p.K % BK == 0, "%s: K=%d must be a multiple of %d", who, p.K, BK);
     SYN3R_REQUIRE(p.ldc % 8 == 0 && p.ldc >= p.N, "%s: ldc=%lld must be >= N and a multiple of 8", who, p.ldc);
     SYN3R_REQUIRE(!p.residual || (p.ldr % 8 == 0 && p.ldr >= p.N), "%s: bad residual stride", who);
@@ -1879,10 +1879,10 @@ extern "C" int syn3r_gemm_f16(const void* A, long long lda, const void* W, void*
 extern "C" int syn3r_gemm_2src_f16(const void* A1, long long lda1, int K1, const void* A2, long long lda2, int K2, const void* W,
                                    void* out, long long ldc, const void* bias, int M, int N, void* stream) {
     GemmParams p{};
+    SYN3R_REQUIRE(A2 != nullptr && SYN3R_DIM_OK(K1) && SYN3R_DIM_OK(K2) && K1 % BK == 0 && K2 % BK == 0, "gemm_2src: K1=%d, K2=%d must be positive multiples of %d", K1, K2, BK);
     p.A = (const __half*)A1; p.lda = lda1; p.A2 = (const __half*)A2; p.lda2 = lda2; p.K1 = K1;
     p.W = (const __half*)W; p.out = (__half*)out; p.ldc = ldc; p.bias = (const __half*)bias;
     p.s_acc = 1.0f; p.s_res = 1.0f; p.s_aux = 1.0f; p.M = M; p.N = N; p.K = K1 + K2;
-    SYN3R_REQUIRE(A2 != nullptr && K1 > 0 && K2 > 0 && K1 % BK == 0 && K2 % BK == 0, "gemm_2src: K1=%d, K2=%d must be positive multiples of %d", K1, K2, BK);
     int rc = check_common(p, "gemm_2src_f16");
     if (rc) return rc;
     SYN3R_REQUIRE(lda1 % 8 == 0 && lda1 >= K1 && lda2 % 8 == 0 && lda2 >= K2 && ((uintptr_t)A2 % 16) == 0, "gemm_2src: bad strides / alignment");
@@ -1895,10 +1895,10 @@ extern "C" int syn3r_gemm_2src_f16(const void* A1, long long lda1, int K1, const
 extern "C" int syn3r_gemm_geglu_f16(const void* A, long long lda, const void* Wpacked, const void* bias_packed, void* out,
                                     long long ldc, int M, int D, int K, void* stream) {
     GemmParams p{};
+    SYN3R_REQUIRE(SYN3R_DIM_OK(D), "gemm_geglu_f16: bad D=%d", D);
     const int tiles = (D + WN - 1) / WN;
     p.A = (const __half*)A; p.lda = lda; p.W = (const __half*)Wpacked; p.out = (__half*)out; p.ldc = ldc;
     p.bias = (const __half*)bias_packed; p.s_acc = 1.0f; p.M = M; p.N = tiles * BN; p.K = K; p.geglu_D = D;
-    SYN3R_REQUIRE(D > 0, "gemm_geglu_f16: bad D=%d", D);
     SYN3R_REQUIRE(ldc >= D && ldc % 8 == 0, "gemm_geglu_f16: ldc=%lld must be >= D and a multiple of 8", ldc);
     long long save = p.ldc;
     p.ldc = ((long long)p.N + 7) / 8 * 8 > p.ldc ? (long long)p.N : p.ldc;   // check_common compares ldc with the packed N
@@ -1910,7 +1910,7 @@ extern "C" int syn3r_gemm_geglu_f16(const void* A, long long lda, const void* Wp
 }
 
 extern "C" size_t syn3r_feedforward_workspace_bytes(int M, int D) {
-    if (M <= 0 || D <= 0) return 0;
+    if (!SYN3R_DIM_OK(M) || !SYN3R_DIM_OK(D)) return 0;
     return (size_t)((M + 127) / 128) * 128 * (size_t)D * sizeof(__half);
 }
 

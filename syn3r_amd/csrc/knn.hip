@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(kThreads) k_knn3(const float4* __restrict__ so
 }  // namespace
 
 extern "C" size_t syn3r_knn3_workspace_bytes(int n) {
-    if (n <= 0) return 0;
+    if (!SYN3R_DIM_OK(n)) return 0;
     const size_t nn = (size_t)n;
     const size_t nbox = (nn + kBox - 1) / kBox;
     return align256(nn * 4) * 4                      // Morton codes / order, ping and pong
@@ -185,7 +185,7 @@ extern "C" size_t syn3r_knn3_workspace_bytes(int n) {
 
 extern "C" int syn3r_knn3_mean_dist2(const float* points, int n, float* out, void* ws, size_t ws_bytes, void* stream_) {
     SYN3R_REQUIRE(points && out && ws, "knn3: null pointer");
-    SYN3R_REQUIRE(n >= 4, "knn3: needs at least 4 points (3 neighbours), got %d", n);
+    SYN3R_REQUIRE(n >= 4 && n <= SYN3R_DIM_MAX, "knn3: needs 4 .. %d points (3 neighbours), got %d", SYN3R_DIM_MAX, n);
     SYN3R_REQUIRE(ws_bytes >= syn3r_knn3_workspace_bytes(n), "knn3: workspace too small (%zu < %zu)", ws_bytes,
                   syn3r_knn3_workspace_bytes(n));
     SYN3R_REQUIRE(((uintptr_t)ws & 255) == 0, "knn3: workspace must be 256-byte aligned");

@@ -242,7 +242,7 @@ void gn_geometry(int samples, int rows, int& chunks, int& rows_per_block) {
 }  // namespace
 
 extern "C" size_t syn3r_groupnorm_workspace_bytes(int samples, int rows) {
-    if (samples <= 0 || rows <= 0) return 0;
+    if (!SYN3R_DIM_OK(samples) || !SYN3R_DIM_OK(rows)) return 0;
     int chunks, rpb;
     gn_geometry(samples, rows, chunks, rpb);
     return (size_t)samples * chunks * 32 * 2 * sizeof(float) + (size_t)samples * 32 * 2 * sizeof(float);
@@ -252,7 +252,7 @@ namespace {
 int groupnorm_launch(const void* x, const void* x2, int C1, void* y, int samples, int rows, int C, const void* gamma,
                      const void* beta, float eps, int silu, void* workspace, size_t workspace_bytes, void* stream_) {
     SYN3R_REQUIRE(x && y && gamma && beta, "groupnorm: null tensor");
-    SYN3R_REQUIRE(samples > 0 && rows > 0 && C > 0 && C % 32 == 0 && C % 8 == 0, "groupnorm: bad sizes samples=%d rows=%d C=%d",
+    SYN3R_REQUIRE(SYN3R_DIM_OK(samples) && SYN3R_DIM_OK(rows) && SYN3R_DIM_OK(C) && C % 32 == 0 && C % 8 == 0, "groupnorm: bad sizes samples=%d rows=%d C=%d",
                   samples, rows, C);
     SYN3R_REQUIRE(x2 ? (C1 > 0 && C1 < C && C1 % 8 == 0) : C1 == C, "groupnorm: bad channel split C1=%d of C=%d", C1, C);
     int threads = gn_threads(C);
@@ -293,7 +293,7 @@ extern "C" int syn3r_groupnorm_f16(const void* x, void* y, int samples, int rows
 extern "C" int syn3r_groupnorm_2src_f16(const void* x1, int C1, const void* x2, int C2, void* y, int samples, int rows,
                                         const void* gamma, const void* beta, float eps, int silu, void* workspace,
                                         size_t workspace_bytes, void* stream_) {
-    SYN3R_REQUIRE(x2 != nullptr && C2 > 0, "groupnorm_2src: second source missing");
+    SYN3R_REQUIRE(x2 != nullptr && SYN3R_DIM_OK(C1) && SYN3R_DIM_OK(C2), "groupnorm_2src: second source missing or bad widths C1=%d C2=%d", C1, C2);
     return groupnorm_launch(x1, x2, C1, y, samples, rows, C1 + C2, gamma, beta, eps, silu, workspace, workspace_bytes, stream_);
 }
 
@@ -420,7 +420,7 @@ extern "C" int syn3r_softmax_rows_f16(const void* x, void* y, long long M, int N
 
 extern "C" int syn3r_time_conv_out(const void* x, long long ldx, const float* w, const float* bias, float* out, int B,
                                    int F, long long HW, void* stream) {
-    SYN3R_REQUIRE(B > 0 && F > 0 && HW > 0 && ldx >= 3, "time_conv_out: bad sizes");
+    SYN3R_REQUIRE(SYN3R_DIM_OK(B) && SYN3R_DIM_OK(F) && HW > 0 && HW <= SYN3R_DIM_MAX && ldx >= 3, "time_conv_out: bad sizes");
     SYN3R_REQUIRE(x && w && bias && out, "time_conv_out: null pointer");
     TimeConvW tw;
     for (int i = 0; i < 27; ++i) tw.w[i] = w[i];     // host pointers: 30 floats travel as kernel arguments

@@ -493,8 +493,8 @@ void raster_fill_camera(Camera& cam, const float* view, const float* proj, const
 }
 }  // namespace syn3r
 
-extern "C" size_t syn3r_raster_geom_bytes(int N) { return N > 0 ? geom_bytes(N) : 0; }
-extern "C" size_t syn3r_raster_image_bytes(int H, int W) { return (H > 0 && W > 0) ? image_bytes(H, W) : 0; }
+extern "C" size_t syn3r_raster_geom_bytes(int N) { return SYN3R_DIM_OK(N) ? geom_bytes(N) : 0; }
+extern "C" size_t syn3r_raster_image_bytes(int H, int W) { return (SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W)) ? image_bytes(H, W) : 0; }
 extern "C" size_t syn3r_raster_binning_bytes(long long P) { return P >= 0 ? binning_bytes(P) : 0; }
 
 extern "C" int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, const float* means3D,
@@ -503,8 +503,9 @@ extern "C" int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, cons
                                        const float* viewmatrix, const float* projmatrix, const float* campos,
                                        float tanfovx, float tanfovy, int H, int W, int* radii, void* geom,
                                        size_t geom_bytes_, long long* num_rendered_host, void* stream_) {
-    SYN3R_REQUIRE(N > 0 && H > 0 && W > 0, "raster_preprocess: bad sizes N=%d H=%d W=%d", N, H, W);
-    SYN3R_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && sh_coeffs >= (sh_degree + 1) * (sh_degree + 1),
+    SYN3R_REQUIRE(SYN3R_DIM_OK(N) && SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W), "raster_preprocess: bad sizes N=%d H=%d W=%d", N, H, W);
+    SYN3R_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "raster_preprocess: sh_degree %d not in 0..3", sh_degree);
+    SYN3R_REQUIRE(sh_coeffs >= (sh_degree + 1) * (sh_degree + 1) && sh_coeffs <= 1024,
                   "raster_preprocess: sh_degree %d needs >= %d coefficients, got %d", sh_degree,
                   (sh_degree + 1) * (sh_degree + 1), sh_coeffs);
     SYN3R_REQUIRE(means3D && scales && rotations && opacities && shs && viewmatrix && projmatrix && campos && radii,

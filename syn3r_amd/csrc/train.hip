@@ -325,7 +325,7 @@ static SsimWindow make_window() {
 }
 
 extern "C" size_t syn3r_photo_loss_workspace_bytes(int C, int H, int W) {
-    if (C <= 0 || H <= 0 || W <= 0) return 0;
+    if (C <= 0 || C > 65535 || !SYN3R_SIDE_OK(H) || !SYN3R_SIDE_OK(W)) return 0;
     const size_t n = (size_t)C * H * W;
     const size_t blocks = (size_t)C * ((H + kTile - 1) / kTile) * ((W + kTile - 1) / kTile);
     return 3 * n * sizeof(float) + ((2 * blocks * sizeof(float) + 255) / 256) * 256;
@@ -334,7 +334,7 @@ extern "C" size_t syn3r_photo_loss_workspace_bytes(int C, int H, int W) {
 extern "C" int syn3r_photo_loss(const float* image, const float* target, int C, int H, int W, float lambda_dssim,
                                 float weight, float* loss3, void* ws, size_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    SYN3R_REQUIRE(C > 0 && C <= 65535 && H > 0 && W > 0, "photo_loss: bad sizes C=%d H=%d W=%d", C, H, W);
+    SYN3R_REQUIRE(C > 0 && C <= 65535 && SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W), "photo_loss: bad sizes C=%d H=%d W=%d", C, H, W);
     SYN3R_REQUIRE(image && target && loss3 && ws, "photo_loss: null pointer");
     SYN3R_REQUIRE(lambda_dssim >= 0.0f && lambda_dssim <= 1.0f, "photo_loss: lambda_dssim must be in [0, 1]");
     SYN3R_REQUIRE(ws_bytes >= syn3r_photo_loss_workspace_bytes(C, H, W), "photo_loss: workspace too small");
@@ -353,7 +353,7 @@ extern "C" int syn3r_photo_loss_backward(const float* image, const float* target
                                          float lambda_dssim, float weight, const float* grad_loss, const void* ws,
                                          float* grad_image, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    SYN3R_REQUIRE(C > 0 && C <= 65535 && H > 0 && W > 0, "photo_loss_backward: bad sizes");
+    SYN3R_REQUIRE(C > 0 && C <= 65535 && SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W), "photo_loss_backward: bad sizes");
     SYN3R_REQUIRE(image && target && ws && grad_image, "photo_loss_backward: null pointer");
     const double n = (double)C * H * W;
     const dim3 grid((W + kTile - 1) / kTile, (H + kTile - 1) / kTile, C);

@@ -473,7 +473,7 @@ __global__ void k_fuse_uncertainty(const float* __restrict__ cond_ori, const flo
 
 }  // namespace
 
-extern "C" size_t syn3r_inverse_warp_workspace_bytes(int nb) { return (size_t)(nb > 0 ? nb : 1) * 16; }
+extern "C" size_t syn3r_inverse_warp_workspace_bytes(int nb) { return (size_t)(SYN3R_SIDE_OK(nb) ? nb : 1) * 16; }
 
 extern "C" int syn3r_inverse_warp(const float* img, const float* depth, const float* depth_pseudo,
                                   const float* pose12, const float* pose21, const float* K, const float* Kinv,
@@ -486,7 +486,7 @@ extern "C" int syn3r_inverse_warp(const float* img, const float* depth, const fl
     SYN3R_REQUIRE(warped_img && warped_depth && mask_warp && mask_depth && mask && warped_masked_img &&
                       mask_inv && mask_depth_strict && mask_reproj && soft_mask_reproj,
                   "inverse_warp: null output");
-    SYN3R_REQUIRE(nb > 0 && H > 0 && W > 0, "inverse_warp: bad shape nb=%d H=%d W=%d", nb, H, W);
+    SYN3R_REQUIRE(SYN3R_SIDE_OK(nb) && SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W), "inverse_warp: bad shape nb=%d H=%d W=%d", nb, H, W);
     SYN3R_REQUIRE((long long)H * W < (1ll << 30), "inverse_warp: image too large");
     if (!workspace || workspace_bytes < syn3r_inverse_warp_workspace_bytes(nb)) {
         set_error("inverse_warp: workspace %zu < %zu", workspace_bytes, syn3r_inverse_warp_workspace_bytes(nb));
@@ -530,7 +530,7 @@ extern "C" int syn3r_reproj_error(const float* depth1, const float* depth2, cons
                                   const float* K1, const float* K1inv, const float* K2, int H, int W, float* err,
                                   void* stream_) {
     SYN3R_REQUIRE(depth1 && depth2 && T12 && T21 && K1 && K1inv && K2 && err, "reproj_error: null argument");
-    SYN3R_REQUIRE(H > 0 && W > 0 && (long long)H * W < (1ll << 30), "reproj_error: bad shape H=%d W=%d", H, W);
+    SYN3R_REQUIRE(SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W), "reproj_error: bad shape H=%d W=%d", H, W);
     RpParams p;
     load4(p.T12, T12); load4(p.T21, T21);
     load3(p.K1, K1); load3(p.K1inv, K1inv); load3(p.K2, K2);
@@ -542,7 +542,7 @@ extern "C" int syn3r_reproj_error(const float* depth1, const float* depth2, cons
 }
 
 extern "C" size_t syn3r_forward_warp_workspace_bytes(int H, int W) {
-    if (H <= 0 || W <= 0) return 0;
+    if (!SYN3R_SIDE_OK(H) || !SYN3R_SIDE_OK(W)) return 0;
     return 16 + (size_t)(H + 2) * (W + 2) * 4 * sizeof(double);
 }
 
@@ -551,7 +551,7 @@ extern "C" int syn3r_forward_warp(const double* frame1, const uint8_t* mask1, co
                                   uint8_t* warped, uint8_t* mask2, double* flow12, void* workspace,
                                   size_t workspace_bytes, void* stream_) {
     SYN3R_REQUIRE(frame1 && depth1 && T && K1inv && K2 && warped && mask2 && flow12, "forward_warp: null argument");
-    SYN3R_REQUIRE(H > 0 && W > 0 && (long long)(H + 2) * (W + 2) < (1ll << 28), "forward_warp: bad shape H=%d W=%d",
+    SYN3R_REQUIRE(SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W) && (long long)(H + 2) * (W + 2) < (1ll << 28), "forward_warp: bad shape H=%d W=%d",
                   H, W);
     size_t need = syn3r_forward_warp_workspace_bytes(H, W);
     if (!workspace || workspace_bytes < need) {
@@ -580,7 +580,7 @@ extern "C" int syn3r_warp_post(const uint8_t* mask_reproj, const float* warped_i
                                float* soft, float* masks, float* soft_pool, void* stream_) {
     SYN3R_REQUIRE(mask_reproj && warped_img && soft_mask_reproj && ero && cond_image && cond_ori && soft && masks && soft_pool,
                   "warp_post: null argument");
-    SYN3R_REQUIRE(n > 0 && H > 0 && W > 0 && h > 0 && w > 0 && H % h == 0 && W % w == 0,
+    SYN3R_REQUIRE(SYN3R_SIDE_OK(n) && SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W) && h > 0 && w > 0 && H % h == 0 && W % w == 0,
                   "warp_post: bad shape n=%d H=%d W=%d pooled %dx%d", n, H, W, h, w);
     SYN3R_REQUIRE(n <= 65535, "warp_post: too many frames");
     hipStream_t stream = (hipStream_t)stream_;
@@ -597,7 +597,7 @@ extern "C" int syn3r_fuse_uncertainty(const float* cond_ori, const float* gs_ima
                                       int W, int h, int w, float* uncertainty, float* cond_image, float* masks,
                                       void* stream_) {
     SYN3R_REQUIRE(cond_ori && gs_images && soft && uncertainty && cond_image && masks, "fuse_uncertainty: null argument");
-    SYN3R_REQUIRE(n > 0 && H > 0 && W > 0 && h > 0 && w > 0 && H % h == 0 && W % w == 0,
+    SYN3R_REQUIRE(SYN3R_SIDE_OK(n) && SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W) && h > 0 && w > 0 && H % h == 0 && W % w == 0,
                   "fuse_uncertainty: bad shape n=%d H=%d W=%d pooled %dx%d", n, H, W, h, w);
     hipStream_t stream = (hipStream_t)stream_;
     const long long npix = (long long)n * H * W;
