@@ -95,3 +95,24 @@ def test_vae_full_size_properties(gpu):
     y1 = vae.decode(z, num_frames=1).sample                                           # every latent its own 1-frame video
     assert near(y1[:1], vae.decode(z[:1], num_frames=1).sample)
     assert not near(y1, y)                                                            # the temporal layers do mix frames
+
+
+def test_post_and_replace_units_at_f25_full_size(gpu):
+    """The reference's own configuration (F = 25, `batch_llff_train.sh:39` / `batch_dtu_train.sh:42`) at full latent size:
+    one (step, pass) unit of the Post variant (four guidance-tile forwards at 40x72 / 48x72 as one batch, gradient step,
+    CFG forward, Euler step) and of the Replace variant - finite, bit-reproducible (no atomics on either path), the
+    two variants give different updates."""
+    from syn3r_amd.pipeline.svd_step import SvdStepBench
+    b = SvdStepBench(25, gpu, seed=5)
+    y1 = b.step_pass_post()
+    b.i = 0
+    y2 = b.step_pass_post()
+    assert y1.shape == (1, 25, 4, 72, 128) and torch.isfinite(y1).all() and torch.equal(y1, y2)
+    b.i = 0
+    z1 = b.step_pass()
+    b.i = 0
+    z2 = b.step_pass()
+    assert z1.shape == y1.shape and torch.isfinite(z1).all() and torch.equal(z1, z2)
+    # the two variants are different updates (at sigma = 700 most of the difference is below the fp16 spacing of the
+    # latents, so only "somewhere" is asserted)
+    assert float((y1.float() - z1.float()).abs().max()) > 0.0
