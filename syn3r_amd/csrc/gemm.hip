@@ -11,14 +11,19 @@
 // which covers bias, the time-embedding add (resnet.py:352), residual adds, the Sk=1
 // cross-attention broadcast and the AlphaBlender mix (resnet.py:789-802).
 //
-// CDNA4 mapping: BMx160x64 block tile (BM = 128: 256 threads = 4 wavefronts, two blocks per CU; BM = 256: 512 threads),
-// each wavefront 64x80 = 4x5 tiles of v_mfma_f32_16x16x32_f16 (f32 accumulate).  Operands are
-// staged global -> registers -> LDS (XOR-swizzled 16-byte chunks, conflict-free ds_read_b128
-// fragment reads), double-buffered: the loads of k-tile t+1 are issued before the MFMAs of tile t
-// and written to the other LDS buffer after them.  Every UNet channel count (320k) is a multiple
-// of BN = 160.  Output tiles go through LDS so that stores are 16 bytes per lane, row-contiguous.
-// Blocks are dealt to XCDs in contiguous chunks (neighbouring M-tiles share the weight panel,
-// the N-tiles of one M-tile share the activation panel in L2).
+// CDNA4 mapping.  All kernels: v_mfma_f32_16x16x32_f16 (f32 accumulate) with the weight fragment as the A operand, LDS
+// images of XOR-swizzled 16-byte chunks (conflict-free ds_read_b128 fragment reads), output tiles through LDS so that
+// stores are 16 bytes per lane and row-contiguous, blocks dealt to XCDs in contiguous chunks.  Kernel families, chosen
+// per shape by launch_dma (DESIGN.md section 4 has the measurements behind every rule):
+//   k_gemm_widep   persistent 256 x 320 tile (dense contractions whose tiles fill the CUs): LDS-DMA 2-stage ring,
+//                  cross-tile prefetch, scalar addressing, lean epilogue, GEGLU gate in registers, two-source A
+//   k_gemm_wide    the same tile, one tile per block (convolution modes, ragged M / N, forced by syn3r_gemm_set_tile)
+//   k_gemm_w128    128 x 320 tile, two blocks per CU (K <= 320 with N > 640: the level-0 qkv projection)
+//   k_ffn320       FeedForward (GEGLU) for C = 320 in one kernel, hidden activation never leaves the CU
+//   k_gemm_dma     BM x 160 tile, LDS-DMA 3-stage ring (BM = 256, wavefronts 4-7 staggered; every convolution /
+//                  temporal convolution and the K = 320 residual projections) or 2-stage (BM = 128, small grids)
+//   k_gemm         register-staged double-buffered variant of k_gemm_dma, kept for tuning (syn3r_gemm_set_tile)
+//   k_gemm_skinny  M <= 16 rows (time embedding, folded cross-attention context)
 #include "common.h"
 #include <cstdlib>
 #include <algorithm>
