@@ -407,3 +407,35 @@ def test_groupnorm_two_source(samples, rows, C1, C2, silu, gpu):
     got = ops.groupnorm(x1, ga, be, samples, 1e-5, silu, x2=x2)
     exp = ops.groupnorm(torch.cat([x1, x2], 1), ga, be, samples, 1e-5, silu)
     assert got.shape == (samples * rows, C1 + C2) and torch.equal(got, exp)
+
+
+def test_persistent_lds_dma_kernel_many_tiles(gpu):
+    """k_gemm_dmap (persistent 256 x 160 tile): more tiles than CUs, so the DMA issue cursor crosses tile boundaries while
+    the previous tile is still being multiplied and the epilogue stages through ONE ring slot in two passes - dense
+    (ragged M, bias / row vector / residual / aux) and temporal convolution, against fp32 references and, bit for bit,
+    against the one-tile-per-block kernel the same shapes used before."""
+    import os
+    from syn3r_amd.unet import ops
+    from syn3r_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 70000 + 8, 320, 192                        # 274 row tiles x 2 column tiles = 548 tiles, M not a tile multiple
+    x, w, b = rnd(g, M, K, dev=gpu), rnd(g, N, K, scale=K ** -0.5, dev=gpu), rnd(g, N, dev=gpu)
+    res, aux, rv = rnd(g, M, N, dev=gpu), rnd(g, M, N, dev=gpu), rnd(g, 4, N, dev=gpu)
+    rpv = (M + 3) // 4
+    y = x.float() @ w.float().T + b.float()
+    B, F, HW, C = 2, 7, 2560, 64                         # 35840 rows x 320 columns: 280 tiles
+    xt = rnd(g, B * F * HW, C, dev=gpu)
+    wt, bt = rnd(g, 320, 3, C, scale=(3 * C) ** -0.5, dev=gpu), rnd(g, 320, dev=gpu)
+    ref_t = Fn.conv3d(xt.float().view(B, F, HW, C).permute(0, 3, 1, 2)[..., None], wt.float().permute(0, 2, 1)[..., None, None],
+                      bt.float(), padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(-1, 320)
+    try:
+        _lib.check(lib.syn3r_gemm_set_tile(-256), "set_tile")
+        o1 = ops.linear(x, w, b, rowvec=rv, rows_per_vec=rpv, residual=res)
+        close(o1, y + rv.float().repeat_interleave(rpv, 0)[:M] + res.float())
+        o2 = ops.linear(x, w, b, residual=res, aux=aux, s_acc=0.3, s_res=1.0, s_aux=0.7)
+        close(o2, 0.3 * y + res.float() + 0.7 * aux.float())
+        o3 = ops.tconv3(xt, wt, bt, B, F, HW, residual=xt.repeat(1, 5).contiguous(), s_acc=0.5, s_res=1.5)
+        close(o3, 0.5 * ref_t + 1.5 * xt.float().repeat(1, 5))
+    finally:
+        lib.syn3r_gemm_set_tile(0)
