@@ -1073,7 +1073,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_widep(GemmParams p) {
     }
 #endif
 #ifdef SYN3R_TIMING     // tools/wide_timing.py: s_memtime ticks of one block's tile phases + both clocks around the tile loop
-    unsigned long long tph[3] = {0, 0, 0}, tkt[2] = {0, 0}, ntile = 0, t_a = __builtin_amdgcn_s_memtime();
+    unsigned long long tph[3] = {0, 0, 0}, tkt[2] = {0, 0}, tgate = 0, ntile = 0, t_a = __builtin_amdgcn_s_memtime();
     const unsigned long long t_begin = t_a, r_begin = __builtin_amdgcn_s_memrealtime();
 #define PSTAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tph[i] += t_ - t_a; t_a = t_; __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -1193,6 +1193,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm_widep(GemmParams p) {
                         acc[0][i][j][r] = y.x; acc[0][i][j][r + 1] = y.y;       // (launch_widep: s_acc == 1 with a gate)
                     }
             }
+#ifdef SYN3R_TIMING
+            { __builtin_amdgcn_sched_barrier(0); tgate += __builtin_amdgcn_s_memtime() - t_a; __builtin_amdgcn_sched_barrier(0); }
+#endif
             const int go0 = etn * 160 + wn * WN;
             const bool full = gm0 + WM <= p.M && go0 + WN <= p.geglu_D;
             widep_store(p, acc[0], epi, le, wv, gm0, go0, p.geglu_D, nullptr, nullptr, nullptr, full);
@@ -1213,7 +1216,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_widep(GemmParams p) {
         g_wide_timing[wv * 8 + 3] = ntile;
         g_wide_timing[wv * 8 + 4] = __builtin_amdgcn_s_memtime() - t_begin;
         g_wide_timing[wv * 8 + 5] = __builtin_amdgcn_s_memrealtime() - r_begin;
-        g_wide_timing[wv * 8 + 6] = tkt[0]; g_wide_timing[wv * 8 + 7] = tkt[1];
+        g_wide_timing[wv * 8 + 6] = tkt[0]; g_wide_timing[wv * 8 + 7] = tgate ? tgate : tkt[1];     // (gated tiles: the gate's share of the epilogue)
     }
 #endif
 #undef PSTAMP

@@ -54,7 +54,10 @@ def run_persistent(M, N, K, geglu):
         top, loop, epi, nt, mt, rt, k0, k1 = [out[wv * 8 + i] for i in range(8)]
         nt = max(nt, 1)
         nkt = K // 64
-        print(f"           k-tile 0: {k0 / nt:7.0f}  k-tile 1: {k1 / nt:7.0f}  k-tiles 2..: {(loop - k0 - k1) / nt / max(nkt - 2, 1):7.0f} each")
+        if geglu:      # slot 7 carries the gate's share of the epilogue instead of k-tile 1
+            print(f"           k-tile 0: {k0 / nt:7.0f}  gate (barrier + bias + GELU arithmetic): {k1 / nt:7.0f} of the epilogue")
+        else:
+            print(f"           k-tile 0: {k0 / nt:7.0f}  k-tile 1: {k1 / nt:7.0f}  k-tiles 2..: {(loop - k0 - k1) / nt / max(nkt - 2, 1):7.0f} each")
         print(f"  wave {wv}: tiles {nt}  per tile: top {top / nt:8.0f}  k-loop {loop / nt:8.0f}  epilogue {epi / nt:8.0f} ticks;"
               f"  clock {mt / max(rt, 1) * 100:.0f} MHz ({mt} memtime / {rt} realtime ticks)")
 
