@@ -289,6 +289,14 @@ def sub_benchmarks(args, dev, loop_a, loop_b, log):
         log("sub-benchmarks: SVD units done")
     out["raster_full_iteration_per_s"] = round(loop_a.full_iteration_rate(50), 1)
     out["raster_full_iteration_note"] = "render + (0.8 L1 + 0.2 (1-SSIM)) + backward + fused Adam on 5 parameter groups, no host sync"
+    if "svd_render_f25_s" in out:
+        # SURVEY 8d composite: the fern-like schedule 10 k iterations + 2 x (3 svd_render + 10 k iterations), DERIVED from the
+        # two measured rates above (complete trainer iterations; svd_render = 200 units at F = 25), not run end to end
+        it_s = 30000.0 / out["raster_full_iteration_per_s"]
+        out["fern_like_schedule_s"] = {"derived_from": "30000 / raster_full_iteration_per_s + 6 x svd_render_f25_s",
+                                       "raster_30k_iterations": round(it_s, 1),
+                                       "replace": round(it_s + 6 * out["svd_render_f25_s"]["replace"], 1),
+                                       "post": round(it_s + 6 * out["svd_render_f25_s"]["post"], 1)}
     # fused inverse warp + reprojection consistency (W2 + C1) at the reference's 576x1024 working size
     from syn3r_amd.solver_utils.forward_warp import inverse_warp
     H, W = 576, 1024
