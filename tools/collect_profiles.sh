@@ -20,5 +20,8 @@ if [ -f "$OUT/fetch/p_counter_collection.csv" ] && [ -f "$OUT/write/p_counter_co
   python3 "$R/tools/pmc_by_kernel.py" "$OUT/fetch/p_counter_collection.csv" FETCH_SIZE > "$OUT/bench_FETCH_SIZE_by_kernel.csv"
   python3 "$R/tools/pmc_by_kernel.py" "$OUT/write/p_counter_collection.csv" WRITE_SIZE > "$OUT/bench_WRITE_SIZE_by_kernel.csv"
 fi
+# per-shape / per-kernel breakdowns of the same build (developer tools; failures here do not fail the collection)
+( timeout -k 10 200 python3 "$R/tools/unet_breakdown.py" 14 detail 2>/dev/null | grep -v amdgpu.ids > "$OUT/unet_shapes.txt" ) || true
+( timeout -k 10 100 python3 "$R/tools/raster_breakdown.py" 2>/dev/null | grep -v amdgpu.ids > "$OUT/raster_breakdown.txt" ) || true
 rm -rf "$OUT/fetch/p_kernel_trace.csv" "$OUT/write/p_kernel_trace.csv" "$OUT/stats/bench_kernel_trace.csv"
 cat "$OUT/bench.json"
