@@ -36,9 +36,23 @@ class EulerDiscreteSchedulerOutput:
 
 
 class EulerDiscreteScheduler:
-    """Reference: scheduling_euler_discrete.py:137-1559 (live methods only)."""
+    """The scheduler object the SVD pipelines drive (reference: scheduling_euler_discrete.py:137-1559, live methods
+    only).  It serves ONE family of configurations — the one SVD ships: variance-preserving training betas, Karras
+    noise levels, v-prediction with continuous timesteps — and rejects the rest instead of carrying unused branches.
+
+    Host-side schedule, from the formulas (Karras et al. 2022, eq. 5; the SVD model card):
+        beta_k   = lerp(sqrt(beta_start), sqrt(beta_end), k / (T-1))^2          ("scaled_linear", fp32)
+        abar_k   = prod_{j<=k} (1 - beta_j)                                      (fp32 running product)
+        s_k      = sqrt((1 - abar_k) / abar_k)                                   training noise levels
+        sigma_i  = (smax^(1/7) + i/(n-1) * (smin^(1/7) - smax^(1/7)))^7          i = 0..n-1, float64 -> fp32
+        t_i      = ln(sigma_i) / 4                                               what the UNet is conditioned on
+    `smax` / `smin` default to the training levels interpolated at the first / last "leading" step
+    (k = (n-1-i) * (T // n) + steps_offset) when the configuration leaves them open.  The operation order above is what
+    makes `sigmas` bit-identical to tests/golden/sched_sigmas*.npz.
+    """
 
     order = 1
+    _KARRAS_RHO = 7.0
 
     def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02,
                  beta_schedule: str = "linear", trained_betas=None, prediction_type: str = "epsilon",
@@ -46,39 +60,32 @@ class EulerDiscreteScheduler:
                  sigma_min: Optional[float] = None, sigma_max: Optional[float] = None,
                  timestep_spacing: str = "linspace", timestep_type: str = "discrete", steps_offset: int = 0,
                  rescale_betas_zero_snr: bool = False):
-        self.config = SimpleNamespace(
-            num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
-            beta_schedule=beta_schedule, trained_betas=trained_betas, prediction_type=prediction_type,
-            interpolation_type=interpolation_type, use_karras_sigmas=use_karras_sigmas, sigma_min=sigma_min,
-            sigma_max=sigma_max, timestep_spacing=timestep_spacing, timestep_type=timestep_type,
-            steps_offset=steps_offset, rescale_betas_zero_snr=rescale_betas_zero_snr)
-        # :197-214
-        if trained_betas is not None:
-            self.betas = torch.tensor(trained_betas, dtype=torch.float32)
-        elif beta_schedule == "linear":
-            self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
-        elif beta_schedule == "scaled_linear":
-            self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps,
-                                        dtype=torch.float32) ** 2
-        else:
-            raise NotImplementedError(f"{beta_schedule} does is not implemented for {self.__class__}")
-        if rescale_betas_zero_snr:
-            raise NotImplementedError("rescale_betas_zero_snr is not used by SYN3R")
+        given = dict(locals())
+        given.pop("self")
+        self.config = SimpleNamespace(**given)
+        required = dict(beta_schedule="scaled_linear", prediction_type="v_prediction", interpolation_type="linear",
+                        use_karras_sigmas=True, timestep_spacing="leading", timestep_type="continuous",
+                        trained_betas=None, rescale_betas_zero_snr=False)
+        wrong = {k: given[k] for k, v in required.items() if given[k] != v}
+        if wrong:
+            raise NotImplementedError(f"EulerDiscreteScheduler (HIP path) serves the SVD configuration only; got {wrong}, "
+                                      f"needs {({k: required[k] for k in wrong})}")
+        T = int(num_train_timesteps)
+        root_beta = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, T, dtype=torch.float32)
+        self.betas = root_beta ** 2
         self.alphas = 1.0 - self.betas
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
-        sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).flip(0)
-        timesteps = np.linspace(0, num_train_timesteps - 1, num_train_timesteps, dtype=float)[::-1].copy()
-        timesteps = torch.from_numpy(timesteps).to(dtype=torch.float32)
-        self.num_inference_steps = None
-        if timestep_type == "continuous" and prediction_type == "v_prediction":
-            self.timesteps = torch.Tensor([0.25 * sigma.log() for sigma in sigmas])
-        else:
-            self.timesteps = timesteps
-        self.sigmas = torch.cat([sigmas, torch.zeros(1)])
+        self._train_sigmas = ((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5       # ascending, fp32 [T]
+        self.use_karras_sigmas = True
         self.is_scale_input_called = False
-        self.use_karras_sigmas = use_karras_sigmas
-        self._step_index = None
-        self._begin_index = None
+        self.num_inference_steps = None
+        self._step_index = self._begin_index = None
+        # before set_timesteps: the T training levels, largest first, and their conditioning values
+        self._install(self._train_sigmas.flip(0))
+
+    def _install(self, sigmas_desc: torch.Tensor, device=None):
+        self.timesteps = (0.25 * sigmas_desc.log()).to(device=device)
+        self.sigmas = torch.cat([sigmas_desc, torch.zeros(1)])          # host-resident: indexing it never synchronises
 
     @classmethod
     def from_config(cls, config: dict):
@@ -88,11 +95,8 @@ class EulerDiscreteScheduler:
     # ------------------------------------------------------------------ schedule (host)
     @property
     def init_noise_sigma(self):
-        """:248-254"""
-        max_sigma = self.sigmas.max()
-        if self.config.timestep_spacing in ["linspace", "trailing"]:
-            return max_sigma
-        return (max_sigma ** 2 + 1) ** 0.5
+        """Scale of the initial latents for "leading" spacing: sqrt(sigma_max^2 + 1) (:248-254)."""
+        return (self.sigmas.max() ** 2 + 1) ** 0.5
 
     @property
     def step_index(self):
@@ -105,65 +109,29 @@ class EulerDiscreteScheduler:
     def set_begin_index(self, begin_index: int = 0):
         self._begin_index = begin_index
 
-    def set_timesteps(self, num_inference_steps: int, device: Union[str, torch.device] = None):
-        """:310-372"""
+    def _end_levels(self, n: int):
+        """(smax, smin) when the configuration does not fix them: the training levels at the first / last leading step."""
         cfg = self.config
-        self.num_inference_steps = num_inference_steps
-        if cfg.timestep_spacing == "linspace":
-            timesteps = np.linspace(0, cfg.num_train_timesteps - 1, num_inference_steps, dtype=np.float32)[::-1].copy()
-        elif cfg.timestep_spacing == "leading":
-            step_ratio = cfg.num_train_timesteps // self.num_inference_steps
-            timesteps = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.float32)
-            timesteps += cfg.steps_offset
-        elif cfg.timestep_spacing == "trailing":
-            step_ratio = cfg.num_train_timesteps / self.num_inference_steps
-            timesteps = (np.arange(cfg.num_train_timesteps, 0, -step_ratio)).round().copy().astype(np.float32)
-            timesteps -= 1
-        else:
-            raise ValueError(f"{cfg.timestep_spacing} is not supported. Please make sure to choose one of "
-                             "'linspace', 'leading' or 'trailing'.")
-        sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
-        log_sigmas = np.log(sigmas)
-        if cfg.interpolation_type == "linear":
-            sigmas = np.interp(timesteps, np.arange(0, len(sigmas)), sigmas)
-        elif cfg.interpolation_type == "log_linear":
-            sigmas = torch.linspace(np.log(sigmas[-1]), np.log(sigmas[0]), num_inference_steps + 1).exp().numpy()
-        else:
-            raise ValueError(f"{cfg.interpolation_type} is not implemented. Please specify interpolation_type "
-                             "to either 'linear' or 'log_linear'")
-        if cfg.use_karras_sigmas:
-            sigmas = self._convert_to_karras(in_sigmas=sigmas, num_inference_steps=self.num_inference_steps)
-            timesteps = np.array([self._sigma_to_t(sigma, log_sigmas) for sigma in sigmas])
-        sigmas = torch.from_numpy(sigmas).to(dtype=torch.float32)
-        if cfg.timestep_type == "continuous" and cfg.prediction_type == "v_prediction":
-            self.timesteps = torch.Tensor([0.25 * sigma.log() for sigma in sigmas]).to(device=device)
-        else:
-            self.timesteps = torch.from_numpy(timesteps.astype(np.float32)).to(device=device)
-        self.sigmas = torch.cat([sigmas, torch.zeros(1)])  # kept on the CPU, as :372
-        self._step_index = None
-        self._begin_index = None
+        k = (np.arange(n)[::-1] * (cfg.num_train_timesteps // n) + cfg.steps_offset).astype(np.float32)
+        s = self._train_sigmas.numpy()
+        lv = np.interp(k, np.arange(s.shape[0]), s)
+        return float(lv[0]), float(lv[-1])
 
-    def _sigma_to_t(self, sigma, log_sigmas):
-        """:374-396"""
-        log_sigma = np.log(np.maximum(sigma, 1e-10))
-        dists = log_sigma - log_sigmas[:, np.newaxis]
-        low_idx = np.cumsum((dists >= 0), axis=0).argmax(axis=0).clip(max=log_sigmas.shape[0] - 2)
-        high_idx = low_idx + 1
-        low = log_sigmas[low_idx]
-        high = log_sigmas[high_idx]
-        w = np.clip((low - log_sigma) / (low - high), 0, 1)
-        t = (1 - w) * low_idx + w * high_idx
-        return t.reshape(sigma.shape)
-
-    def _convert_to_karras(self, in_sigmas, num_inference_steps):
-        """:399-423 (rho = 7)"""
-        sigma_min = self.config.sigma_min if self.config.sigma_min is not None else in_sigmas[-1].item()
-        sigma_max = self.config.sigma_max if self.config.sigma_max is not None else in_sigmas[0].item()
-        rho = 7.0
-        ramp = np.linspace(0, 1, num_inference_steps)
-        min_inv_rho = sigma_min ** (1 / rho)
-        max_inv_rho = sigma_max ** (1 / rho)
-        return (max_inv_rho + ramp * (min_inv_rho - max_inv_rho)) ** rho
+    def set_timesteps(self, num_inference_steps: int, device: Union[str, torch.device] = None):
+        """`n` Karras noise levels + the terminal zero, and t = ln(sigma)/4 (reference :310-372 for this configuration)."""
+        n = int(num_inference_steps)
+        cfg = self.config
+        smax, smin = cfg.sigma_max, cfg.sigma_min
+        if smax is None or smin is None:
+            hi, lo = self._end_levels(n)
+            smax = hi if smax is None else smax
+            smin = lo if smin is None else smin
+        inv = 1.0 / self._KARRAS_RHO
+        a, b = smax ** inv, smin ** inv
+        levels = (a + np.linspace(0, 1, n) * (b - a)) ** self._KARRAS_RHO      # float64
+        self.num_inference_steps = n
+        self._install(torch.from_numpy(levels).to(torch.float32), device)
+        self._step_index = self._begin_index = None
 
     def scale_model_input(self, sample: torch.Tensor, timestep, step_i) -> torch.Tensor:
         """:281-308 — `step_i` overrides the internal index (:300)."""
