@@ -381,14 +381,14 @@ def main():
         for _ in range(traced):
             step()
         from syn3r_amd import raster as _r
-        _r.flush_pair_checks()                     # every render's pair list was complete (raises otherwise)
+        truncated = _r.flush_pair_checks()         # every render's pair list was complete (raises otherwise)
         barrier()
         dt = time.perf_counter() - t0
     log(f"timed region done: {dt:.3f} s")
-    # ONE collective at the end (north_star): the fixed 8-field per-scene record of syn3r_amd/dist.py; the job's time is
+    # ONE collective at the end (north_star): the fixed per-scene record of syn3r_amd/dist.py; the job's time is
     # the MAX of the ranks' wall-clocks, read from the gathered records
     psnr, ssim = loop_a.metrics()
-    rec = [float(rank), psnr, ssim, float("nan"), args.raster_iters * args.steps / dt, (args.steps / dt) if loop_b else 0.0, dt, 1.0]
+    rec = [float(rank), psnr, ssim, float("nan"), args.raster_iters * args.steps / dt, (args.steps / dt) if loop_b else 0.0, dt, float(truncated), 1.0]
     allrec = D.gather_records(rec)
     dt_max = float(allrec[:, D.RECORD_FIELDS.index("wall_s")].max())
 

@@ -166,20 +166,24 @@ class DiffusionGS:
         return self._frames_to_gs(frames, image_o, image_o2, replace), interpolated_poses, pseudo_images
 
     def _frames_to_gs(self, frames, image_o, image_o2, replace):
-        """diffusionGS.py:909-916: end frames replaced by the input views, every frame resized to the GS resolution as
-        the reference's `PIL.Image.resize` does on uint8 frames (bicubic, with the area-scaled support PIL uses when
-        shrinking = `antialias=True`), CHW in [0,1]."""
+        """diffusionGS.py:909-916: end frames replaced by the input views, every frame resized to the GS resolution, CHW
+        in [0,1].  The reference does this step ON PIL IMAGES (the pipeline returns PIL frames; `fr.resize((W, H))` =
+        PIL's default bicubic filter, two uint8 passes with clipping in between) — so it is done with PIL here too:
+        25 small host images per view pair, bit-identical to the reference (tests/test_orchestrator.py)."""
+        import PIL.Image
+        n = len(frames)
         if replace:
             frames[0], frames[-1] = image_o, image_o2
         out = []
-        for fr in frames:
-            u8 = np.clip(np.asarray(fr, dtype=np.float32) * 255.0, 0, 255).astype(np.uint8)      # PIL frames are uint8
-            t = torch.from_numpy(u8).permute(2, 0, 1)[None].float()
-            if t.shape[-2:] != (self.gs_height, self.gs_width):
-                t = torch.nn.functional.interpolate(t, size=(self.gs_height, self.gs_width), mode="bicubic",
-                                                    align_corners=False, antialias=True)
-                t = t.round().clamp(0, 255)                                                         # PIL rounds back to uint8
-            out.append(t[0] / 255.0)
+        for k, fr in enumerate(frames):
+            v = np.clip(np.asarray(fr) * 255.0, 0, 255)              # in the frame's own dtype, as the reference
+            # diffused frames reach the reference as PIL images made by `(f * 255).round()` (tensor2vid / numpy_to_pil);
+            # only the two replaced end frames are truncated, `(image_o * 255).astype(np.uint8)` (diffusionGS.py:909-911)
+            u8 = v.astype(np.uint8) if (replace and k in (0, n - 1)) else np.rint(v).astype(np.uint8)
+            im = PIL.Image.fromarray(u8)
+            if (im.height, im.width) != (self.gs_height, self.gs_width):
+                im = im.resize((self.gs_width, self.gs_height))
+            out.append(torch.from_numpy(np.array(im)).permute(2, 0, 1) / 255.0)
         return out
 
     def _finish_forward_warp(self, interpolated_poses, image1, image2, depth1, depth2, pseudo_images, replace):

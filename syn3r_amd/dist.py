@@ -12,7 +12,9 @@ from typing import List, Sequence
 import torch
 import torch.distributed as dist
 
-RECORD_FIELDS = ("scene_id", "psnr", "ssim", "lpips", "raster_iters_per_s", "svd_units_per_s", "wall_s", "ok")
+# `truncated_renders`: training renders whose (Gaussian, tile) list outgrew the async binning capacity (must be 0)
+RECORD_FIELDS = ("scene_id", "psnr", "ssim", "lpips", "raster_iters_per_s", "svd_units_per_s", "wall_s",
+                 "truncated_renders", "ok")
 
 
 def init(backend: str | None = None) -> tuple[int, int, int]:

@@ -302,8 +302,11 @@ class GSTrainer:
 
     def load_checkpoint(self, checkpoint: str):
         """diffusionGS.py:1618,1624 — restore the Gaussians from a checkpoint file; optimiser state starts afresh
-        (the orchestrator calls reset_optimizers right after, :1634)."""
-        state, it = torch.load(checkpoint, map_location=self.gaussians._xyz.device, weights_only=False)
+        (the orchestrator calls reset_optimizers right after, :1634).  The file is THIS repository's format — a
+        `(dict of tensors / ints, iteration)` pair written by `save_checkpoint` under the reference's file names — and
+        is read with the tensors-only loader (`weights_only=True`: no pickled code is executed).  FSGS' own
+        `chkpnt*.pth` (a tuple of optimiser and model objects) is a different format and is rejected by that loader."""
+        state, it = torch.load(checkpoint, map_location=self.gaussians._xyz.device, weights_only=True)
         self.gaussians.restore(state)
         self.iteration = int(it)
         self.reset_optimizers()
@@ -520,11 +523,18 @@ class GSTrainer:
         self.iteration += 1
         return loss.detach()
 
+    def _capacity_keys(self):
+        g = self.gaussians
+        dev, n = g._xyz.device, g._xyz.shape[0]
+        shapes = {(int(c.image_height), int(c.image_width)) for c in self.scene.train_cameras[1.0]}
+        from .. import raster
+        return [raster.capacity_key(dev, n, h, w) for h, w in shapes]
+
     def _loop(self, first_iter: int, n: int) -> float:
         from .. import raster
         prev = raster.get_pair_count_mode()
         # async mode sizes the binning buffer from earlier renders of the same (N, H, W): one exact (sync) render per
-        # camera first, so the capacity covers the view with the most (Gaussian, tile) pairs with 1.5x headroom
+        # camera first, so the capacity covers the view with the most (Gaussian, tile) pairs with 2x headroom
         raster.set_pair_count_mode("sync")
         if n > first_iter:
             with torch.no_grad():
@@ -533,20 +543,32 @@ class GSTrainer:
         raster.set_pair_count_mode("async")          # no host round trip per render inside the loop
         self.iteration = first_iter                  # the density-control schedule counts from the start of this loop
         last = None
+
+        def late_overflow(e):                        # an EARLIER render outgrew its pair capacity (reported late, see raster)
+            if "async pair-count" not in str(e):
+                raise e
+            self.truncated_renders += int(getattr(e, "truncated", 1))
+
         try:
             for _ in range(first_iter, n):
+                keys0 = self._capacity_keys() if self.densify else None
                 try:
                     last = self.train_step()
-                except L.Syn3rError as e:            # an EARLIER render outgrew its pair capacity (reported late, see raster):
-                    if "async pair-count" not in str(e):
-                        raise
-                    self.truncated_renders += 1      # that one step saw a truncated image; capacity has been raised - go on
+                except L.Syn3rError as e:            # the truncated image's step has already been applied: counted, reported
+                    late_overflow(e)                 # in the scene record (`truncated_renders`), capacity has been raised
+                if keys0 is not None:
+                    keys1 = self._capacity_keys()
+                    if keys1 != keys0:               # densification changed N: every (N, H, W) key is new.  Check what
+                        try:                         # the old shapes still owe, then seed the new capacity from the old
+                            raster.flush_pair_checks()           # one scaled by N_new / N_old (max over cameras is kept)
+                        except L.Syn3rError as e:
+                            late_overflow(e)
+                        for k0, k1 in zip(keys0, keys1):
+                            raster.carry_capacity(k0, k1, k1[1] / max(k0[1], 1))
             try:
                 raster.flush_pair_checks()           # every remaining render's pair list was complete
             except L.Syn3rError as e:
-                if "async pair-count" not in str(e):
-                    raise
-                self.truncated_renders += 1
+                late_overflow(e)
         finally:
             raster.set_pair_count_mode(prev)
         return float(last) if last is not None else 0.0     # ONE synchronisation, at the end of the loop

@@ -145,7 +145,11 @@ def run_scene(name: str, args, device, factory: Callable) -> List[float]:
     ev = trainer.evaluate(sc.get("test_cameras"))
     iters = trainer.iteration - it0
     units = 2.0 * args.num_inference_steps * args.refine_cycle_num * max(sc["num_input_views"] - (args.densify_type == "interpolate_loop0_gs"), 0)
-    return [0.0, ev["psnr"], ev["ssim"], ev["lpips"], iters / wall, units / wall, wall, 1.0]
+    if trainer.truncated_renders:
+        print(f"[syn3r] scene {name}: {trainer.truncated_renders} training render(s) ran with a truncated pair list",
+              file=sys.stderr, flush=True)
+    return [0.0, ev["psnr"], ev["ssim"], ev["lpips"], iters / wall, units / wall, wall,
+            float(trainer.truncated_renders), 1.0]
 
 
 def main(argv: Optional[Sequence[str]] = None) -> int:

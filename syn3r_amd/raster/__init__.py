@@ -78,10 +78,12 @@ def get_pair_count_mode() -> str:
     return _pair_mode
 
 
-def _check_pending(key, wait: bool):
-    """Examine finished renders of this shape (all of them if `wait`), oldest first; never blocks the host
-    unless asked to or more than 8 renders are unchecked."""
+def _check_pending(key, wait: bool) -> int:
+    """Examine finished renders of this shape (all of them if `wait`), oldest first; never blocks the host unless
+    asked to or more than 8 renders are unchecked.  Returns how many of the examined renders had outgrown their binning
+    buffer (their images were built from a truncated pair list); the capacity of the shape is raised on the way."""
     queue = _pending.get(key)
+    truncated = 0
     while queue:
         evt, host, cap = queue[0]
         if not (wait or len(queue) > 8 or evt.query()):
@@ -91,15 +93,42 @@ def _check_pending(key, wait: bool):
         P, overflow = int(host[0]), int(host[1])
         _capacity[key] = max(_capacity.get(key, 0), int(P * _HEADROOM) + 4096)
         if overflow or P > cap:
-            queue.clear()
-            raise L.Syn3rError(f"rasteriser (async pair-count mode): a previous render needed {P} pairs but the binning "
-                               f"buffer held {cap}; that image is invalid — capacity has been raised, render again")
+            truncated += 1
+    if queue is not None and not queue:
+        del _pending[key]
+    return truncated
 
 
-def flush_pair_checks() -> None:
-    """Verify the overflow flag of every render still unchecked (call at the end of a training loop)."""
+def _overflow_error(n: int) -> "L.Syn3rError":
+    return L.Syn3rError(f"rasteriser (async pair-count mode): {n} previous render(s) needed more (Gaussian, tile) pairs than "
+                        "the binning buffer held; those images are invalid - capacity has been raised, render again")
+
+
+def flush_pair_checks() -> int:
+    """Verify the overflow flag of EVERY render still unchecked, for every shape (call at the end of a training loop).
+    All queues are drained before anything is raised; the error carries the total in `.truncated`."""
+    total = 0
     for key in list(_pending):
-        _check_pending(key, wait=True)
+        total += _check_pending(key, wait=True)
+    if total:
+        err = _overflow_error(total)
+        err.truncated = total
+        raise err
+    return 0
+
+
+def carry_capacity(old_key, new_key, scale: float) -> None:
+    """A change of the Gaussian count (densification) changes the capacity key (device, N, H, W).  Start the new shape
+    from the old one's capacity scaled by N_new / N_old instead of from the next single view's count, and forget the
+    old key (its renders have been checked by then: call after `flush_pair_checks`)."""
+    cap = _capacity.pop(old_key, None)
+    _pending.pop(old_key, None)
+    if cap is not None:
+        _capacity[new_key] = max(_capacity.get(new_key, 0), int(cap * max(scale, 1.0)) + 4096)
+
+
+def capacity_key(dev: torch.device, N: int, H: int, W: int):
+    return (dev.index, int(N), int(H), int(W))
 
 
 class _Rasterize(torch.autograd.Function):
@@ -131,7 +160,11 @@ class _Rasterize(torch.autograd.Function):
         key = (dev.index, N, H, W)
         use_async = _pair_mode == "async" and not s.debug
         if use_async:
-            _check_pending(key, wait=False)
+            n_trunc = _check_pending(key, wait=False)
+            if n_trunc:
+                err = _overflow_error(n_trunc)
+                err.truncated = n_trunc
+                raise err
         use_async = use_async and key in _capacity
         P = C.c_longlong(0)
         rc = lib.syn3r_raster_preprocess(N, int(s.sh_degree), M, L.ptr(m3), L.ptr(sc), L.ptr(ro), L.ptr(op), L.ptr(sh),

@@ -325,7 +325,10 @@ class UNetSpatioTemporalConditionModel:
     def _context_cache(self, ehs: torch.Tensor, shared: bool) -> dict:
         """Per-context store of the folded cross-attention vectors.  Keyed on the storage the caller's tensor views
         (address, offset, shape, strides, in-place version); the entry holds the tensor, so the address cannot be handed
-        to other data while the entry lives.  A handful of contexts (start / end image, their guidance-tile views)."""
+        to other data while the entry lives.  A handful of contexts (start / end image, their guidance-tile views).
+        INVARIANT: `_version` only sees writes made through torch.  A context buffer refilled by a raw-pointer kernel
+        (this library's own operators write through `data_ptr()`) keeps its version: call `invalidate_context_cache()`
+        after such a write.  The pipelines build their contexts with torch ops, once per `__call__`."""
         key = (ehs.untyped_storage().data_ptr(), ehs.storage_offset(), tuple(ehs.shape), tuple(ehs.stride()), ehs._version, shared)
         store = self.__dict__.setdefault("_ctx_store", {})
         ent = store.get(key)
@@ -334,6 +337,10 @@ class UNetSpatioTemporalConditionModel:
                 store.pop(next(iter(store)))
             ent = store[key] = (ehs, {})
         return ent[1]
+
+    def invalidate_context_cache(self) -> None:
+        """Forget every folded cross-attention vector (see `_context_cache`)."""
+        self.__dict__.setdefault("_ctx_store", {}).clear()
 
     def w(self, name: str) -> torch.Tensor:
         return self.packed.get(name, self.p.t.get(name))

@@ -18,12 +18,12 @@ WORKER = textwrap.dedent("""
     mine = D.assign_scenes(scenes, rank, world)
     assert mine == scenes[rank::world]
     ok = 1.0 if rank == 0 else 0.0
-    rec = [float(rank), 20.0 + rank if ok else math.nan, 0.7, 0.2, 400.0 + rank, 5.0, 12.0, ok]
+    rec = [float(rank), 20.0 + rank if ok else math.nan, 0.7, 0.2, 400.0 + rank, 5.0, 12.0, 0.0, ok]
     allrec = D.gather_records(rec)
     assert allrec.shape == (world, len(D.RECORD_FIELDS))
     assert allrec[:, 0].tolist() == [float(r) for r in range(world)]
     assert torch.isnan(allrec[1, 1]) and allrec[0, 1] == 20.0
-    tab = D.gather_record_table([rec, [math.nan] * 7 + [0.0]])
+    tab = D.gather_record_table([rec, [math.nan] * (len(D.RECORD_FIELDS) - 1) + [0.0]])
     assert tab.shape == (2 * world, len(D.RECORD_FIELDS)) and tab[2 * rank, 0] == float(rank) and tab[2 * rank + 1, -1] == 0.0
     if rank == 0:
         table = D.summary_table(allrec)
@@ -56,8 +56,8 @@ def test_world2_gloo_gather(tmp_path):
 
 def test_single_process_gather():
     from syn3r_amd import dist as D
-    rec = D.gather_records([0, 30.0, 0.9, 0.1, 100.0, 5.0, 1.0, 1.0], device=__import__("torch").device("cpu"))
-    assert rec.shape == (1, 8)
+    rec = D.gather_records([0, 30.0, 0.9, 0.1, 100.0, 5.0, 1.0, 0.0, 1.0], device=__import__("torch").device("cpu"))
+    assert rec.shape == (1, len(D.RECORD_FIELDS)) and D.RECORD_FIELDS[-2:] == ("truncated_renders", "ok")
     assert D.assign_scenes(list("abcdefghij"), 1, 8) == ["b", "j"]
 
 

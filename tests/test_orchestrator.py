@@ -108,3 +108,23 @@ def test_knn_oracle_bruteforce_agrees_with_kdtree():
     p[:50] = p[50:100]
     a, b = KO.mean_dist2_bruteforce(p), KO.mean_dist2_kdtree(p)
     assert np.allclose(a, b, rtol=2e-5, atol=1e-9)
+
+
+def test_frames_to_gs_matches_pil():
+    """diffusionGS.py:909-916 done with PIL itself: interior frames are ROUNDED to uint8 (tensor2vid / numpy_to_pil), the
+    two replaced end frames are truncated, all are resized by PIL's default (bicubic) filter."""
+    import PIL.Image
+    from types import SimpleNamespace
+    from syn3r_amd.diffusionGS import DiffusionGS
+    rng = np.random.default_rng(3)
+    frames = [rng.random((48, 64, 3), dtype=np.float32) for _ in range(4)]
+    image_o, image_o2 = rng.random((48, 64, 3)), rng.random((48, 64, 3))
+    for gh, gw in ((48, 64), (30, 40)):
+        me = SimpleNamespace(gs_height=gh, gs_width=gw)
+        got = DiffusionGS._frames_to_gs(me, list(frames), image_o, image_o2, True)
+        pil = [PIL.Image.fromarray((f * 255).round().astype("uint8")) for f in frames]
+        pil[0] = PIL.Image.fromarray((image_o * 255).astype(np.uint8))
+        pil[-1] = PIL.Image.fromarray((image_o2 * 255).astype(np.uint8))
+        ref = [torch.from_numpy(np.asarray(fr.resize((gw, gh)))).permute([2, 0, 1]) / 255. for fr in pil]
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
