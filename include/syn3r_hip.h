@@ -459,6 +459,24 @@ int syn3r_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 size_t syn3r_knn3_workspace_bytes(int n);
 int syn3r_knn3_mean_dist2(const float* points, int n, float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* Statistical outlier removal of a point cloud: what model/diffusionGS.py:321 asks of open3d
+ * (`down_pcd.remove_statistical_outlier(nb_neighbors=20, std_ratio=3.0)`; open3d 0.17.0 is not in the reference tree, the
+ * published algorithm is restated in csrc/knn.hip).  points [n,3] float64 (open3d holds doubles).  Outputs, all device
+ * memory: avg_dist [n] float64 = mean distance to the nb_neighbors nearest points (the point itself included, as the k-d
+ * tree query returns it); keep [n] bytes = 0 < avg < mean + std_ratio * std; stats [4] = {mean, std (n-1), threshold,
+ * valid count}.  nb_neighbors must be 20 (the reference's call).  ws: syn3r_pcd_outlier_workspace_bytes(n), 256-byte aligned. */
+size_t syn3r_pcd_outlier_workspace_bytes(int n);
+int syn3r_pcd_statistical_outlier(const double* points, int n, int nb_neighbors, double std_ratio, double* avg_dist,
+                                  unsigned char* keep, double* stats, void* ws, size_t ws_bytes, void* stream);
+
+/* Forward / backward optical-flow cycle-consistency mask: the test behind
+ * `gsTrainer.generate_corresp_mask(gs_renderings, svd_outputs, dist_thresh=3, desc_only=False)` (model/diffusionGS.py:377;
+ * the FSGS wrapper and GMFlow are absent, see csrc/warp.hip).  flow_fw / flow_bw [n,2,H,W] fp32 (A->B and B->A, channel 0 =
+ * dx); mask [n,H,W] fp32 in {0,1}: |fw(x) + bw(x + fw(x))| < thresh and x + fw(x) inside the image; dist (nullable)
+ * [n,H,W] = that cycle error (+inf outside). */
+int syn3r_flow_cycle_mask(const float* flow_fw, const float* flow_bw, int n, int H, int W, float thresh, float* mask, float* dist,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

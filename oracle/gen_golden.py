@@ -456,14 +456,7 @@ def gen_orchestrator():
     """Pure-numpy methods of the reference's DiffusionGS (model/diffusionGS.py:1120-1296).  The module
     imports packages that are absent here (FSGS submodule, cv2, open3d, trimesh); they are not touched by
     these methods, so empty placeholder modules satisfy the import statements."""
-    import types
-    for name in ("cv2", "trimesh", "open3d", "FSGS", "FSGS.utils", "FSGS.utils.trainer", "FSGS.scene", "FSGS.scene.cameras"):
-        if name not in sys.modules:
-            sys.modules[name] = types.ModuleType(name)
-    sys.modules["FSGS.utils.trainer"].init_GSTrainer = None
-    sys.modules["FSGS.utils.trainer"].GSTrainer = object
-    sys.modules["FSGS.scene.cameras"].Camera = object
-    from model.diffusionGS import DiffusionGS
+    DiffusionGS = _reference_diffusiongs()
     out = {}
     for k, (a, b) in enumerate(GI.orch_pose_pairs()):
         poses = DiffusionGS.pose_interpolation(None, a, b)
@@ -483,10 +476,105 @@ def gen_orchestrator():
     print("orchestrator", {k: getattr(v, "shape", ()) for k, v in out.items()})
 
 
+def _reference_diffusiongs():
+    """The reference's DiffusionGS class; the absent packages its module imports get empty placeholder modules (the
+    methods called here never touch them, except the name `trimesh.Scene` that densify_views instantiates and drops)."""
+    import types
+    for name in ("cv2", "trimesh", "open3d", "FSGS", "FSGS.utils", "FSGS.utils.trainer", "FSGS.scene", "FSGS.scene.cameras"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["FSGS.utils.trainer"].init_GSTrainer = None
+    sys.modules["FSGS.utils.trainer"].GSTrainer = object
+    sys.modules["FSGS.scene.cameras"].Camera = object
+    sys.modules["trimesh"].Scene = object
+    from model.diffusionGS import DiffusionGS
+    return DiffusionGS
+
+
+class _Captured(Exception):
+    pass
+
+
+def gen_n2():
+    """Key-frame bookkeeping of the point-cloud densification (model/diffusionGS.py:179-308) and the frame filter /
+    pair graph / intrinsics of `densify_pcds` (:347-435), captured from the REFERENCE's own methods run on a stand-in
+    `self`: `_interpolate_between_gs_v3`, `render_GS`, `gsTrainer.generate_corresp_mask` and `dust3r` are recorders fed
+    with seeded data (the networks are absent); everything between them is the reference's code."""
+    import tempfile
+    import types
+    DiffusionGS = _reference_diffusiongs()
+    out = {}
+    for name, (V, dtype, fps, nkey) in GI.N2_CASES.items():
+        vposes = GI.n2_view_poses(V)
+        cap = {}
+
+        def interp(i, j, replace=True, perturb_interp_poses=False):
+            poses = list(DiffusionGS.pose_interpolation(None, vposes[i], vposes[j]))
+            frames = [torch.full((3, 4, 6), GI.n2_frame_id(i, k), dtype=torch.float32) for k in range(25)]
+            return frames, poses, None
+
+        def densify_pcds(frames, poses, key_frame_mask=None, input_flags=None, win_samples=-1):
+            cap.update(frames=np.array([float(f[0, 0, 0]) for f in frames], np.float32), poses=np.array(poses),
+                       key_frame_mask=np.array(key_frame_mask), input_flags=np.array(input_flags), win_samples=win_samples)
+            raise _Captured
+
+        with tempfile.TemporaryDirectory() as tmp:
+            me = types.SimpleNamespace(num_input_views=V, save_dir=tmp, fps_keyframe_sampling=fps,
+                                       _interpolate_between_gs_v3=interp, densify_pcds=densify_pcds)
+            try:
+                DiffusionGS.densify_views(me, 0, down_sample_rate=1, densify_type=dtype, num_views_for_pcd_densification=nkey)
+            except _Captured:
+                pass
+        for k in ("frames", "poses", "key_frame_mask", "input_flags"):
+            out[f"{name}_sel_{k}"] = cap[k]
+
+        # ---- densify_pcds itself on what densify_views handed over
+        n = len(cap["frames"])
+        means = GI.n2_mask_means(n)
+        rec = {}
+        calls = []
+
+        def render_GS(idx=None, pose=None, return_alpha=False):
+            calls.append(np.array(pose))
+            return pose, np.zeros((3, 4, 6), np.float32), np.ones((4, 6), np.float32), np.ones((4, 6), np.float32)
+
+        def corresp(gs_renderings, svd_outputs, dist_thresh, desc_only):
+            i = len(calls) - 1
+            assert dist_thresh == 3 and desc_only is False
+            return [[torch.full((4, 6), float(means[i]))]], None
+
+        class Dust3r:
+            def to(self, dev):
+                rec.setdefault("to", []).append(dev)
+
+            def make_pairs(self, imgs, scene_graph, global_image_inds):
+                rec.update(pair_frames=np.array([float(f[0, 0, 0]) / 255.0 for f in imgs], np.float32), scene_graph=scene_graph,
+                           pair_inds=np.array(global_image_inds, np.int64))
+                return "pairs"
+
+            def run(self, frames, c2w_poses, intrinsics, preset_pairs):
+                assert preset_pairs == "pairs"
+                rec.update(run_frames=np.array([float(f[0, 0, 0]) / 255.0 for f in frames], np.float32),
+                           c2w=np.array(c2w_poses), K=np.array(intrinsics))
+                return None, "trimesh_scene"
+
+        K = np.array([[500.0, 0, 320.0], [0, 510.0, 240.0], [0, 0, 1]], np.float32)
+        me = types.SimpleNamespace(render_GS=render_GS, gsTrainer=types.SimpleNamespace(generate_corresp_mask=corresp),
+                                   dust3r=Dust3r(), gs_intrinsics=K, gs_width=640)
+        frames = [torch.full((3, 4, 6), float(v)) for v in cap["frames"]]
+        res = DiffusionGS.densify_pcds(me, frames, list(cap["poses"]), key_frame_mask=list(cap["key_frame_mask"]),
+                                       input_flags=list(cap["input_flags"]), win_samples=-1)
+        assert res == "trimesh_scene" and rec["scene_graph"] == "complete" and rec["to"] == ["cuda", "cpu"]
+        for k in ("pair_frames", "pair_inds", "run_frames", "c2w", "K"):
+            out[f"{name}_pcd_{k}"] = rec[k]
+    np.savez_compressed(GOLD / "n2_bookkeeping.npz", **out)
+    print("n2", {k: getattr(v, "shape", ()) for k, v in out.items()})
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     Sch, consistency, forward_warp, inverse_warp = _import_reference()
-    which = sys.argv[1:] or ["warp", "sched", "unet", "vae", "pipeline", "orch"]
+    which = sys.argv[1:] or ["warp", "sched", "unet", "vae", "pipeline", "orch", "n2"]
     if "pipeline" in which:
         gen_pipeline()
     if "pipeline_one_pass" in which:
@@ -497,6 +585,8 @@ def main():
         gen_pipeline_real_unet_vae()
     if "orch" in which:
         gen_orchestrator()
+    if "n2" in which:
+        gen_n2()
     if "unet" in which:
         gen_unet()
     if "unet_full" in which:              # ~30 min of CPU, 1.52 B parameters: not part of the default set

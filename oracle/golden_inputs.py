@@ -129,3 +129,36 @@ def orch_masks():
     hi = (0.5 + 0.5 * rng.random((23, 72, 128))).astype(f32)
     ramp = (rng.random((23, 72, 128)) * np.sin(np.linspace(0.1, np.pi - 0.1, 23))[:, None, None]).astype(f32)
     return [lo, hi, ramp]
+
+
+def n2_view_poses(V, seed=0):
+    """V input-view w2c poses on a gently curving, unevenly spaced path (key-frame selection has something to choose)."""
+    rng = np.random.default_rng(100 + seed)
+    out = []
+    x = 0.0
+    for v in range(V):
+        x += 0.25 + 0.2 * rng.random()
+        p = _rot_y(6.0 * v + 3.0 * rng.standard_normal()) @ _rot_x(2.0 * rng.standard_normal()) @ np.eye(4)
+        p[:3, 3] = [x, 0.05 * rng.standard_normal(), 0.1 * np.sin(0.7 * v)]
+        out.append(p.astype(np.float32))
+    return out
+
+
+def n2_frame_id(view, k):
+    """Marker value of the mock diffused frame k of view pair `view` (frames are [3,4,6] constants)."""
+    return (view * 100 + k) / 4096.0
+
+
+N2_CASES = {
+    # name: (V input views, densify_type, fps_keyframe_sampling, num_views_for_pcd_densification)
+    "v3_fps4": (3, "interpolate_gs_v2", 1, 4),
+    "v3_lin4": (3, "interpolate_gs_v2", 0, 4),
+    "v9_fps4": (9, "interpolate_gs_v2", 1, 4),
+    "v4_loop0_fps3": (4, "interpolate_loop0_gs", 1, 3),
+    "v9_loop0_lin5": (9, "interpolate_loop0_gs", 0, 5),
+}
+
+
+def n2_mask_means(n, seed=0):
+    """Mean of the mock correspondence mask per candidate frame (the keep rule thresholds it at 0.3, diffusionGS.py:385)."""
+    return np.random.default_rng(200 + seed).random(n).astype(np.float32)

@@ -22,6 +22,7 @@ c_i = C.c_int
 c_p = C.c_void_p
 c_sz = C.c_size_t
 c_ll = C.c_longlong
+c_d = C.c_double
 
 F32, F16 = 0, 1
 
@@ -93,6 +94,9 @@ SIGNATURES = {
     "syn3r_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_i, c_p]),
     "syn3r_knn3_workspace_bytes": (c_sz, [c_i]),
     "syn3r_knn3_mean_dist2": (c_i, [c_p, c_i, c_p, c_p, c_sz, c_p]),
+    "syn3r_pcd_outlier_workspace_bytes": (c_sz, [c_i]),
+    "syn3r_pcd_statistical_outlier": (c_i, [c_p, c_i, c_i, c_d, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "syn3r_flow_cycle_mask": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
 }
 
 

@@ -471,6 +471,39 @@ __global__ void k_fuse_uncertainty(const float* __restrict__ cond_ori, const flo
     cond[i * 3 + 2] = fminf(fmaxf(c2, 0.f), 1.f);
 }
 
+// Forward / backward optical-flow consistency mask: the test behind the reference's
+// `gsTrainer.generate_corresp_mask(gs_renderings, svd_outputs, dist_thresh=3, desc_only=False)` (model/diffusionGS.py:377).
+// FSGS' wrapper and GMFlow are absent from /root/reference; the quantity is the published cycle check of a flow pair
+// (GMFlow `forward_backward_consistency_check`, with the fixed pixel threshold the call site passes): a pixel x of image A is
+// a correspondence when following the A->B flow and then the B->A flow SAMPLED at the landing point (bilinear, pixel
+// coordinates) returns to within `thresh` pixels of x, and the landing point lies inside the image.
+// flows [n,2,H,W] (channel 0 = dx, 1 = dy).  mask [n,H,W] in {0,1}; dist [n,H,W] (optional) = the cycle error, +inf outside.
+__global__ void __launch_bounds__(256) k_flow_cycle_mask(const float* __restrict__ fw, const float* __restrict__ bw, int H, int W,
+                                                        long long npix, float thresh, float* __restrict__ mask,
+                                                        float* __restrict__ dist) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const int hw = H * W;
+    const int b = (int)(i / hw), r = (int)(i % hw), y = r / W, x = r % W;
+    const float* f = fw + (size_t)b * 2 * hw;
+    const float* g = bw + (size_t)b * 2 * hw;
+    const float fx = f[r], fy = f[hw + r];
+    const float tx = (float)x + fx, ty = (float)y + fy;
+    float d = __builtin_huge_valf();
+    if (tx >= 0.0f && tx <= (float)(W - 1) && ty >= 0.0f && ty <= (float)(H - 1)) {
+        const int x0 = min((int)tx, W - 2 < 0 ? 0 : W - 2), y0 = min((int)ty, H - 2 < 0 ? 0 : H - 2);
+        const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+        const float ax = tx - (float)x0, ay = ty - (float)y0;
+        const float w00 = (1.0f - ax) * (1.0f - ay), w01 = ax * (1.0f - ay), w10 = (1.0f - ax) * ay, w11 = ax * ay;
+        const float gx = ((g[y0 * W + x0] * w00 + g[y0 * W + x1] * w01) + g[y1 * W + x0] * w10) + g[y1 * W + x1] * w11;
+        const float gy = ((g[hw + y0 * W + x0] * w00 + g[hw + y0 * W + x1] * w01) + g[hw + y1 * W + x0] * w10) + g[hw + y1 * W + x1] * w11;
+        const float ex = fx + gx, ey = fy + gy;
+        d = sqrtf(ex * ex + ey * ey);
+    }
+    mask[i] = d < thresh ? 1.0f : 0.0f;
+    if (dist) dist[i] = d;
+}
+
 }  // namespace
 
 extern "C" size_t syn3r_inverse_warp_workspace_bytes(int nb) { return (size_t)(SYN3R_SIDE_OK(nb) ? nb : 1) * 16; }
@@ -607,5 +640,20 @@ extern "C" int syn3r_fuse_uncertainty(const float* cond_ori, const float* gs_ima
     SYN3R_LAUNCH(k_warp_pool, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)nullptr,
                  (const float*)uncertainty, H, W, h, w, cells, (float*)nullptr, masks);
     SYN3R_LAUNCH_CHECK("fuse_uncertainty launch");
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_flow_cycle_mask(const float* flow_fw, const float* flow_bw, int n, int H, int W, float thresh, float* mask,
+                                     float* dist, void* stream_) {
+    SYN3R_REQUIRE(flow_fw && flow_bw && mask, "flow_cycle_mask: null argument");
+    SYN3R_REQUIRE(SYN3R_SIDE_OK(n) && SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W) && (long long)n * H * W < (1ll << 40),
+                  "flow_cycle_mask: bad shape n=%d H=%d W=%d", n, H, W);
+    SYN3R_REQUIRE(thresh > 0.0f, "flow_cycle_mask: threshold must be positive");
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long npix = (long long)n * H * W;
+    SYN3R_REQUIRE((npix + 255) / 256 < (1ll << 31), "flow_cycle_mask: too many pixels");
+    SYN3R_LAUNCH(k_flow_cycle_mask, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, flow_fw, flow_bw, H, W, npix, thresh,
+                 mask, dist);
+    SYN3R_LAUNCH_CHECK("flow_cycle_mask launch");
     return SYN3R_OK;
 }

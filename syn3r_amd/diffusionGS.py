@@ -9,8 +9,10 @@ keeps the reference's constructor, method names, artefact names (`dense_views…
 What runs where: the rasteriser behind `gsTrainer.render_view` / `training`, the inverse warps, the UNet and the
 scheduler steps are HIP kernels; poses, masks and the lambda schedule are host numerics (`syn3r_amd.orchestrator`).
 Everything stays on the device between stages (the reference round-trips through numpy and PNG files,
-diffusionGS.py:151-169,1447-1475).  Out of scope and therefore rejected: dust3r/GMFlow point-cloud densification
-(`num_views_for_pcd_densification > 1`, sources absent — SURVEY.md N2).
+diffusionGS.py:151-169,1447-1475).  Point-cloud densification (`num_views_for_pcd_densification > 1`): the
+two networks it needs (GMFlow behind `gsTrainer.generate_corresp_mask`, dust3r as `gsTrainer.dust3r`) are trainer
+attributes supplied by the caller, exactly where the reference keeps them; everything around them — key-frame selection,
+the keep rule, the pair graph, the cloud filter — is built here.
 CLIP and the temporal VAE are passed in as modules (`svd_components`), see `pipeline/svd_2pass.py`.
 """
 from __future__ import annotations
@@ -203,11 +205,11 @@ class DiffusionGS:
         return self._frames_to_gs(frames, image_o, image_o2, replace), interpolated_poses, pseudo_images
 
     def densify_views(self, cycle_num, down_sample_rate=1, densify_type="interpolate", num_views_for_pcd_densification=4):
-        """diffusionGS.py:174-340 (view densification; point-cloud densification is out of scope)."""
-        if num_views_for_pcd_densification > 1:
-            raise NotImplementedError("dust3r/GMFlow point-cloud densification is out of scope (sources absent); "
-                                      "run with --num_views_for_pcd_densification 1")
-        dense_views, dense_poses = [], []
+        """diffusionGS.py:179-343.  View densification per input-view pair (HOT LOOP B), the key-frame / input-frame
+        bookkeeping (:221-224,268-294) and, for `num_views_for_pcd_densification > 1`, the point-cloud densification:
+        `densify_pcds` on the key frames, then the cloud filter (`syn3r_amd.pcd`: stride `n // 100000`, statistical outlier
+        removal k = 20 / 3 sigma on the device) and `dense_views/dense_views_cyc{c}.ply` (:302-336)."""
+        dense_views, dense_poses, key_frame_mask, input_flags = [], [], [], []
         os.makedirs(os.path.join(self.save_dir, "dense_views"), exist_ok=True)
         for i in range(self.num_input_views):
             saving_path = os.path.join(self.save_dir, "dense_views" f"interpolated_dense_views_cyc{cycle_num}_view{i}.pt")
@@ -227,13 +229,73 @@ class DiffusionGS:
                 if down_sample_rate < 1:
                     idx = np.linspace(0, len(frames) - 1, int(len(frames) * down_sample_rate), dtype=int)
                     frames, poses = [frames[k] for k in idx], [poses[k] for k in idx]
+            input_flags.extend([True] + [False] * (len(frames) - 2))           # a pair's first frame is an input view
             dense_views.extend(frames[:-1])
             dense_poses.extend(poses[:-1])
+            key_frame_mask.extend(list(O.key_frame_template(poses, len(frames), num_views_for_pcd_densification,
+                                                            bool(self.fps_keyframe_sampling))))
             if densify_type == "interpolate_loop0_gs" and i == self.num_input_views - 2:
+                input_flags.append(True)                                       # the open chain's last input view
                 dense_views.append(frames[-1])
                 dense_poses.append(poses[-1])
+                key_frame_mask.append(True)
+            assert len(dense_views) == len(dense_poses) == len(key_frame_mask) == len(input_flags)
             torch.save({"views": frames, "poses": poses}, saving_path)
-        return dense_views, dense_poses, None
+        dense_pcds = None
+        if num_views_for_pcd_densification > 1:
+            key = np.nonzero(key_frame_mask)[0]
+            trimesh_scene = self.densify_pcds([dense_views[k] for k in key], [dense_poses[k] for k in key],
+                                              key_frame_mask=[True] * len(key), input_flags=[input_flags[k] for k in key],
+                                              win_samples=-1)
+            cloud = trimesh_scene.geometry["geometry_0"]
+            from . import pcd as P
+            dense_pcds = P.filter_dense_cloud(cloud.vertices, cloud.colors, self.device)        # :314-334
+            P.write_point_cloud(os.path.join(self.save_dir, "dense_views", f"dense_views_cyc{cycle_num}.ply"), dense_pcds)
+        return dense_views, dense_poses, dense_pcds
+
+    def densify_pcds(self, diffused_frames, interpolated_poses, key_frame_mask=None, input_flags=None, win_samples=-1):
+        """diffusionGS.py:347-435.  Every candidate frame is rendered from the Gaussians and compared with its diffused
+        frame by the trainer's correspondence mask (`gsTrainer.generate_corresp_mask(..., dist_thresh=3, desc_only=False)`:
+        the flow network is an attribute of the trainer, the cycle test is `syn3r_flow_cycle_mask`); frames whose mask
+        mean exceeds 0.3 — and every input view — go to dust3r (`self.dust3r`, the trainer's attribute as in the
+        reference :51) with camera-to-world poses, intrinsics scaled to a 512-wide image and the complete pair graph of
+        the kept key frames.  Returns dust3r's trimesh scene."""
+        assert len(diffused_frames) == len(interpolated_poses)
+        if key_frame_mask is not None:
+            assert len(diffused_frames) == len(key_frame_mask)
+        if self.dust3r is None:
+            raise RuntimeError("densify_pcds needs gsTrainer.dust3r (the reference's trainer attribute, diffusionGS.py:51): "
+                               "an object with to(device) / run(frames, c2w_poses=, intrinsics=, preset_pairs=)")
+        if isinstance(diffused_frames[0], torch.Tensor):
+            diffused_frames = [im.permute([1, 2, 0]).cpu().numpy() * 255 for im in diffused_frames]
+        num_frames = len(diffused_frames)
+        kept_frames, kept_c2w, kept_K, kept_key_inds = [], [], [], []
+        for i in range(num_frames):
+            _, image, _, _ = self.render_GS(pose=interpolated_poses[i], return_alpha=True)
+            masks, _ = self.gsTrainer.generate_corresp_mask(
+                gs_renderings=[torch.from_numpy(np.ascontiguousarray(image))],
+                svd_outputs=[torch.from_numpy(np.ascontiguousarray(diffused_frames[i].transpose([2, 0, 1])))],
+                dist_thresh=3, desc_only=False)
+            share = float(masks[0][0].mean())
+            if (i == 0 or i == num_frames - 1) and share < 0.2:
+                print("Warning: Weird phenomenon, the first or last frame is not good, please check the input images")
+            if share > 0.3 or (input_flags is not None and input_flags[i]):
+                if key_frame_mask is not None and key_frame_mask[i]:
+                    kept_key_inds.append(len(kept_frames))
+                kept_frames.append(diffused_frames[i])
+                kept_c2w.append(np.linalg.inv(interpolated_poses[i]))
+                K = self.gs_intrinsics.copy()
+                K[:2] = K[:2] * 512 / self.gs_width
+                kept_K.append(K)
+        self.dust3r.to("cuda")
+        key_frames = [kept_frames[k] for k in kept_key_inds]
+        if hasattr(self.dust3r, "make_pairs"):
+            pairs = self.dust3r.make_pairs(key_frames, scene_graph="complete", global_image_inds=kept_key_inds)
+        else:
+            pairs = O.complete_pair_graph(kept_key_inds)
+        _, trimesh_scene = self.dust3r.run(kept_frames, c2w_poses=kept_c2w, intrinsics=kept_K, preset_pairs=pairs)
+        self.dust3r.to("cpu")
+        return trimesh_scene
 
     def refine_GS(self, dense_views, dense_poses, intrinsics, cam_confidence=0.01, gs_start_iter=0,
                   disable_densification=False, load_iteration=None, pseudo_cam_sampling_rate=1, load_ckpt=True):

@@ -163,8 +163,8 @@ class GaussianModel:
         sqrt(mean squared distance to the 3 nearest neighbours), identity rotation, opacity 0.1.  The reference does this
         inside FSGS (`simple-knn` CUDA extension, absent); the exact 3-NN search is `csrc/knn.hip` (`train_ops.knn3_mean_dist2`)."""
         dev = self._xyz.device
-        pts = torch.as_tensor(np.asarray(points), dtype=torch.float32, device=dev)
-        rgb = torch.as_tensor(np.asarray(colors), dtype=torch.float32, device=dev)
+        to_dev = lambda a: (a.detach() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))).to(dev, torch.float32)
+        pts, rgb = to_dev(points), to_dev(colors)
         if pts.dim() != 2 or pts.shape[1] != 3 or rgb.shape != pts.shape:
             raise ValueError("reset_gaussians_from_pcd: points and colours must both be [n,3]")
         n = pts.shape[0]
@@ -247,7 +247,8 @@ class GSTrainer:
                  checkpoint_iterations: Optional[Sequence[int]] = None):
         self.gaussians, self.opt = gaussians, opt or OptimizationParams()
         self.scene = _Scene(train_cameras, model_path)
-        self.dust3r = None
+        self.dust3r = None                # injected: to(device) / [make_pairs] / run(frames, c2w_poses=, intrinsics=, preset_pairs=)
+        self.flow_net = None              # injected: flow_net(image_a [3,H,W], image_b [3,H,W]) -> flow a->b [2,H,W] (GMFlow's role)
         self.checkpoint_iterations: List[int] = list(checkpoint_iterations or [])
         self.iteration = 0
         self.densify = False              # adaptive density control inside train_step (training / finetune set it)
@@ -315,11 +316,35 @@ class GSTrainer:
         """diffusionGS.py:1685-1687 — re-initialise (or extend) the Gaussians from a dense point cloud: an object with
         `.points` / `.colors` (open3d) or a (points [n,3], colours [n,3] in [0,1]) pair."""
         if hasattr(pcd, "points"):
-            pts, col = np.asarray(pcd.points), np.asarray(pcd.colors)
+            pts, col = pcd.points, pcd.colors            # open3d-like cloud or syn3r_amd.pcd.PointCloud (device tensors)
         else:
             pts, col = pcd
         self.gaussians.set_from_pcd(pts, col, append=append_to_old_gaussians)
         self.reset_optimizers()
+
+    def generate_corresp_mask(self, gs_renderings, svd_outputs, dist_thresh: float = 3, desc_only: bool = False):
+        """diffusionGS.py:377 — per (Gaussian render, diffused frame) pair the mask of pixels with a consistent dense
+        correspondence, and the flows.  FSGS' wrapper and its GMFlow network are absent; here the flow network is the
+        injected attribute `flow_net` (called once per direction) and the test is the forward / backward cycle error below
+        `dist_thresh` pixels (`syn3r_flow_cycle_mask`, csrc/warp.hip).  Images go to `flow_net` exactly as the orchestrator
+        passes them ([3,H,W] tensors; the reference hands over the render in [0,1] and the diffused frame in [0,255]).
+        Returns (masks, flow_bwfw): masks[i] is [1,H,W] fp32 in {0,1} (the caller reads `masks[0][0]`), flow_bwfw[i] the
+        (forward, backward) flow pair."""
+        if desc_only:
+            raise NotImplementedError("desc_only=True (descriptor matching) is internal to FSGS; the orchestrator passes False")
+        if self.flow_net is None:
+            raise RuntimeError("generate_corresp_mask needs GSTrainer.flow_net (the optical-flow network, GMFlow in the reference)")
+        assert len(gs_renderings) == len(svd_outputs)
+        from ..pcd import flow_cycle_mask
+        dev = self.gaussians._xyz.device
+        masks, flows = [], []
+        for a, b in zip(gs_renderings, svd_outputs):
+            a, b = a.to(dev, torch.float32), b.to(dev, torch.float32)
+            fw = torch.as_tensor(self.flow_net(a, b), dtype=torch.float32).to(dev)
+            bw = torch.as_tensor(self.flow_net(b, a), dtype=torch.float32).to(dev)
+            masks.append(flow_cycle_mask(fw[None], bw[None], float(dist_thresh)))
+            flows.append((fw, bw))
+        return masks, flows
 
     def find_nearest_cam(self, cams: Sequence[Camera], candidates: Sequence[Camera], multi_view_max_angle: float = 30.0,
                          multi_view_min_dis: float = 0.01, multi_view_max_dis: float = 1.5, multi_view_num: int = 8):

@@ -304,3 +304,49 @@ def consistency_check_from_nearby_images_bw(intrinsics, interpolated_poses, imag
         intensity_conf = torch.exp(-((torch.norm(warped - imgs[cur], dim=0)) / 0.1) ** 3)
         intensity_uncertainty_masks.append(1 - intensity_conf)
     return uncertainty_masks, intensity_uncertainty_masks
+
+
+# ---------------------------------------------------------------------------------------------- N2 (key frames, pair graph)
+def view_selection_for_pcd_densification(poses: Sequence[np.ndarray], pose_num: int, alpha: float = 1.0, beta: float = 1.0) -> List[int]:
+    """diffusionGS.py:185-217 — farthest-point sampling of `pose_num` of the w2c `poses` under the distance
+    1 - covisibility,  covisibility(i, j) = exp(-alpha |c_i - c_j|) * exp(-beta angle(z_i, z_j))  (camera centres c and
+    viewing directions z of the camera-to-world matrices), seeded with pose 0; each round adds the pose whose nearest
+    selected pose is farthest.  Returns the indices in selection order."""
+    n = len(poses)
+    assert n > pose_num, "The number of poses should be larger than the number of poses to select"
+    cam = [np.linalg.inv(p) for p in poses]
+    centre = [c[:3, 3] for c in cam]
+    axis = [c[:3, 2] for c in cam]
+    far = np.zeros((n, n))
+    for i in range(n):
+        for j in range(i, n):
+            gap = np.linalg.norm(centre[i] - centre[j])
+            c = np.dot(axis[i], axis[j]) / (np.linalg.norm(axis[i]) * np.linalg.norm(axis[j]))
+            turn = np.arccos(np.clip(c, -1.0, 1.0))
+            far[i, j] = far[j, i] = 1 - np.exp(-alpha * gap) * np.exp(-beta * turn)
+    chosen = [0]
+    while len(chosen) < pose_num:
+        nearest = far[chosen].min(axis=0)
+        nearest[chosen] = -np.inf
+        chosen.append(int(np.argmax(nearest)))
+    return chosen
+
+
+def key_frame_template(interpolated_poses: Sequence[np.ndarray], n_frames: int, num_key: int, fps: bool) -> np.ndarray:
+    """diffusionGS.py:274-284 — which of a view pair's first n_frames - 1 frames feed the point-cloud densification:
+    `num_key` indices by farthest-pose sampling (sorted) or evenly spaced, the LAST of them dropped (the pair's end
+    frame is the next pair's start frame), as a boolean template of length n_frames - 1."""
+    if fps:
+        key = sorted(view_selection_for_pcd_densification(interpolated_poses, num_key, alpha=1.0, beta=1.0))
+    else:
+        key = list(np.linspace(0, n_frames - 1, num_key, dtype=int))
+    template = np.zeros(n_frames - 1, dtype=bool)
+    template[np.asarray(key[:-1], dtype=int)] = True
+    return template
+
+
+def complete_pair_graph(global_image_inds: Sequence[int]) -> List[tuple]:
+    """dust3r `make_pairs(scene_graph='complete')` over the kept key frames (diffusionGS.py:401): every unordered pair
+    once, as global frame indices.  Used when the injected dust3r object has no `make_pairs` of its own."""
+    g = list(global_image_inds)
+    return [(g[a], g[b]) for a in range(len(g)) for b in range(a + 1, len(g))]

@@ -148,6 +148,10 @@ def test_training_with_density_control_changes_the_set_and_keeps_fitting(gpu):
         assert grp["params"][0] is p and tr.optimizer.state[p]["exp_avg"].shape == p.shape
     assert np.isfinite(last) and last < 0.8 * first, (first, last)
     assert tr.truncated_renders == 0
+    # six changes of the Gaussian count: the async pair capacity followed them (carried over, scaled by N_new / N_old) and
+    # the keys of the counts that no longer exist are gone, every queued check has been read
+    from syn3r_amd import raster
+    assert not raster._pending and raster.capacity_key(gpu, n_now, H, W) in raster._capacity
     # the flag the orchestrator forwards (refine_GS, diffusionGS.py:1610,1640) switches it off
     counts.clear()
     tr.finetune(0, 1, iterations=40, disable_densification=True)
