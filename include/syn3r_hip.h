@@ -275,13 +275,16 @@ int syn3r_sort_pairs(unsigned long long* keys, unsigned* vals, unsigned long lon
  * nn.Linear / 1x1 convolutions (attention_processor.py:187-202, resnet.py:316,
  * transformer_temporal.py:236,273) with the adds that follow them fused.
  * W is the nn.Linear weight as stored ([out_features, in_features]).
- * rows_per_vec < 0 selects rowvec[m mod |rows_per_vec|] instead (the batch-interleaved context of
- * the temporal cross-attention, transformer_temporal.py:310-317).
+ * rows_per_vec = -P selects rowvec[m mod P] instead (the batch-interleaved context of the temporal
+ * cross-attention, transformer_temporal.py:310-317, for a batch of P).  rv_group_rows = G > 0 (with
+ * rows_per_vec < 0): the rows come in groups of G, each emulating a SEPARATE batch-of-P call of the reference:
+ * row m adds rowvec[(m / G) * P + m mod P] (the forward- and backward-in-time passes of a denoising step,
+ * SVD_2pass_prob_uncertain.py:661-742, in one launch).  rv_group_rows = 0: one group.
  * K % 64 == 0; strides in elements, multiples of 8; pointers 16-byte aligned;
  * bias / rowvec / residual / aux may be NULL.
  */
 int syn3r_gemm_f16(const void* A, long long lda, const void* W, void* out, long long ldc, const void* bias,
-                   const void* rowvec, long long ldrv, int rows_per_vec, const void* residual, long long ldr,
+                   const void* rowvec, long long ldrv, int rows_per_vec, int rv_group_rows, const void* residual, long long ldr,
                    const void* aux, long long ldaux, float s_acc, float s_res, float s_aux, int M, int N, int K,
                    void* stream);
 

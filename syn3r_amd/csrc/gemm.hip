@@ -47,12 +47,23 @@ constexpr int EPI_LD = 88;                 // padded row stride (halfs) of the e
 
 enum { MODE_DENSE = 0, MODE_CONV2D = 1, MODE_TCONV = 2 };
 
+// Which row of the per-sample vector table row m adds.  rows_per_vec > 0: one vector per block of rows.
+// rows_per_vec = -P: vector m mod P (the batch-interleaved context of the temporal cross-attention,
+// transformer_temporal.py:310-317, for a batch of P); with rv_group = G > 0 the rows come in groups of G that each
+// emulate a SEPARATE batch-of-P call: group g = m / G reads vectors g * P + m mod P (two CFG passes in one launch).
+__device__ __forceinline__ int rowvec_index(int m, int rows_per_vec, int rv_group) {
+    if (rows_per_vec > 0) return m / rows_per_vec;
+    const int P = -rows_per_vec;
+    return (rv_group > 0 ? (m / rv_group) * P : 0) + m % P;
+}
+
 struct GemmParams {
     const __half* A; long long lda;       // dense: row stride; conv: unused (NHWC dense)
     const __half* W;                      // [N][K], K contiguous
     __half* out; long long ldc;
     const __half* bias;                   // [N] or null
     const __half* rowvec; long long ldrv; int rows_per_vec;   // [M/rows_per_vec][ldrv] or null
+    int rv_group;                         // rows_per_vec < 0 only: rows per context group (0 = one group), see rowvec_index
     const __half* residual; long long ldr;
     const __half* aux; long long ldaux;
     float s_acc, s_res, s_aux;
@@ -148,8 +159,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
         const int m = gm0 + row;
         const __half* rv = nullptr;
         if (p.rowvec && m < p.M) {
-            // rows_per_vec > 0: one vector per block of rows; < 0: vector index = m mod |rows_per_vec|
-            int vi = p.rows_per_vec > 0 ? m / p.rows_per_vec : m % (-p.rows_per_vec);
+            const int vi = rowvec_index(m, p.rows_per_vec, p.rv_group);
             rv = p.rowvec + (long long)vi * p.ldrv;
         }
 #pragma unroll
@@ -884,7 +894,7 @@ __device__ __forceinline__ void lean_store(const GemmParams& p, float4v (*acc)[T
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int m = gm0 + i * 16 + fr;
-            const int vi = m < p.M ? (p.rows_per_vec > 0 ? m / p.rows_per_vec : m % (-p.rows_per_vec)) : 0;
+            const int vi = m < p.M ? rowvec_index(m, p.rows_per_vec, p.rv_group) : 0;
             rv[i] = p.rowvec + (long long)vi * p.ldrv;
         }
     }
@@ -2041,6 +2051,7 @@ int check_common(const GemmParams& p, const char* who) {
     SYN3R_REQUIRE(!p.residual || (p.ldr % 8 == 0 && p.ldr >= p.N), "%s: bad residual stride", who);
     SYN3R_REQUIRE(!p.aux || (p.ldaux % 8 == 0 && p.ldaux >= p.N), "%s: bad aux stride", who);
     SYN3R_REQUIRE(!p.rowvec || (p.rows_per_vec != 0 && p.ldrv >= p.N), "%s: bad rowvec arguments", who);
+    SYN3R_REQUIRE(p.rv_group >= 0 && (p.rv_group == 0 || p.rows_per_vec < 0), "%s: rv_group_rows needs rows_per_vec < 0", who);
     SYN3R_REQUIRE(((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out | (uintptr_t)p.residual | (uintptr_t)p.aux) % 16 == 0,
                   "%s: operands must be 16-byte aligned", who);
     return SYN3R_OK;
@@ -2121,12 +2132,13 @@ int launch_skinny(const GemmParams& p, hipStream_t stream) {
 }
 
 extern "C" int syn3r_gemm_f16(const void* A, long long lda, const void* W, void* out, long long ldc, const void* bias,
-                              const void* rowvec, long long ldrv, int rows_per_vec, const void* residual,
+                              const void* rowvec, long long ldrv, int rows_per_vec, int rv_group_rows, const void* residual,
                               long long ldr, const void* aux, long long ldaux, float s_acc, float s_res, float s_aux,
                               int M, int N, int K, void* stream) {
     GemmParams p{};
     p.A = (const __half*)A; p.lda = lda; p.W = (const __half*)W; p.out = (__half*)out; p.ldc = ldc;
     p.bias = (const __half*)bias; p.rowvec = (const __half*)rowvec; p.ldrv = ldrv; p.rows_per_vec = rows_per_vec;
+    p.rv_group = rv_group_rows;
     p.residual = (const __half*)residual; p.ldr = ldr; p.aux = (const __half*)aux; p.ldaux = ldaux;
     p.s_acc = s_acc; p.s_res = s_res; p.s_aux = s_aux; p.M = M; p.N = N; p.K = K;
     int rc = check_common(p, "gemm_f16");

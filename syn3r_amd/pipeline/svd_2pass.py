@@ -14,6 +14,8 @@ Differences from the reference that do not change results:
   * the "Post" gradient pass does not run autograd through the UNet: the UNet input is detached
     (…post.py:732), so the gradient is the closed form implemented by `syn3r_step_interp`
     (SURVEY.md §8a S2) — saves ≈96 TFLOP per (step, pass);
+  * the forward- and backward-in-time passes of a step run as ONE stack of UNet launches (`merge_passes`, default on
+    with the HIP UNet): same per-sample arithmetic, weights stream once per step;
   * `one_pass=True` runs the forward-in-time pass only (BASELINE.json configs[1] "SVD_1pass");
   * `num_frames` is a parameter (the reference asserts 25, …post.py:531).
 """
@@ -132,59 +134,121 @@ class StableVideoDiffusionPipeline:
         return frames.float()
 
     # ------------------------------------------------------------------ the hot loop
-    def _unet(self, x, t, ehs, added):
-        return self.unet(x, t, encoder_hidden_states=ehs, added_time_ids=added, return_dict=False)[0]
+    def _unet(self, x, t, ehs, added, **kw):
+        return self.unet(x, t, encoder_hidden_states=ehs, added_time_ids=added, return_dict=False, **kw)[0]
 
-    def _pass_replace(self, i, t, latents, image_latents, ehs, added, cond, mask, lam, do_cfg):
-        """SVD_2pass_prob_uncertain.py:691-716"""
-        sch = self.scheduler
+    def _cfg(self, noise_pred, do_cfg):
+        if not do_cfg:
+            return noise_pred
+        u, c = noise_pred.chunk(2)
+        return u + self.guidance_scale * (c - u)
+
+    def _model_input(self, i, t, latents, image_latents, do_cfg):
+        """…post.py:700-703: CFG duplication, `scale_model_input`, the conditioning-image latents on the channel axis."""
         x = torch.cat([latents] * 2) if do_cfg else latents
-        x = sch.scale_model_input(x, t, step_i=i).to(latents.dtype)
-        x = torch.cat([x, image_latents], dim=2)
-        noise_pred = self._unet(x, t, ehs, added)
-        if do_cfg:
-            u, c = noise_pred.chunk(2)
-            noise_pred = u + self.guidance_scale * (c - u)
-        return sch.step_interp_prob_uncertain(noise_pred, t, latents, cond, mask, lam, step_i=i).prev_sample
+        x = self.scheduler.scale_model_input(x, t, step_i=i).to(latents.dtype)
+        return torch.cat([x, image_latents], dim=2)
 
-    def _pass_post(self, i, t, latents, image_latents, ehs, added, cond, mask, lam, do_cfg):
+    @staticmethod
+    def _tile_operands(cond, mask):
+        """The guidance tiles' views of one pass's conditioning latents and mask (…post.py:739-758), cut ONCE per pass: the
+        scheduler keeps the kernel-side form of these objects per object, so handing it the same tensors at every step
+        is what lets that cache hit (100 steps x 4 tiles)."""
+        h, w = cond.shape[-2:]
+        tiles, ov_y, ov_x = post_tiles(h, w)
+        ops_ = []
+        for ty, tx in tiles:
+            ops_.append((cond[:2, :, :, ty, tx].contiguous(), mask[0:1, :, :, ty, tx].contiguous()))
+        return tiles, ov_y, ov_x, ops_
+
+    @staticmethod
+    def _stitch(grads, ov_y, ov_x):
+        """…post.py:776-778"""
+        g1 = torch.cat((grads[0], grads[1][:, :, :, ov_y:, :]), -2)
+        g2 = torch.cat((grads[2], grads[3][:, :, :, ov_y:, :]), -2)
+        return torch.cat((g1, g2[:, :, :, :, ov_x:]), -1)
+
+    def _pass_replace(self, i, t, latents, image_latents, ehs, added, cond, mask, lam, do_cfg, tile_ops=None):
+        """SVD_2pass_prob_uncertain.py:691-716"""
+        x = self._model_input(i, t, latents, image_latents, do_cfg)
+        noise_pred = self._cfg(self._unet(x, t, ehs, added), do_cfg)
+        return self.scheduler.step_interp_prob_uncertain(noise_pred, t, latents, cond, mask, lam, step_i=i).prev_sample
+
+    def _pass_post(self, i, t, latents, image_latents, ehs, added, cond, mask, lam, do_cfg, tile_ops=None):
         """…post.py:700-800"""
         sch = self.scheduler
-        x = torch.cat([latents] * 2) if do_cfg else latents
-        x = sch.scale_model_input(x, t, step_i=i).to(latents.dtype)
-        x = torch.cat([x, image_latents], dim=2)
-        h, w = latents.shape[-2:]
-        tiles, ov_y, ov_x = post_tiles(h, w)
+        x = self._model_input(i, t, latents, image_latents, do_cfg)
+        tiles, ov_y, ov_x, tops = tile_ops if tile_ops is not None else self._tile_operands(cond, mask)
         # :726-774 — four B = 1 forwards of the unconditional half in the reference.  Tiles 0/2 and 1/3 have equal
         # shapes and share the same (unconditional) context and time ids, so each pair runs as ONE batch-of-2 forward:
         # identical per-sample arithmetic (GroupNorm and attention are per sample; the reference's batch-interleaved
         # temporal context is the same vector for both), larger contractions.
         grads = [None] * 4
         for pair in ((0, 2), (1, 3)):
-            sls = [(slice(0, 1), slice(None), slice(None)) + tiles[k] for k in pair]
-            xb = torch.cat([x[sl] for sl in sls], dim=0).contiguous()
+            xb = torch.cat([x[0:1, :, :, tiles[k][0], tiles[k][1]] for k in pair], dim=0).contiguous()
             noise = self._unet(xb, t, ehs[0:1].expand(2, -1, -1), added[0:1].expand(2, -1).contiguous())   # stride-0 context
-            for n, (k, sl) in enumerate(zip(pair, sls)):
-                out = sch.step_interp(noise[n:n + 1], t, latents[sl].contiguous(), cond[(slice(0, 2),) + sl[1:]].contiguous(),
-                                      mask[sl].contiguous(), lam, step_i=i, lr=0.02, compute_grad=True)
+            for n, k in enumerate(pair):
+                out = sch.step_interp(noise[n:n + 1], t, latents[0:1, :, :, tiles[k][0], tiles[k][1]].contiguous(), tops[k][0],
+                                      tops[k][1], lam, step_i=i, lr=0.02, compute_grad=True)
                 grads[k] = out.grad
-        g1 = torch.cat((grads[0], grads[1][:, :, :, ov_y:, :]), -2)     # :776-778
-        g2 = torch.cat((grads[2], grads[3][:, :, :, ov_y:, :]), -2)
-        g3 = torch.cat((g1, g2[:, :, :, :, ov_x:]), -1)
-        next_latents = latents - g3.half()                              # :779
-        noise_pred = self._unet(x, t, ehs, added)                       # :786-792 (input built from the ORIGINAL latents)
-        if do_cfg:
-            u, c = noise_pred.chunk(2)
-            noise_pred = u + self.guidance_scale * (c - u)
+        next_latents = latents - self._stitch(grads, ov_y, ov_x).half()    # :779
+        noise_pred = self._cfg(self._unet(x, t, ehs, added), do_cfg)       # :786-792 (input built from the ORIGINAL latents)
         return sch.step_interp(noise_pred, t, next_latents, cond, mask, lam, step_i=i, compute_grad=False).prev_sample
+
+    # ---- both passes of a step in ONE UNet call -------------------------------------------------------------------
+    # The forward- and backward-in-time passes of a step read the same latents (time-flipped) and do not depend on each
+    # other (…post.py:679-698, SVD_2pass_prob_uncertain.py:661-742).  Stacked on the batch axis they are one launch
+    # sequence of twice the rows: every weight streams once per step instead of twice and the launches whose grids
+    # left CUs idle (M = 4 032 / 9 000 / 10 800 rows) fill the chip.  Per-sample arithmetic is the reference's: the only
+    # batch-coupled operator, the interleaved temporal cross-attention context, is applied per pass (`ctx_group`).
+    def _merged_replace(self, i, t, lat, img4, ehs4, added4, ops2, do_cfg):
+        sch = self.scheduler
+        g = 2 if do_cfg else 1
+        x = torch.cat([self._model_input(i, t, lat[k], img4[k * g:(k + 1) * g], do_cfg) for k in range(2)])
+        noise = self._unet(x, t, ehs4, added4, ctx_group=g)
+        out = []
+        for k in range(2):
+            cond, mask, lam, _ = ops2[k]
+            pred = self._cfg(noise[k * g:(k + 1) * g], do_cfg)
+            out.append(sch.step_interp_prob_uncertain(pred, t, lat[k], cond, mask, lam, step_i=i).prev_sample)
+        return out
+
+    def _merged_post(self, i, t, lat, img4, ehs4, added4, ops2, do_cfg, tile_ctx):
+        sch = self.scheduler
+        g = 2 if do_cfg else 1
+        x = torch.cat([self._model_input(i, t, lat[k], img4[k * g:(k + 1) * g], do_cfg) for k in range(2)])
+        tiles, ov_y, ov_x, _ = ops2[0][3]
+        grads = [[None] * 4, [None] * 4]
+        ehs_t, added_t, grp = tile_ctx
+        for pair in ((0, 2), (1, 3)):                              # the four tile forwards of BOTH passes: two B = 4 calls
+            xb = torch.cat([x[k * g:k * g + 1, :, :, tiles[q][0], tiles[q][1]] for k in range(2) for q in pair], dim=0).contiguous()
+            noise = self._unet(xb, t, ehs_t, added_t, ctx_group=grp)
+            for k in range(2):
+                tops = ops2[k][3][3]
+                for n, q in enumerate(pair):
+                    o = sch.step_interp(noise[2 * k + n:2 * k + n + 1], t, lat[k][0:1, :, :, tiles[q][0], tiles[q][1]].contiguous(),
+                                        tops[q][0], tops[q][1], ops2[k][2], step_i=i, lr=0.02, compute_grad=True)
+                    grads[k][q] = o.grad
+        noise = self._unet(x, t, ehs4, added4, ctx_group=g)         # the CFG forwards of both passes: one B = 4 call
+        out = []
+        for k in range(2):
+            cond, mask, lam, _ = ops2[k]
+            nxt = lat[k] - self._stitch(grads[k], ov_y, ov_x).half()
+            pred = self._cfg(noise[k * g:(k + 1) * g], do_cfg)
+            out.append(sch.step_interp(pred, t, nxt, cond, mask, lam, step_i=i, compute_grad=False).prev_sample)
+        return out
 
     @torch.no_grad()
     def denoise(self, latents, image_latent_start, image_latent_end, emb_start, emb_end, added_time_ids,
                 temp_cond_latents, mask, lambda_ts, num_inference_steps: int, min_guidance_scale=1.0,
-                max_guidance_scale=3.0, one_pass: bool = False, callback: Optional[Callable] = None):
+                max_guidance_scale=3.0, one_pass: bool = False, callback: Optional[Callable] = None,
+                merge_passes: Optional[bool] = None):
         """The denoising loop (…post.py:656-831 / SVD_2pass_prob_uncertain.py:649-748) on prepared
         tensors.  latents [1,F,4,h,w]; image_latent_* [B,F,4,h,w]; emb_* [B,1,D]; temp_cond_latents
-        [2,F,4,h,w] fp32 (already divided by factor_s); mask [1,F-2,4,h,w]; lambda_ts [steps,F] f64."""
+        [2,F,4,h,w] fp32 (already divided by factor_s); mask [1,F-2,4,h,w]; lambda_ts [steps,F] f64.
+        `merge_passes` (default: on when the UNet takes `ctx_group`, i.e. the HIP UNet; SYN3R_MERGE_PASSES=0 turns it off):
+        the two passes of a step share their UNet launches."""
+        import os
         dev = self.device
         F = latents.shape[1]
         do_cfg = max_guidance_scale > 1.0
@@ -193,19 +257,43 @@ class StableVideoDiffusionPipeline:
         gs = torch.linspace(min_guidance_scale, max_guidance_scale, F).unsqueeze(0).to(dev, latents.dtype)
         self._guidance_scale = _append_dims(gs, latents.ndim)
         weight_fw = torch.linspace(1, 0, F)[None, :, None, None, None].to(device=dev, dtype=latents.dtype)
-        step = self._pass_post if self.variant == "post" else self._pass_replace
+        post = self.variant == "post"
+        step = self._pass_post if post else self._pass_replace
         mask = mask.to(dev)
         lambda_ts = lambda_ts.detach().to("cpu", torch.float64)     # read on the host, one row per step: never a device sync
         cond_bw, mask_bw, lam_bw = temp_cond_latents.flip(dims=[1]), mask.flip(dims=[1]), lambda_ts.flip(dims=[1])
+        tops_fw = self._tile_operands(temp_cond_latents, mask) if post else None
+        tops_bw = self._tile_operands(cond_bw, mask_bw) if post and not one_pass else None
+        if merge_passes is None:
+            merge_passes = os.environ.get("SYN3R_MERGE_PASSES") != "0"
+        merged = bool(merge_passes) and not one_pass and getattr(self.unet, "supports_ctx_group", False)
+        if merged:
+            g = 2 if do_cfg else 1
+            img4 = torch.cat([image_latent_start, image_latent_end]).contiguous()
+            ehs4 = torch.cat([emb_start, emb_end]).contiguous()                 # built once: the UNet keys its folded contexts on it
+            added4 = torch.cat([added_time_ids, added_time_ids]).contiguous()
+            ops2 = ((temp_cond_latents, mask, lambda_ts, tops_fw), (cond_bw, mask_bw, lam_bw, tops_bw))
+            if post:                                                            # the tiles run the UNCONDITIONAL half (…post.py:759-760)
+                if torch.equal(emb_start[0:1], emb_end[0:1]):                   # (zeros for both passes: one shared context)
+                    tile_ctx = (emb_start[0:1].expand(4, -1, -1), added_time_ids[0:1].expand(4, -1).contiguous(), None)
+                else:
+                    tile_ctx = (torch.cat([emb_start[0:1]] * 2 + [emb_end[0:1]] * 2).contiguous(),
+                                added_time_ids[0:1].expand(4, -1).contiguous(), 1)
         for i, t in enumerate(timesteps):
-            fw = step(i, t, latents, image_latent_start, emb_start, added_time_ids, temp_cond_latents, mask, lambda_ts,
-                      do_cfg)
-            if one_pass:
-                latents = fw
-            else:
-                bw = step(i, t, latents.flip(dims=[1]), image_latent_end, emb_end, added_time_ids, cond_bw, mask_bw,
-                          lam_bw, do_cfg)
+            if merged:
+                lat = (latents, latents.flip(dims=[1]))
+                fw, bw = (self._merged_post(i, t, lat, img4, ehs4, added4, ops2, do_cfg, tile_ctx) if post else
+                          self._merged_replace(i, t, lat, img4, ehs4, added4, ops2, do_cfg))
                 latents = weight_fw * fw + (1 - weight_fw) * bw.flip(dims=[1])      # :828 / :736
+            else:
+                fw = step(i, t, latents, image_latent_start, emb_start, added_time_ids, temp_cond_latents, mask, lambda_ts,
+                          do_cfg, tops_fw)
+                if one_pass:
+                    latents = fw
+                else:
+                    bw = step(i, t, latents.flip(dims=[1]), image_latent_end, emb_end, added_time_ids, cond_bw, mask_bw,
+                              lam_bw, do_cfg, tops_bw)
+                    latents = weight_fw * fw + (1 - weight_fw) * bw.flip(dims=[1])  # :828 / :736
             if callback is not None:
                 callback(i, t, latents)
         return latents
@@ -218,7 +306,7 @@ class StableVideoDiffusionPipeline:
                  num_videos_per_prompt: Optional[int] = 1, generator=None, latents: Optional[torch.Tensor] = None,
                  output_type: Optional[str] = "pil", callback_on_step_end=None, return_dict: bool = True,
                  latent_num: int = 1, one_pass: bool = False, dtype: torch.dtype = torch.float16,
-                 aug_noise: Optional[torch.Tensor] = None):
+                 aug_noise: Optional[torch.Tensor] = None, merge_passes: Optional[bool] = None):
         if callback_on_step_end is not None:
             raise NotImplementedError
         if latent_num != 1 or num_videos_per_prompt != 1:
@@ -263,7 +351,8 @@ class StableVideoDiffusionPipeline:
                 torch.randn(shape, device=dev, dtype=dtype)
         latents = latents.to(dev, dtype) * self.scheduler.init_noise_sigma      # prepare_latents
         latents = self.denoise(latents, lat_start, lat_end, emb_start, emb_end, added, cond, mask, lambda_ts,
-                               num_inference_steps, min_guidance_scale, max_guidance_scale, one_pass=one_pass)
+                               num_inference_steps, min_guidance_scale, max_guidance_scale, one_pass=one_pass,
+                               merge_passes=merge_passes)
         if output_type == "latent":
             frames = latents
         else:

@@ -72,6 +72,41 @@ class SvdStepBench:
         return self._post_pipe._pass_post(i, self.sch.timesteps[i], self.latents, self.image_latents, self.ehs, self.added,
                                           self.temp_cond, self.mask, self.lambda_ts, True)
 
+    def step_both(self, variant: str = "replace"):
+        """BOTH passes of one denoising step the way the pipelines run them (`merge_passes`): the forward- and the
+        time-flipped backward pass stacked into one UNet launch sequence, the two scheduler steps, the blend
+        (SVD_2pass_prob_uncertain.py:661-742 / …post.py:679-828).  = 2 (step, pass) units."""
+        from .svd_2pass import StableVideoDiffusionPipeline
+        key = "_both_" + variant
+        st = getattr(self, key, None)
+        if st is None:
+            pipe = StableVideoDiffusionPipeline(None, None, self.unet, self.sch, variant=variant, device=self.dev)
+            pipe._guidance_scale = self.guidance
+            g = torch.Generator(device=self.dev).manual_seed(77)
+            F, h, w = self.F, self.h, self.w
+            img_end = torch.randn(1, F, 4, h, w, generator=g, device=self.dev).half().repeat(2, 1, 1, 1, 1)
+            img_end[0].zero_()
+            ehs_end = torch.cat([torch.zeros(1, 1, 1024, device=self.dev), torch.randn(1, 1, 1024, generator=g, device=self.dev)], 0).half()
+            cond_bw, mask_bw, lam_bw = self.temp_cond.flip(dims=[1]), self.mask.flip(dims=[1]), self.lambda_ts.flip(dims=[1])
+            post = variant == "post"
+            ops2 = ((self.temp_cond, self.mask, self.lambda_ts, pipe._tile_operands(self.temp_cond, self.mask) if post else None),
+                    (cond_bw, mask_bw, lam_bw, pipe._tile_operands(cond_bw, mask_bw) if post else None))
+            st = dict(pipe=pipe, img4=torch.cat([self.image_latents, img_end]).contiguous(), ehs4=torch.cat([self.ehs, ehs_end]).contiguous(),
+                      added4=torch.cat([self.added, self.added]).contiguous(), ops2=ops2,
+                      tile_ctx=(self.ehs[0:1].expand(4, -1, -1), self.added[0:1].expand(4, -1).contiguous(), None),
+                      weight_fw=torch.linspace(1, 0, F, device=self.dev).half()[None, :, None, None, None])
+            setattr(self, key, st)
+        i = self.i % 100
+        self.i += 1
+        t = self.sch.timesteps[i]
+        lat = (self.latents, self.latents.flip(dims=[1]))
+        p = st["pipe"]
+        if variant == "post":
+            fw, bw = p._merged_post(i, t, lat, st["img4"], st["ehs4"], st["added4"], st["ops2"], True, st["tile_ctx"])
+        else:
+            fw, bw = p._merged_replace(i, t, lat, st["img4"], st["ehs4"], st["added4"], st["ops2"], True)
+        return st["weight_fw"] * fw + (1 - st["weight_fw"]) * bw.flip(dims=[1])
+
     def count_flops(self) -> dict:
         """Algorithmic FLOPs of one unit, counted from the launched contractions (2*M*N*K)."""
         ops.FLOPS.update(enabled=True, gemm=0.0, attn=0.0)

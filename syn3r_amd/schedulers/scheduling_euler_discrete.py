@@ -184,15 +184,15 @@ class EulerDiscreteScheduler:
 
     def _prepared(self, slot: str, src: torch.Tensor, make):
         """Per-object cache (identity + in-place version counter; the entry keeps `src` alive, so its address cannot be
-        handed to another tensor meanwhile).  A few entries per slot: the forward and the time-flipped backward pass
-        alternate two sets of objects."""
+        handed to another tensor meanwhile).  Sixteen entries per slot: the forward and the time-flipped backward pass
+        alternate two sets of objects, each with its full-frame tensors and its four guidance-tile views (10 per slot)."""
         cache = self.__dict__.setdefault("_prep_cache", {}).setdefault(slot, [])
         for ent in cache:
             if ent[0] is src and ent[1] == src._version:
                 return ent[2]
         val = make(src)
         cache.insert(0, (src, src._version, val))
-        del cache[4:]
+        del cache[16:]
         return val
 
     def step_interp(self, model_output, timestep, sample, temp_cond_latents=None, mask=None, lambda_ts=None,

@@ -65,6 +65,8 @@ class _Params:
 
 
 class UNetSpatioTemporalConditionModel:
+    supports_ctx_group = True          # forward(..., ctx_group=G): see the pipelines' merged passes
+
     def __init__(self, sample_size: Optional[int] = None, in_channels: int = 8, out_channels: int = 4,
                  down_block_types: Tuple[str, ...] = ("CrossAttnDownBlockSpatioTemporal",) * 3 + ("DownBlockSpatioTemporal",),
                  up_block_types: Tuple[str, ...] = ("UpBlockSpatioTemporal",) + ("CrossAttnUpBlockSpatioTemporal",) * 3,
@@ -442,11 +444,21 @@ class UNetSpatioTemporalConditionModel:
         # (transformer_temporal.py:310-317) while the temporal tokens are batch-major (attention.py:487-489):
         # token (b, pixel) reads the context of batch item (b*HW + pixel) mod B.  Reproduced, not fixed.
         # With ONE context shared by every batch item (B = 1, or a stride-0 expanded context) the interleave is moot.
-        if HW % B and not st["shared_ctx"]:
-            raise NotImplementedError("temporal cross-attention context interleave needs h*w divisible by the batch "
-                                      "size (or one context shared by the batch: pass it expanded, stride 0)")
+        # `ctx_group` = G (forward(..., ctx_group=G)): the batch is a stack of B / G separate batch-of-G calls of the
+        # reference (the forward- and backward-in-time passes of one denoising step), so the interleave runs inside each
+        # group of G samples; G = 1 is the reference's B = 1 call per sample (every token reads its own context).
+        G = st["ctx_group"]
+        if st["shared_ctx"]:
+            rpv, grp = B * F * HW, 0
+        elif G == 1:
+            rpv, grp = F * HW, 0
+        else:
+            if HW % G:
+                raise NotImplementedError("temporal cross-attention context interleave needs h*w divisible by the batch "
+                                          "size (or one context shared by the batch: pass it expanded, stride 0)")
+            rpv, grp = -G, (G * F * HW if G != B else 0)
         tt = ops.linear(a1, W(t + ".attn1.to_out.0.weight"), W(t + ".attn1.to_out.0.bias"), residual=tt,
-                        rowvec=self._cross_vec(t + ".attn2", ehs, st["ctx_cache"]), rows_per_vec=B * F * HW if st["shared_ctx"] else -B)
+                        rowvec=self._cross_vec(t + ".attn2", ehs, st["ctx_cache"]), rows_per_vec=rpv, rv_group_rows=grp)
         n3 = ops.layernorm(tt, W(t + ".norm3.weight"), W(t + ".norm3.bias"))
         a, om = self._blend_scales(pre + ".time_mixer.mix_factor")
         # alpha*hs + (1-alpha)*(ff + tt)
@@ -456,8 +468,13 @@ class UNetSpatioTemporalConditionModel:
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor,
-                added_time_ids: torch.Tensor, return_dict: bool = False):
-        """Reference: unet_spatio_temporal_condition.py:356-489.  sample [B,F,Cin,h,w] fp16 -> [B,F,Cout,h,w]."""
+                added_time_ids: torch.Tensor, return_dict: bool = False, ctx_group: Optional[int] = None):
+        """Reference: unet_spatio_temporal_condition.py:356-489.  sample [B,F,Cin,h,w] fp16 -> [B,F,Cout,h,w].
+
+        `ctx_group` (extension): the batch stacks B / ctx_group INDEPENDENT calls of the reference, each of batch size
+        ctx_group, sharing timestep and time ids (the two passes of a denoising step: SVD_2pass_prob_uncertain.py:661-742).
+        Every per-sample operator is unaffected by the stacking; the one batch-coupled spot — the reference's
+        batch-interleaved temporal cross-attention context — is applied per group.  Default: one call (ctx_group = B)."""
         if self.device is None:
             raise L.Syn3rError("UNet weights are not loaded (load_state_dict / from_pretrained / init_random)")
         dev = L.require_gpu(sample, encoder_hidden_states, added_time_ids)
@@ -483,7 +500,10 @@ class UNetSpatioTemporalConditionModel:
         # the folded cross-attention vector is computed once and added to every row
         shared_ctx = B == 1 or encoder_hidden_states.stride(0) == 0
         ctx = encoder_hidden_states[:1] if shared_ctx else encoder_hidden_states
-        st = dict(B=B, F=F, h=h, w=w_, temb_act=Fn.silu(emb).contiguous(), shared_ctx=shared_ctx,
+        G = B if ctx_group is None else int(ctx_group)
+        if G < 1 or B % G:
+            raise ValueError(f"ctx_group={ctx_group} must divide the batch size {B}")
+        st = dict(B=B, F=F, h=h, w=w_, temb_act=Fn.silu(emb).contiguous(), shared_ctx=shared_ctx, ctx_group=G,
                   ehs=ctx.reshape(ctx.shape[0], -1).to(H).contiguous(), ctx_cache=self._context_cache(encoder_hidden_states, shared_ctx))
         st["temb_all"] = ops.linear(st["temb_act"], W("time_emb_proj.all.weight"), W("time_emb_proj.all.bias"))
         # 2. conv_in on NHWC with channels padded to 64 (:428)

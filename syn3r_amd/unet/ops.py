@@ -41,11 +41,12 @@ def _rowvec(rv: Optional[torch.Tensor]):
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
-           rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0, residual: Optional[torch.Tensor] = None,
+           rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0, rv_group_rows: int = 0,
+           residual: Optional[torch.Tensor] = None,
            aux: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0, s_aux: float = 1.0,
            out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [M,K] @ weight[N,K]^T with the fused epilogue of syn3r_gemm_f16.  x may be a column
-    slice of a wider matrix (stride(0) >= K)."""
+    slice of a wider matrix (stride(0) >= K).  rows_per_vec / rv_group_rows: see include/syn3r_hip.h."""
     dev = L.require_gpu(x, weight)
     M, K = x.shape
     N = weight.shape[0]
@@ -57,7 +58,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         out = torch.empty((M, N), dtype=H, device=dev)
     lib = L.load()
     rc = lib.syn3r_gemm_f16(x.data_ptr(), x.stride(0), L.ptr(weight), out.data_ptr(), out.stride(0), L.ptr(bias),
-                            rv_ptr, rv_ld, int(rows_per_vec),
+                            rv_ptr, rv_ld, int(rows_per_vec), int(rv_group_rows),
                             residual.data_ptr() if residual is not None else None,
                             residual.stride(0) if residual is not None else 0,
                             aux.data_ptr() if aux is not None else None, aux.stride(0) if aux is not None else 0,

@@ -29,6 +29,7 @@ def _ctype_name(t):
     from syn3r_amd import _lib as L
     if t is L.c_i: return "int"
     if t is L.c_f: return "float"
+    if t is L.c_d: return "double"
     if t is L.c_sz: return "size_t"
     if t is L.c_ll: return "long long"
     if t is L.c_p: return "void*"
@@ -50,6 +51,7 @@ def _driver_source():
                 elif c == "long long": vals.append(["0", "-1", "4611686018427387904LL"][variant])
                 elif c == "size_t": vals.append(["0", "1", "(size_t)-1"][variant])
                 elif c == "float": vals.append(["0.0f", "-1.0f", "3.0e38f"][variant])
+                elif c == "double": vals.append(["0.0", "-1.0", "1.0e300"][variant])
                 elif c == "const char*": vals.append(["(const char*)0", "\"k_\"", "\"\""][variant])
                 elif a not in (L.c_p,) and c == "void*": vals.append(["(void*)0", "(void*)scratch", "(void*)scratch"][variant])   # out-pointers
                 else: vals.append(["(void*)0", "(void*)0", "(void*)scratch"][variant])

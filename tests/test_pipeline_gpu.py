@@ -125,3 +125,43 @@ def test_pipeline_with_hip_unet_and_vae_matches_reference_frames(gpu, golden_dir
     # (measured: mean 6.4e-4, max 6.1e-3, tools/pipeline_parity.py)
     assert err.mean() < 2e-3, err.mean()
     assert (err > 2e-2).mean() < 1e-4, ((err > 2e-2).mean(), err.max())
+
+
+@pytest.mark.parametrize("variant", ["replace", "post"])
+def test_merged_passes_equal_separate_passes(variant, gpu):
+    """`merge_passes`: the forward- and backward-in-time passes of a step stacked into one UNet launch sequence (B = 4 CFG
+    calls; for Post also the guidance tiles of both passes, with one shared or two distinct unconditional contexts) give
+    the latents of the pass-by-pass loop."""
+    from oracle import unet_weights as UW
+    from syn3r_amd.pipeline.svd_2pass import StableVideoDiffusionPipeline
+    from syn3r_amd.schedulers.scheduling_euler_discrete import SVD_XT_SCHEDULER_CONFIG, EulerDiscreteScheduler
+    from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel
+    unet = UNetSpatioTemporalConditionModel(**UW.PIPELINE_CONFIG)
+    unet.load_state_dict(UW.make_state_dict(unet.parameter_shapes(), seed=3), gpu)
+    inp = PM.pipeline_inputs(seed=4)
+
+    outs = {}
+    for distinct in (False, True):
+        for merge in (False, True):
+            pipe = StableVideoDiffusionPipeline(PM.MockVAE(), PM.MockImageEncoder(), unet, EulerDiscreteScheduler(**SVD_XT_SCHEDULER_CONFIG),
+                                                variant=variant, device=gpu)
+            if distinct:                  # start / end passes with DIFFERENT unconditional embeddings (tile contexts per pass)
+                enc = pipe._encode_image
+                count = [0]
+
+                def encode(image, do_cfg, enc=enc, count=count):
+                    e = enc(image, do_cfg).clone()
+                    count[0] += 1
+                    e[0] += 0.05 * count[0]
+                    return e
+                pipe._encode_image = encode
+            outs[(distinct, merge)] = pipe(
+                [im.to(gpu) for im in inp["image"]], temp_cond=[t.to(gpu) for t in inp["temp_cond"]], mask=inp["mask"].clone(),
+                lambda_ts=inp["lambda_ts"], num_frames=25, decode_chunk_size=8, num_inference_steps=2, latent_num=1,
+                latents=inp["latents"].clone(), output_type="latent", dtype=torch.float16, aug_noise=inp["noise"],
+                merge_passes=merge).frames.float()
+        a, b = outs[(distinct, False)], outs[(distinct, True)]
+        scale = float(a.abs().max())
+        err = (a - b).abs()
+        assert float(err.mean()) < 5e-4 * scale and float((err > 1e-2 * scale).float().mean()) < 1e-4, (float(err.mean()), float(err.max()), scale)
+    assert not torch.allclose(outs[(False, True)], outs[(True, True)], atol=1e-3 * scale)       # the patched contexts did matter

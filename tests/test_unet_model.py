@@ -118,3 +118,27 @@ def test_shared_context_batch_equals_single_items(gpu):
         assert float(err.max()) < 2e-2 * scale and float(err.mean()) < 2e-3 * scale, (float(err.max()), scale)
     with pytest.raises(NotImplementedError):        # two DIFFERENT contexts need the interleave, which needs even h*w
         model(x, t, ehs.to(gpu).half(), added.to(gpu))
+
+
+@pytest.mark.gpu
+def test_ctx_group_stack_equals_separate_calls(gpu):
+    """forward(..., ctx_group=G): a batch that stacks independent batch-of-G calls (the two passes of a denoising step in
+    one launch sequence) returns what the separate calls return — including the reference's batch-interleaved temporal
+    context, which couples the samples INSIDE a call and must not couple the stacked calls."""
+    from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel
+    model = UNetSpatioTemporalConditionModel(**UW.SMALL_CONFIG)
+    model.load_state_dict(UW.make_state_dict(model.parameter_shapes()), gpu)
+    sample, t, ehs, added = UW.make_inputs(4, 5, 16, 32, seed=21)       # 2 x 4 pixels at the coarsest level: divisible by 4
+    s, e, a = sample.half().to(gpu), ehs.half().to(gpu), added[:1].repeat(4, 1).to(gpu)
+    close = lambda x, y: torch.allclose(x.float(), y.float(), atol=2e-3 * float(y.float().abs().max()), rtol=1e-2)
+    both = model(s, t, e, a, ctx_group=2)[0]
+    for k in range(2):
+        sep = model(s[2 * k:2 * k + 2].contiguous(), t, e[2 * k:2 * k + 2].contiguous(), a[:2])[0]
+        assert close(both[2 * k:2 * k + 2], sep)
+    whole = model(s, t, e, a)[0]                              # one batch-of-4 call interleaves over all four contexts: different
+    assert not close(whole, both)
+    ones = model(s[:2].contiguous(), t, e[:2].contiguous(), a[:2], ctx_group=1)[0]        # G = 1: every sample its own B = 1 call
+    for k in range(2):
+        assert close(ones[k:k + 1], model(s[k:k + 1].contiguous(), t, e[k:k + 1].contiguous(), a[:1])[0])
+    with pytest.raises(ValueError):
+        model(s, t, e, a, ctx_group=3)

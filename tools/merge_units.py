@@ -1,0 +1,26 @@
+"""Per-(step, pass) unit times at F frames: pass-by-pass against both passes stacked (merge_passes)."""
+import sys, time
+sys.path.insert(0, ".")
+import torch
+from syn3r_amd.pipeline.svd_step import SvdStepBench
+
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+dev = torch.device("cuda", 0)
+b = SvdStepBench(F, dev)
+
+
+def wall_ms(fn, n=3):
+    fn(); fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / n
+
+
+print(f"F={F}")
+print("replace  pass-by-pass unit %.1f ms" % wall_ms(b.step_pass))
+print("replace  merged       unit %.1f ms" % (wall_ms(lambda: b.step_both("replace")) / 2))
+print("post     pass-by-pass unit %.1f ms" % wall_ms(b.step_pass_post))
+print("post     merged       unit %.1f ms" % (wall_ms(lambda: b.step_both("post")) / 2))
