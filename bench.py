@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-benchmarks", action="store_true",
                     help="skip the extra timed sub-results (Post / Replace units at F = 25, full trainer iteration, inverse warp)")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the measured full-size svd_render calls and the scaled DiffusionGS.run schedule (~2 min of GPU)")
+    ap.add_argument("--e2e-steps", type=int, default=100, help="denoising steps of the measured svd_render calls (reference: 100)")
     ap.add_argument("--no-kernel-trace", action="store_true",
                     help="skip the HIP-event kernel timing (rocprofv3 --pmc passes: the counters serialise every launch)")
     ap.add_argument("--trace-steps", type=int, default=1,
@@ -224,6 +227,78 @@ def cpu_baseline_unet(args):
     return dt * scale, f"oracle/unet_oracle.py CFG forward [2,{F},8,{h},{w}] (full 1.52 B-parameter configuration) took {dt:.1f} s; x{scale:.0f} by tokens to [2,{args.frames},8,72,128]"
 
 
+def cpu_baseline_geometry_scheduler(dev):
+    """the geometry functions at 576x1024 (SURVEY 8d synthetic warp) and the scheduler steps on
+    [1,25,4,72,128], the oracle (kind 'port': numpy restatements pinned by reference-run fixtures) timed on the host cores
+    once each, beside the device time of the HIP path on the same inputs (sum of kernel time, HIP events)."""
+    from oracle import golden_inputs as GI
+    from oracle import scheduler_oracle as SO
+    from oracle import warp_oracle as WO
+    from syn3r_amd import _lib as L
+    from syn3r_amd.schedulers.scheduling_euler_discrete import SVD_XT_SCHEDULER_CONFIG, EulerDiscreteScheduler
+    from syn3r_amd.solver_utils.consistency import consistency_check_with_depth
+    from syn3r_amd.solver_utils.forward_warp import forward_warp, inverse_warp
+    H, W = 576, 1024
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    depth = (2 + 0.5 * np.sin(xs / 97) + 0.3 * np.cos(ys / 53)).astype(np.float32)
+    K = np.array([[800, 0, W / 2], [0, 800, H / 2], [0, 0, 1]], np.float32)
+    T1 = np.eye(4, dtype=np.float32)
+    T2 = np.eye(4, dtype=np.float32)
+    T2[0, 3], T2[2, 3] = 0.05, 0.02
+    rgb = np.random.default_rng(0).random((3, H, W), dtype=np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def host_s(fn):
+        t0 = time.perf_counter()
+        fn()
+        return time.perf_counter() - t0
+
+    def dev_us(fn, n=5):
+        fn()
+        torch.cuda.synchronize()
+        with L.kernel_trace() as tr:
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+        return 1e3 * sum(v[1] for v in tr.result.values()) / n
+
+    out = {}
+    img, d, k, p1, p2 = t(rgb), t(depth), t(K), t(T1), t(T2)
+    frame = (rgb.transpose(1, 2, 0) * 255).astype(np.float64)
+    f64 = lambda a: a.astype(np.float64)
+    out["W1_forward_warp_576x1024"] = dict(
+        cpu_port_s=round(host_s(lambda: WO.forward_warp(frame, None, f64(depth), f64(T1), f64(T2), f64(K), None)), 3),
+        gpu_device_us=round(dev_us(lambda: forward_warp(frame, None, f64(depth), f64(T1), f64(T2), f64(K), None)), 1))
+    out["W2_inverse_warp_576x1024"] = dict(
+        cpu_port_s=round(host_s(lambda: WO.inverse_warp(rgb, depth, depth, T1, T2, K, 20)), 3),
+        gpu_device_us=round(dev_us(lambda: inverse_warp(img, d[None], d[None], p1, p2, k, bandwidth=20)), 1))
+    out["C1_consistency_check_576x1024"] = dict(
+        cpu_port_s=round(host_s(lambda: WO.consistency_check_with_depth(depth, T2, K, depth, T1, K)), 3),
+        gpu_device_us=round(dev_us(lambda: consistency_check_with_depth(d, p2, k, d, p1, k)), 1))
+    c = GI.sched_case("full_f16")
+    sch = EulerDiscreteScheduler(**SVD_XT_SCHEDULER_CONFIG)
+    sch.set_timesteps(100)
+    sig, i = sch.sigmas.numpy(), c["step_i"]
+    g = {n: t(c[n]) for n in ("model_output", "sample", "temp_cond", "mask")}
+    lam = torch.from_numpy(c["lambda_ts"])
+    ts = sch.timesteps[i]
+    for name, grad in (("S2_step_interp_grad", True), ("S2_step_interp", False)):
+        out[name + "_25x4x72x128"] = dict(
+            cpu_port_s=round(host_s(lambda: SO.step_interp(c["model_output"], c["sample"], c["temp_cond"], c["mask"], c["lambda_ts"][i], sig, i,
+                                                           lr=0.02, compute_grad=grad)), 3),
+            gpu_device_us=round(dev_us(lambda: sch.step_interp(g["model_output"], ts, g["sample"], g["temp_cond"], g["mask"], lam, step_i=i,
+                                                               lr=0.02, compute_grad=grad)), 1))
+    out["S3_step_interp_prob_uncertain_25x4x72x128"] = dict(
+        cpu_port_s=round(host_s(lambda: SO.step_interp_prob_uncertain(c["model_output"], c["sample"], c["temp_cond"], c["mask"],
+                                                                      c["lambda_ts"][i], sig, i)), 3),
+        gpu_device_us=round(dev_us(lambda: sch.step_interp_prob_uncertain(g["model_output"], ts, g["sample"], g["temp_cond"], g["mask"], lam,
+                                                                          step_i=i)), 1))
+    out["note"] = ("cpu_port_s: oracle/warp_oracle.py / oracle/scheduler_oracle.py (numpy, one run each, host cores as numpy uses them); "
+                   "gpu_device_us: sum of kernel time of the HIP path on the same inputs.  Reference-run timings of the same functions "
+                   "in the build container (8 cores): BASELINE.md section 3")
+    return out
+
+
 def cpu_baseline(args, with_unet: bool):
     """Composite CPU figure in the headline's unit: raster iterations per second of the same block
     (raster_iters raster iterations + one SVD unit), from the two bounded oracle samples."""
@@ -280,23 +355,47 @@ def sub_benchmarks(args, dev, loop_a, loop_b, log):
         from syn3r_amd.pipeline.svd_step import SvdStepBench
         out["svd_post_unit_f14_ms"] = round(wall_ms(loop_b.step_pass_post, 3), 2)
         b25 = SvdStepBench(25, dev, seed=args.seed, unet=loop_b.unet)
-        out["svd_replace_unit_f25_ms"] = round(wall_ms(b25.step_pass, 3), 2)
-        out["svd_post_unit_f25_ms"] = round(wall_ms(b25.step_pass_post, 3), 2)
-        # one svd_render = 100 denoise steps x 2 passes of the unit
-        out["svd_render_f25_s"] = {"replace": round(0.2 * out["svd_replace_unit_f25_ms"], 1), "post": round(0.2 * out["svd_post_unit_f25_ms"], 1)}
+        # (step, pass) units at F = 25 the way the pipelines run them: both passes of a step stacked into one UNet launch
+        # sequence (merge_passes) = 2 units per call; the pass-by-pass figures beside them
+        out["svd_replace_unit_f25_ms"] = round(wall_ms(lambda: b25.step_both("replace"), 3) / 2, 2)
+        out["svd_post_unit_f25_ms"] = round(wall_ms(lambda: b25.step_both("post"), 3) / 2, 2)
+        out["svd_unit_f25_pass_by_pass_ms"] = {"replace": round(wall_ms(b25.step_pass, 3), 2), "post": round(wall_ms(b25.step_pass_post, 3), 2)}
         del b25
         torch.cuda.empty_cache()
         log("sub-benchmarks: SVD units done")
     out["raster_full_iteration_per_s"] = round(loop_a.full_iteration_rate(50), 1)
     out["raster_full_iteration_note"] = "render + (0.8 L1 + 0.2 (1-SSIM)) + backward + fused Adam on 5 parameter groups, no host sync"
-    if "svd_render_f25_s" in out:
-        # SURVEY 8d composite: the fern-like schedule 10 k iterations + 2 x (3 svd_render + 10 k iterations), DERIVED from the
-        # two measured rates above (complete trainer iterations; svd_render = 200 units at F = 25), not run end to end
-        it_s = 30000.0 / out["raster_full_iteration_per_s"]
-        out["fern_like_schedule_s"] = {"derived_from": "30000 / raster_full_iteration_per_s + 6 x svd_render_f25_s",
-                                       "raster_30k_iterations": round(it_s, 1),
-                                       "replace": round(it_s + 6 * out["svd_render_f25_s"]["replace"], 1),
-                                       "post": round(it_s + 6 * out["svd_render_f25_s"]["post"], 1)}
+    if loop_b is not None and not args.no_end_to_end:
+        # MEASURED end to end (syn3r_amd/measure.py): one full-size svd_render per variant (26 VAE encodes, 100 steps x 2 passes
+        # at F = 25, chunked decode: SVD_2pass_prob_uncertain_post.py:544-848) and a scaled schedule through DiffusionGS.run
+        # (500 + 500 trainer iterations around ONE densified view pair, model/diffusionGS.py:1668-1697)
+        import tempfile
+        from syn3r_amd import measure as M
+        comps = M.full_size_components(dev, unet=loop_b.unet, seed=args.seed)
+        out["denoise_host_gap"] = {v: M.measure_denoise_gap(comps, v, dev) for v in ("replace", "post")}
+        rep = M.measure_svd_render(comps, "replace", dev, steps=args.e2e_steps)
+        log(f"sub-benchmarks: measured svd_render (replace): {rep['wall_s']} s")
+        with tempfile.TemporaryDirectory() as tmp:
+            sched = M.measure_schedule(comps, dev, tmp, variant="post", N=args.gaussians, H=args.height, W=args.width,
+                                       iterations=500, steps=args.e2e_steps, seed=args.seed)
+        log(f"sub-benchmarks: measured schedule (post): {sched['wall_s']} s")
+        out["svd_render_f25_s"] = {"measured": True, "steps": args.e2e_steps, "replace": rep["wall_s"], "post": sched["svd_render_s"],
+                                   "replace_stages": {k: rep[k] for k in ("vae_encode_s", "denoise_s", "vae_decode_s", "denoise_ms_per_step_pass")},
+                                   "note": "wall-clock of StableVideoDiffusionPipeline.__call__ with the HIP VAE and UNet (seeded weights); "
+                                           "'post' is the call DiffusionGS.svd_render made inside schedule_scaled"}
+        out["schedule_scaled"] = sched
+        # the fern-like schedule 10 k + 2 x (3 view pairs + 10 k), from the MEASURED stage rates of the scaled run
+        # (trainer iterations/s inside training()/finetune(), one whole view pair incl. its svd_render) and, beside it, the
+        # round-2 derivation from the isolated unit rates
+        it_s = 30000.0 / sched["trainer_iters_per_s"]
+        out["fern_like_schedule_s"] = {
+            "from_measured_stages": {"raster_30k_iterations": round(it_s, 1), "post": round(it_s + 6 * sched["view_pair_s"], 1),
+                                     "replace": round(it_s + 6 * (sched["view_pair_s"] - sched["svd_render_s"] + rep["wall_s"]), 1)},
+            "derived_from_unit_rates": {"formula": "30000 / raster_full_iteration_per_s + 6 x 200 x unit_f25_ms",
+                                        "replace": round(30000.0 / out["raster_full_iteration_per_s"] + 1.2 * out["svd_replace_unit_f25_ms"], 1),
+                                        "post": round(30000.0 / out["raster_full_iteration_per_s"] + 1.2 * out["svd_post_unit_f25_ms"], 1)}}
+        del comps
+        torch.cuda.empty_cache()
     # fused inverse warp + reprojection consistency (W2 + C1) at the reference's 576x1024 working size
     from syn3r_amd.solver_utils.forward_warp import inverse_warp
     H, W = 576, 1024
@@ -448,6 +547,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 of the single-GPU run only
             log("cpu baseline (oracle on the host cores, bounded sample) ...")
             out["cpu_baseline"] = cpu_baseline(args, loop_b is not None)
+            out["cpu_baseline"]["sample_note"] = ("thin samples: ONE oracle run per leg (raster at 1/4 of the pixels, UNet at 1/84 of the "
+                                                  "tokens), extrapolated linearly; kind 'port' because reference Python does not travel to the GPU box")
+            out["cpu_baseline"]["geometry_and_scheduler"] = cpu_baseline_geometry_scheduler(dev)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
