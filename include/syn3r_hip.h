@@ -52,6 +52,8 @@ const char* syn3r_arch(void);
  * syn3r_trace_report synchronises them, writes one "kernel calls total_ms"
  * line per kernel into buf and clears the trace.  on = 2 additionally puts
  * the contraction shape into the kernel name (per-shape tuning tables).
+ * The switch, the filter and the recorded spans belong to the CALLING THREAD
+ * (thread-local): a thread traces and reports its own launches only.
  */
 int syn3r_trace_enable(int on);
 /* restrict the tracer to kernels whose name contains one of the comma-separated substrings ("" = all):
@@ -296,9 +298,10 @@ int syn3r_gemm_2src_supported(int M, int N, int K1, int K2, long long lda1, long
 int syn3r_gemm_2src_f16(const void* A1, long long lda1, int K1, const void* A2, long long lda2, int K2, const void* W,
                         void* out, long long ldc, const void* bias, int M, int N, void* stream);
 
-/* Tuning / test hook: 0 = library default (kernel chosen per shape); 128 / 256 = register-staged kernel of that
- * block height; -128 / -256 = LDS-DMA kernel of that block height; -320 = the 256 x 320 wide-tile LDS-DMA kernel;
- * -321 = its 128 x 320 two-blocks-per-CU variant (dense contractions; the convolutions keep the default). */
+/* Test / tuning hook, PER CALLING THREAD (thread-local: the library holds no state shared between host threads): the
+ * contraction kernel family this thread's next launches use.  0 = chosen per shape (default); -128 / -256 = the 160-column
+ * LDS-DMA kernel of that block height; -320 = the persistent 256 x 320 kernel wherever it admits the shape; -321 = the
+ * 128 x 320 two-blocks-per-CU kernel (dense contractions; the convolutions keep the default). */
 int syn3r_gemm_set_tile(int bm);
 
 /*

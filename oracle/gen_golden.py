@@ -215,6 +215,32 @@ def gen_vae():
     np.savez_compressed(GOLD / "vae_small.npz", **out)
 
 
+def gen_vae_full():
+    """The REFERENCE AutoencoderKLTemporalDecoder in the SVD-XT configuration (97.7 M parameters), CPU fp32, at the
+    pipelines' size: one encode at 576x1024 (autoencoder_kl_temporal_decoder.py:317-343) and a 2-frame decode from 72x128
+    latents (:345-370); the decoded frames are stored every 8th pixel.  A few minutes of CPU."""
+    import time
+    from diffusers.models import AutoencoderKLTemporalDecoder
+    from oracle import unet_weights as UW
+    from oracle import vae_weights as VW
+    model = AutoencoderKLTemporalDecoder(**VW.FULL_VAE_CONFIG)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(UW.make_state_dict(shapes, seed=13))
+    model.eval()
+    out = {}
+    st = VW.FULL_VAE_STRIDE
+    with torch.no_grad():
+        t0 = time.time()
+        out["moments"] = model.encode(VW.make_full_image()).latent_dist.parameters.numpy()
+        print(f"vae_full encode {time.time() - t0:.0f} s", flush=True)
+        t0 = time.time()
+        out["decoded_f2"] = model.decode(VW.make_full_latents(), num_frames=2).sample.numpy()[..., ::st, ::st]
+        print(f"vae_full decode {time.time() - t0:.0f} s", flush=True)
+    for k in out:
+        print("vae_full", k, out[k].shape, float(np.abs(out[k]).mean()), float(out[k].std()))
+    np.savez_compressed(GOLD / "vae_full.npz", **out)
+
+
 def gen_pipeline():
     """Run the REFERENCE pipeline classes' own __call__ (both variants) on the CPU with mock CLIP / VAE /
     UNet (oracle/pipeline_mocks.py), 3 denoise steps, output_type='latent'."""
@@ -593,6 +619,8 @@ def main():
         gen_unet_full([w for w in which if w in UNET_FULL_CASES] or None)
     if "vae" in which:
         gen_vae()
+    if "vae_full" in which:               # a few minutes of CPU: not part of the default set
+        gen_vae_full()
     if "warp" in which:
         gen_warp(consistency, forward_warp, inverse_warp)
     if "sched" in which:

@@ -17,20 +17,20 @@ extern "C" int syn3r_version(void) { return 100; }
 extern "C" const char* syn3r_arch(void) { return "gfx950"; }
 
 // ---------------------------------------------------------------- kernel tracer
+// State is PER CALLING THREAD (thread_local): a thread that enables tracing times ITS OWN launches and reads its own
+// report; other threads' launches are untouched (no global mutable state, no lock on the launch path).
 #include <map>
 #include <string>
 #include <vector>
-#include <mutex>
 
 namespace syn3r {
 namespace {
 struct Span { std::string name; hipEvent_t a, b; };
-std::mutex g_mu;
-bool g_on = false;
-bool g_detail = false;
-std::string g_filter;   // comma-separated substrings; empty = every kernel
-std::vector<Span> g_spans;
-std::vector<hipEvent_t> g_pool;
+thread_local bool g_on = false;
+thread_local bool g_detail = false;
+thread_local std::string g_filter;   // comma-separated substrings; empty = every kernel
+thread_local std::vector<Span> g_spans;
+thread_local std::vector<hipEvent_t> g_pool;
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e;
@@ -53,7 +53,6 @@ static bool wanted(const char* name) {
     return false;
 }
 bool trace_open(const char* name, hipEvent_t* start, hipEvent_t* stop) {
-    std::lock_guard<std::mutex> lk(g_mu);
     if (!wanted(name)) return false;
     Span s{name, get_event(), get_event()};
     *start = s.a;
@@ -64,14 +63,12 @@ bool trace_open(const char* name, hipEvent_t* start, hipEvent_t* stop) {
 }  // namespace syn3r
 
 extern "C" int syn3r_trace_enable(int on) {
-    std::lock_guard<std::mutex> lk(syn3r::g_mu);
     syn3r::g_on = on != 0;
     syn3r::g_detail = on == 2;
     return SYN3R_OK;
 }
 
 extern "C" int syn3r_trace_filter(const char* substrings) {
-    std::lock_guard<std::mutex> lk(syn3r::g_mu);
     syn3r::g_filter = substrings ? substrings : "";
     return SYN3R_OK;
 }
@@ -79,7 +76,6 @@ extern "C" int syn3r_trace_filter(const char* substrings) {
 // Synchronises the recorded events, aggregates per kernel name and writes
 // "name calls total_ms\n" lines into buf (truncated to cap); clears the trace.
 extern "C" int syn3r_trace_report(char* buf, size_t cap) {
-    std::lock_guard<std::mutex> lk(syn3r::g_mu);
     std::map<std::string, std::pair<long long, double>> agg;
     for (auto& s : syn3r::g_spans) {
         float ms = 0.f;

@@ -17,12 +17,10 @@
 // per shape by launch_dma (DESIGN.md section 4 has the measurements behind every rule):
 //   k_gemm_widep   persistent 256 x 320 tile (dense contractions whose tiles fill the CUs): LDS-DMA 2-stage ring,
 //                  cross-tile prefetch, scalar addressing, lean epilogue, GEGLU gate in registers, two-source A
-//   k_gemm_wide    the same tile, one tile per block (convolution modes, ragged M / N, forced by syn3r_gemm_set_tile)
 //   k_gemm_w128    128 x 320 tile, two blocks per CU (K <= 320 with N > 640: the level-0 qkv projection)
 //   k_ffn320       FeedForward (GEGLU) for C = 320 in one kernel, hidden activation never leaves the CU
 //   k_gemm_dma     BM x 160 tile, LDS-DMA 3-stage ring (BM = 256, wavefronts 4-7 staggered; every convolution /
 //                  temporal convolution and the K = 320 residual projections) or 2-stage (BM = 128, small grids)
-//   k_gemm         register-staged double-buffered variant of k_gemm_dma, kept for tuning (syn3r_gemm_set_tile)
 //   k_gemm_skinny  M <= 16 rows (time embedding, folded cross-attention context)
 #include "common.h"
 #include <cstdlib>
@@ -260,160 +258,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
     }
 }
 
-template <int MODE, int BM>
-__global__ void __launch_bounds__(BM * 2, 2) k_gemm(GemmParams p) {
-    constexpr int NTHREADS = BM * 2;
-    constexpr int A_TILE = BM * BK;
-    constexpr int RSTEP = NTHREADS / 8;             // rows covered by one staging sweep
-    constexpr int B_ITERS = (BN * 8 + NTHREADS - 1) / NTHREADS;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    __half* As = (__half*)smem_raw;                 // [2][BM][BK]
-    __half* Bs = As + 2 * A_TILE;                   // [2][BN][BK]
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const unsigned bid = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
-    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;   // N-tiles of one M-tile adjacent
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // ---- per-thread staging assignment
-    const int a_chunk = tid & 7;
-    const int a_row0 = tid >> 3;                    // rows a_row0 + RSTEP*i, i = 0..3
-    long long a_off[4];                             // dense: element offset of the row; conv: pixel index pieces
-    int a_n[4], a_y[4], a_x[4];                     // conv: sample / output y / output x ; tconv: frame index in a_y
-    bool a_ok[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = m0 + a_row0 + RSTEP * i;
-        a_ok[i] = m < p.M;
-        int mc = a_ok[i] ? m : p.M - 1;
-        if constexpr (MODE == MODE_DENSE) {
-            a_off[i] = (long long)mc * p.lda;
-            a_n[i] = a_y[i] = a_x[i] = 0;
-        } else if constexpr (MODE == MODE_CONV2D) {
-            int hw = p.Ho * p.Wo;
-            a_n[i] = mc / hw;
-            int r = mc - a_n[i] * hw;
-            a_y[i] = r / p.Wo;
-            a_x[i] = r - a_y[i] * p.Wo;
-            a_off[i] = 0;
-        } else {
-            int fi = (mc / p.HW) % p.F;
-            a_y[i] = fi;
-            a_n[i] = a_x[i] = 0;
-            a_off[i] = (long long)mc * p.Cin;
-        }
-    }
-    const int b_chunk = tid & 7;
-    long long b_off[B_ITERS];
-    bool b_ok[B_ITERS];
-#pragma unroll
-    for (int i = 0; i < B_ITERS; ++i) {
-        int q = tid + NTHREADS * i;
-        int row = q >> 3;
-        b_ok[i] = (q < BN * 8);
-        int n = n0 + row;
-        bool in = b_ok[i] && n < p.N;
-        b_off[i] = (long long)(in ? n : (p.N - 1)) * p.K;
-        if (!in && b_ok[i]) b_off[i] = -1;          // zero-fill rows beyond N
-    }
-
-    const int nkt = p.K / BK;
-    const int cpb = (MODE == MODE_DENSE) ? 1 : p.Cin / BK;   // k-tiles per tap
-
-    u32x4 ra[4], rb[B_ITERS];
-    auto load_tile = [&](int kt) {
-        const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
-        if constexpr (MODE == MODE_DENSE) {
-            const int k0 = kt * BK + a_chunk * 8;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = *(const u32x4*)(p.A + a_off[i] + k0);
-        } else if constexpr (MODE == MODE_CONV2D) {
-            const int tap = kt / cpb, c0 = (kt - tap * cpb) * BK + a_chunk * 8;
-            const int dy = tap / 3 - p.pad, dx = tap % 3 - p.pad;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int yy = a_y[i] * p.stride + dy, xx = a_x[i] * p.stride + dx;
-                // bounds on the (possibly upsampled) input grid
-                int Hg = p.ups ? p.Hi * 2 : p.Hi, Wg = p.ups ? p.Wi * 2 : p.Wi;
-                bool ok = yy >= 0 && yy < Hg && xx >= 0 && xx < Wg;
-                if (p.ups) { yy >>= 1; xx >>= 1; }
-                long long off = (((long long)a_n[i] * p.Hi + yy) * p.Wi + xx) * p.Cin + c0;
-                ra[i] = ok ? *(const u32x4*)(p.A + off) : z;
-            }
-        } else {
-            const int tap = kt / cpb, c0 = (kt - tap * cpb) * BK + a_chunk * 8;
-            const int df = tap - 1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int ff = a_y[i] + df;
-                bool ok = ff >= 0 && ff < p.F;
-                long long off = a_off[i] + (long long)df * p.HW * p.Cin + c0;
-                ra[i] = ok ? *(const u32x4*)(p.A + off) : z;
-            }
-        }
-        const int kb = kt * BK + b_chunk * 8;
-#pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) {
-            if (b_ok[i]) rb[i] = (b_off[i] >= 0) ? *(const u32x4*)(p.W + b_off[i] + kb) : z;
-        }
-    };
-    auto store_tile = [&](int buf) {
-        __half* as = As + buf * A_TILE;
-        __half* bs = Bs + buf * B_TILE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *(u32x4*)(as + swz(a_row0 + RSTEP * i, a_chunk)) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) {
-            int q = tid + NTHREADS * i;
-            if (b_ok[i]) *(u32x4*)(bs + swz(q >> 3, b_chunk)) = rb[i];
-        }
-    };
-
-    float4v acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
-
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
-        const __half* as = As + cur * A_TILE + (wm * WM) * BK;
-        const __half* bs = Bs + cur * B_TILE + (wn * WN) * BK;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            half8 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                int row = i * 16 + fr;
-                af[i] = *(const half8*)(as + row * BK + (((ks * 4 + fq) ^ (row & 7)) << 3));
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                int row = j * 16 + fr;
-                bf[j] = *(const half8*)(bs + row * BK + (((ks * 4 + fq) ^ (row & 7)) << 3));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nkt) store_tile(cur ^ 1);
-        __syncthreads();
-    }
-
-    gemm_epilogue(p, acc, smem_raw, lane, wv, wm, wn, m0, n0, tile_n);
-}
-
 // ---------------------------------------------------------------------------------------------
 // LDS-DMA pipelined variant (default).  global_load_lds (16 B per lane, per-lane source address = an
 // im2col gather for the convolutions, a zero page for padding / out-of-range rows) writes straight into a
@@ -571,7 +415,7 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
     const unsigned sw0 = (unsigned)(((0 + fq) ^ (fr & 7)) << 4), sw1 = (unsigned)(((4 + fq) ^ (fr & 7)) << 4);
 
     // BM = 256 (two wavefronts per SIMD behind one barrier): wavefronts 4-7 defer every stage's second MFMA group past
-    // the next barrier (stagger, see k_gemm_wide): they multiply while their SIMD partners issue DMA and read fragments.
+    // the next barrier (stagger: DESIGN.md section 4, round 2): they multiply while their SIMD partners issue DMA and read fragments.
     half8 a0[TM], b0[TN], a1[TM], b1[TN];
     const bool defer = (BM == 256) && wv >= 4;
     auto mma1 = [&]() {
@@ -633,14 +477,16 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wide-tile variant: 256 x 320 output tile, 512 threads, ONE block per CU, wavefront tile 64 x 160
+// Wide tile: 256 x 320 output tile, 512 threads, ONE block per CU, wavefront tile 64 x 160
 // (4 x 10 MFMA tiles = 160 accumulator registers).  Against the 128 x 160 blocks it halves the L2->LDS bytes
 // per FLOP (N = 320 is one tile: A is read exactly once) and issues 0.35 instead of 0.45 fragment reads per
 // MFMA; the price is one wave-pair per SIMD and no second block to hide a tile's prologue and epilogue, so it
 // is selected per shape (launch_dma).  2-stage LDS ring of 73,728-byte stages, one barrier per k-tile, the
 // fragments of a k-half are read into the SAME registers after the 40 MFMAs of the previous half have issued
 // (the partner wavefront on the SIMD covers the read latency).  The GEGLU pair [80 hidden | 80 gate] of a
-// 160-column group lives in one wavefront, so the gate is applied in registers.
+// 160-column group lives in one wavefront, so the gate is applied in registers.  (Rounds 1-2 also carried a
+// one-tile-per-block form of this tile, k_gemm_wide; the persistent form below superseded it on every shape and the
+// shapes it does not admit go to the 160-column kernels.)
 constexpr int WBM = 256, WBN = 320, WTN = 10;
 constexpr int W_A_BYTES = WBM * BK * 2;                      // 32,768
 constexpr int W_B_BYTES = WBN * BK * 2;                      // 40,960
@@ -649,221 +495,6 @@ constexpr int W_STAGE = W_A_BYTES + W_B_BYTES;               // 73,728
 #ifdef SYN3R_TIMING
 __device__ unsigned long long g_wide_timing[64];
 #endif
-
-template <int MODE>
-__global__ void __launch_bounds__(512, 2) k_gemm_wide(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv >> 1, wn = wv & 1;
-    const int Ncols = p.geglu_D > 0 ? p.N : p.N;
-    const int tiles_n = (Ncols + WBN - 1) / WBN;
-    const int tiles_m = (p.M + WBM - 1) / WBM;
-    const unsigned bid = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
-    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
-    const int m0 = tile_m * WBM, n0 = tile_n * WBN;
-
-    // Addressing state is kept small (160 of the 256 registers are accumulators): per A piece the clamped row
-    // index and the running source pointer, per B piece the running pointer, and ONE bit mask of the pieces that
-    // advance (rows in range); the im2col decomposition of a row is redone at every tap change.
-    const int prow = lane >> 3;
-    const int csrc = (lane & 7) ^ prow;
-    const __half* zero = g_zero_page;
-    int a_m[4];
-    unsigned live = 0;                    // bit i: A piece i advances; bit 4 + j: B piece j advances
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = m0 + wv * 32 + i * 8 + prow;
-        a_m[i] = m < p.M ? m : p.M - 1;
-    }
-    const __half* b_cur[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        int n = n0 + (wv * 5 + j) * 8 + prow;
-        bool ok = n < p.N;
-        b_cur[j] = ok ? p.W + (long long)n * p.K + csrc * 8 : zero;
-        if (ok) live |= 16u << j;
-    }
-    const int cpb = (MODE == MODE_DENSE) ? 1 : p.Cin / BK;
-    const __half* a_cur[4];
-    int tap_next = 0, c_left = 0;
-    auto setup_tap = [&](int tap) {
-        live &= ~15u;
-        if constexpr (MODE == MODE_CONV2D) {
-            const int dy = tap / 3 - p.pad, dx = tap % 3 - p.pad;
-            const int Hg = p.ups ? p.Hi * 2 : p.Hi, Wg = p.ups ? p.Wi * 2 : p.Wi;
-            const int hw = p.Ho * p.Wo;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int an = a_m[i] / hw, r = a_m[i] - an * hw;
-                const int ay = r / p.Wo, ax = r - ay * p.Wo;
-                int yy = ay * p.stride + dy, xx = ax * p.stride + dx;
-                bool ok = yy >= 0 && yy < Hg && xx >= 0 && xx < Wg;
-                if (p.ups) { yy >>= 1; xx >>= 1; }
-                long long off = (((long long)an * p.Hi + yy) * p.Wi + xx) * p.Cin + csrc * 8;
-                a_cur[i] = ok ? p.A + off : zero;
-                if (ok) live |= 1u << i;
-            }
-        } else if constexpr (MODE == MODE_TCONV) {
-            const int df = tap - 1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int ff = (a_m[i] / p.HW) % p.F + df;
-                bool ok = ff >= 0 && ff < p.F;
-                a_cur[i] = ok ? p.A + ((long long)a_m[i] + (long long)df * p.HW) * p.Cin + csrc * 8 : zero;
-                if (ok) live |= 1u << i;
-            }
-        }
-    };
-    if constexpr (MODE == MODE_DENSE) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (p.a_tiled) {              // rows past the padded matrix re-read the last allocated row block
-                int m = m0 + wv * 32 + i * 8 + prow;
-                const int last_rb = (p.M + 127) >> 7;
-                int rb = m >> 7;
-                rb = rb < last_rb ? rb : last_rb - 1;
-                a_cur[i] = p.A + (long long)rb * (p.K >> 6) * 8192 + (m & 127) * 64 + csrc * 8;
-            } else {
-                a_cur[i] = p.A + (long long)a_m[i] * p.lda + csrc * 8;
-            }
-        }
-        live |= 15u;
-    }
-    const int a_step = (MODE == MODE_DENSE && p.a_tiled) ? 8192 : BK;   // halfs per k-tile
-    auto issue_stage = [&](int buf) {     // stages are issued in k order
-        char* st = smem_raw + buf * W_STAGE;
-        if constexpr (MODE != MODE_DENSE) {
-            if (c_left == 0) { setup_tap(tap_next); ++tap_next; c_left = cpb; }
-            --c_left;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)a_cur[i], (lds_void_t*)(st + (wv * 4 + i) * 1024), 16, 0, 0);
-            a_cur[i] += ((live >> i) & 1u) * a_step;
-        }
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)b_cur[j], (lds_void_t*)(st + W_A_BYTES + (wv * 5 + j) * 1024), 16, 0, 0);
-            b_cur[j] += ((live >> (4 + j)) & 1u) * BK;
-        }
-    };
-
-    float4v acc[2][TM][TN];               // [column half][row tile][column tile]: halves are 80 columns each
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[hh][i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
-
-    const int nkt = p.K / BK;
-    const int fr = lane & 15, fq = lane >> 4;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
-    const unsigned a_row = (unsigned)((wm * WM + fr) * 128);
-    const unsigned b_row = (unsigned)(W_A_BYTES + (wn * 160 + fr) * 128);
-    const unsigned swz[2] = {(unsigned)(((0 + fq) ^ (fr & 7)) << 4), (unsigned)(((4 + fq) ^ (fr & 7)) << 4)};
-
-    // -DSYN3R_TIMING (tools/wide_timing.py): per-wavefront s_memtime sums of the loop's segments for one block
-#ifdef SYN3R_TIMING
-    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#define TMARK(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsum[i] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define TMARK(i)
-#endif
-    // Stagger (MI355X_MICROARCH.md, "Two waves per SIMD", item 9): wavefronts w and w + 4 share a SIMD and run this
-    // same loop behind the same barrier, so unstaggered they issue their LDS-DMA, read their fragments and want the
-    // matrix pipe at the same moments (measured: ~700 of ~3500 cycles per k-tile with the pipe idle).  Wavefronts 4-7
-    // DEFER the second k-half's MFMAs of every stage past the next barrier (its fragments are in registers by then, so
-    // the slot is free as before): after a barrier they multiply while their partners issue DMA and read, and they
-    // issue DMA and read while the partners multiply.  Same arithmetic in the same order: results bit for bit unchanged.
-    half8 af[TM], bf[WTN];
-    const bool defer = wv >= 4;
-    auto read_half = [&](unsigned sb, int kh) {
-        const unsigned aa = sb + a_row + swz[kh], ba = sb + b_row + swz[kh];
-        DS_READ128(af[0], aa, 0); DS_READ128(af[1], aa, 2048); DS_READ128(af[2], aa, 4096); DS_READ128(af[3], aa, 6144);
-        DS_READ128(bf[0], ba, 0); DS_READ128(bf[1], ba, 2048); DS_READ128(bf[2], ba, 4096); DS_READ128(bf[3], ba, 6144);
-        DS_READ128(bf[4], ba, 8192); DS_READ128(bf[5], ba, 10240); DS_READ128(bf[6], ba, 12288); DS_READ128(bf[7], ba, 14336);
-        DS_READ128(bf[8], ba, 16384); DS_READ128(bf[9], ba, 18432);
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]),
-                       "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7]), "+v"(bf[8]), "+v"(bf[9]));
-    };
-    auto mma = [&]() {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < WTN; ++j)
-                acc[j / TN][i][j % TN] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[j / TN][i][j % TN], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);   // the next reads reuse af / bf: keep them behind these MFMAs
-    };
-    issue_stage(0);
-    int buf = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage kt (the only one in flight) has landed
-        TMARK(0);
-        __builtin_amdgcn_s_barrier();
-        TMARK(1);
-        if (defer && kt > 0) mma();                          // second k-half of stage kt-1 (deferred wavefronts)
-        if (kt + 1 < nkt) issue_stage(buf ^ 1);              // the slot every wavefront finished reading in iteration kt-1
-        TMARK(2);
-        const unsigned sb = lds0 + (unsigned)buf * W_STAGE;
-        read_half(sb, 0);
-        TMARK(3);
-        mma();
-        TMARK(4);
-        read_half(sb, 1);
-        TMARK(5);
-        if (!defer) mma();
-        TMARK(6);
-        buf ^= 1;
-    }
-    if (defer) mma();
-#ifdef SYN3R_TIMING
-    if (blockIdx.x == gridDim.x / 2 && lane == 0)
-        for (int i = 0; i < 8; ++i) g_wide_timing[wv * 8 + i] = tsum[i];
-#endif
-#undef TMARK
-    __syncthreads();   // every wavefront is done reading the ring before the epilogue reuses it
-
-    if (p.geglu_D > 0) {
-        // GEGLU.forward: hidden * gelu(gate) on the fp16-rounded projection output (activations.py); the wavefront's
-        // 160 columns are one packed group [80 hidden | 80 gate]
-        const int gn = n0 + wn * 160;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = gn + j * 16 + fq * 4;
-            float bh[4], bg[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                bh[r] = (p.bias && n + r < p.N) ? __half2float(p.bias[n + r]) : 0.f;
-                bg[r] = (p.bias && n + 80 + r < p.N) ? __half2float(p.bias[n + 80 + r]) : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {       // pairs: the gate is packed fp32 arithmetic (gelu_pk, common.h)
-                    const syn3r_f2 hv = (syn3r_f2){(float)(_Float16)(acc[0][i][j][r] + bh[r]), (float)(_Float16)(acc[0][i][j][r + 1] + bh[r + 1])};
-                    const syn3r_f2 gv = (syn3r_f2){(float)(_Float16)(acc[1][i][j][r] + bg[r]), (float)(_Float16)(acc[1][i][j][r + 1] + bg[r + 1])};
-#ifdef SYN3R_EXP_NOGATE        // timing experiments (wrong results): compile the gate / the output stores out
-                    const syn3r_f2 y = hv + gv;
-#else
-                    const syn3r_f2 y = hv * gelu_pk(gv);
-#endif
-                    acc[0][i][j][r] = y.x; acc[0][i][j][r + 1] = y.y;
-                }
-        }
-        GemmParams q = p;
-        q.bias = nullptr; q.rowvec = nullptr; q.residual = nullptr; q.aux = nullptr; q.s_acc = 1.0f;
-        q.N = p.geglu_D; q.geglu_D = 0;
-        gemm_epilogue<0>(q, acc[0], smem_raw, lane, wv, wm, wn, m0, tile_n * 160, tile_n);
-        return;
-    }
-    // (no residual prefetch here: with the other half's 80 accumulators live it would spill)
-    gemm_epilogue<0>(p, acc[0], smem_raw, lane, wv, wm, wn * 2, m0, n0, tile_n);
-    __builtin_amdgcn_wave_barrier();     // a wavefront's staging area is its own: program order is enough
-    gemm_epilogue<0>(p, acc[1], smem_raw, lane, wv, wm, wn * 2 + 1, m0, n0, tile_n);
-}
 
 // ---------------------------------------------------------------------------------------------
 // PERSISTENT form of the 256 x 320 tile (dense contractions with M and N multiples of 8: every UNet projection).
@@ -1069,7 +700,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_widep(GemmParams p) {
     const int nkt = p.K / BK;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
     unsigned a_row = 0, b_row = 0, swz[2] = {0, 0};
-    const bool defer = wv >= 4;           // stagger of the SIMD partners, as in k_gemm_wide
+    const bool defer = wv >= 4;           // stagger of the SIMD partners, as in k_gemm_dma
     // Cross-tile prefetch: every tile starts in ring slot 0, so with an even k-tile count the last k-tile sits in
     // slot 1 and slot 0 is free for the next tile's stage 0, while slot 1 plus the 16 KB behind the ring are exactly
     // the 90,112 bytes the epilogue stages the accumulators through.  Odd counts issue after the epilogue.
@@ -1368,7 +999,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_dmap(GemmParams p) {
     const unsigned a_row = (unsigned)((wm * WM + fr) * 128);
     const unsigned b_row = (unsigned)(DMA_A_BYTES + (wn * WN + fr) * 128);
     const unsigned sw0 = (unsigned)(((0 + fq) ^ (fr & 7)) << 4), sw1 = (unsigned)(((4 + fq) ^ (fr & 7)) << 4);
-    const bool defer = wv >= 4;           // stagger of the SIMD partners (see k_gemm_wide)
+    const bool defer = wv >= 4;           // stagger of the SIMD partners (see k_gemm_widep)
 
     int issued = 0, consumed = 0;         // stages requested / stages whose k-tile has been multiplied (wave-uniform)
     if (issue_next()) ++issued;
@@ -1545,7 +1176,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_w128(GemmParams p) {
     __syncthreads();   // every wavefront is done reading the ring before the epilogue reuses it
 
     if (p.geglu_D > 0) {
-        // GEGLU.forward as in k_gemm_wide: the wavefront's 160 columns are one packed group [80 hidden | 80 gate]
+        // GEGLU.forward: the wavefront's 160 columns are one packed group [80 hidden | 80 gate]
         const int gn = n0 + wn * 160;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -1893,37 +1524,20 @@ int launch_widep(const GemmParams& p, hipStream_t stream) {
     return SYN3R_OK;
 }
 
-template <int MODE>
-int launch_wide(const GemmParams& p, hipStream_t stream) {
-    if constexpr (MODE == MODE_DENSE) {
-        static int pers_env = -2;       // SYN3R_WIDE_PERSISTENT=0: the one-tile-per-block kernel (tuning)
-        if (pers_env == -2) { const char* e = getenv("SYN3R_WIDE_PERSISTENT"); pers_env = e ? atoi(e) : 1; }
-        const bool lean = (!p.rowvec || p.geglu_D <= 0) && (!p.aux || p.residual) && (p.geglu_D <= 0 || (p.geglu_D % 8 == 0 && p.s_acc == 1.0f));
-        const bool small = (p.a_tiled ? (long long)((p.M + 127) / 128) * 128 * p.K : (long long)p.M * p.lda) < (1ll << 31) &&
-                           (long long)p.N * p.K < (1ll << 31) &&      // 32-bit byte offsets inside the operands
-                           (!p.A2 || (long long)p.M * p.lda2 < (1ll << 31));
-        if (pers_env != 0 && lean && small && p.M % 8 == 0 && p.N % 8 == 0 && p.M >= 8 && p.N >= 8) return launch_widep(p, stream);
-    }
-    constexpr size_t lds = (size_t)2 * W_STAGE;   // 147,456 B
-    static_assert(8 * WM * EPI_LD * sizeof(__half) <= lds, "epilogue staging must fit in the ring");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_wide<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_wide)");
-        attr_set = true;
-    }
-    int tiles = ((p.M + WBM - 1) / WBM) * ((p.N + WBN - 1) / WBN);
-    char name[96];
-    if (trace_on()) {
-        if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_wide<%d>[M%d,N%d,K%d,e%d]", MODE, p.M, p.N, p.K, p.geglu_D > 0 ? 2 : (p.residual != nullptr));
-        else snprintf(name, sizeof(name), "k_gemm_wide<%d>", MODE);
-    }
-    SYN3R_LAUNCH_NAMED(name, (k_gemm_wide<MODE>), dim3(tiles), dim3(512), lds, stream, p);
-    SYN3R_LAUNCH_CHECK("gemm_wide launch");
-    return SYN3R_OK;
+// Does the persistent 256 x 320 kernel take this contraction?  Lean epilogue (no row vector together with a gate, aux only
+// with a residual, a gate of whole 16-byte chunks and s_acc = 1), 32-bit byte offsets inside the operands, M and N
+// multiples of 8.  Everything else goes to the 160-column kernels, whose epilogue is general.
+bool widep_admits(const GemmParams& p) {
+    const bool lean = (!p.rowvec || p.geglu_D <= 0) && (!p.aux || p.residual) && (p.geglu_D <= 0 || (p.geglu_D % 8 == 0 && p.s_acc == 1.0f));
+    const bool small = (p.a_tiled ? (long long)((p.M + 127) / 128) * 128 * p.K : (long long)p.M * p.lda) < (1ll << 31) &&
+                       (long long)p.N * p.K < (1ll << 31) && (!p.A2 || (long long)p.M * p.lda2 < (1ll << 31));
+    return lean && small && p.M % 8 == 0 && p.N % 8 == 0 && p.M >= 8 && p.N >= 8;
 }
 
-int g_dma_bm = 0;   // 0 = by shape; 128 / 256 forced (syn3r_gemm_set_tile(-128 / -256), tuning only)
+// Kernel family forced by the CALLING THREAD (syn3r_gemm_set_tile; tests and tuning tools): 0 = by shape, 128 / 256 = the
+// 160-column LDS-DMA kernel of that block height, -320 = the persistent 256 x 320 kernel wherever it admits the shape,
+// -321 = the 128 x 320 kernel.  thread_local: no state shared between host threads.
+thread_local int g_dma_bm = 0;
 
 template <int MODE>
 int launch_dmap(const GemmParams& p, hipStream_t stream) {
@@ -1984,20 +1598,21 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
     if (wide_env == -2) { const char* e = getenv("SYN3R_GEMM_WIDE"); wide_env = e ? atoi(e) : -1; }
     static int w128_env = -2;       // SYN3R_GEMM_W128: unset = by shape; 0 = never, 1 = wherever the wide tile would run (tuning)
     if (w128_env == -2) { const char* e = getenv("SYN3R_GEMM_W128"); w128_env = e ? atoi(e) : -1; }
+    const bool wide_ok = MODE == MODE_DENSE && widep_admits(p);
     if (g_dma_bm == -321) { if constexpr (MODE == MODE_DENSE) return launch_w128(p, stream); }   // syn3r_gemm_set_tile(-321)
-    if (g_dma_bm == -320) return launch_wide<MODE>(p, stream);       // forced by syn3r_gemm_set_tile(-320)
-    if (g_dma_bm == 0 && wide_env != 0) {
+    if (g_dma_bm == -320 && wide_ok) return launch_widep(p, stream);                              // syn3r_gemm_set_tile(-320)
+    if (g_dma_bm == 0 && wide_env != 0 && wide_ok) {
         // measured on MI355X inside the UNet (tools/gemm_ab.py, same box): the 256 x 320 tile is 7..14 % faster on
         // the dense contractions whenever its tiles fill the 256 CUs (last round >= 80 % full), except the
         // residual-add projections with K <= 320, whose time is their epilogue;
-        // the implicit-GEMM convolutions are within 3 % either way and keep the two-blocks-per-CU kernel
+        // the implicit-GEMM convolutions are within 3 % either way and keep the 160-column kernel
         const long long tiles = (long long)((p.M + WBM - 1) / WBM) * ((p.N + WBN - 1) / WBN);
         const long long rounds = (tiles + 255) / 256;
         const bool fills = tiles * 10 >= rounds * 256 * 8;
         // (round 2: with the persistent kernel's epilogue - row vector, all ten residual requests in flight at once - the
         // K = 640 / 1280 residual projections are 3..4 % faster on the wide tile; K = 320 stays 4 % slower there)
         const bool short_residual = p.residual != nullptr && p.K <= 320;
-        if (wide_env == 1 || (MODE == MODE_DENSE && fills && !short_residual)) {
+        if (wide_env == 1 || (fills && !short_residual)) {
             // K <= 320 (5 k-tiles): the tile's time is its gate and store tail, which a second block on the CU
             // overlaps: 128 x 320 blocks are 6 % faster on the L0 gated projection and 2 % on qkv; from K = 640 on
             // the 256-row tile's weight reuse wins (+1..12 %) (tools/gemm_ab.py SYN3R_GEMM_W128 0 1, same box); on the
@@ -2005,7 +1620,7 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
             // (round 2, persistent 256-row kernel with the lean epilogue: it now wins the K = 320 shapes of one or two tile
             // columns by 12..20 % and ties on qkv, N = 960, which stays here)
             if constexpr (MODE == MODE_DENSE) { if (w128_env == 1 || (w128_env != 0 && p.K <= 320 && p.N > 640)) return launch_w128(p, stream); }
-            return launch_wide<MODE>(p, stream);
+            return launch_widep(p, stream);
         }
     }
     // 256-row blocks (eight wavefronts, wavefronts 4-7 staggered by half a k-tile against their SIMD partners) against
@@ -2018,30 +1633,8 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
     return bm == 128 ? launch_dma_bm<MODE, 128>(p, stream) : launch_dma_bm<MODE, 256>(p, stream);
 }
 
-int g_tile_bm = 0;   // 0 = LDS-DMA kernel (default); 128 / 256 = register-staged kernel of that block height
-
-template <int MODE, int BM>
-int launch_bm(const GemmParams& p, hipStream_t stream) {
-    constexpr size_t lds = (size_t)2 * (BM * BK + B_TILE) * sizeof(__half);   // 106,496 B (BM 256) / 73,728 B (BM 128)
-    static_assert((BM / 64) * 2 * WM * EPI_LD * sizeof(__half) <= lds, "epilogue staging must fit in the tile buffers");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm<MODE, BM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
-        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm)");
-        attr_set = true;
-    }
-    int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    SYN3R_LAUNCH((k_gemm<MODE, BM>), dim3(tiles), dim3(BM * 2), lds, stream, p);
-    SYN3R_LAUNCH_CHECK("gemm launch");
-    return SYN3R_OK;
-}
-
 template <int MODE>
-int launch(const GemmParams& p, hipStream_t stream) {
-    if (g_tile_bm == 0) return launch_dma<MODE>(p, stream);
-    return g_tile_bm == 256 ? launch_bm<MODE, 256>(p, stream) : launch_bm<MODE, 128>(p, stream);
-}
+int launch(const GemmParams& p, hipStream_t stream) { return launch_dma<MODE>(p, stream); }
 
 int check_common(const GemmParams& p, const char* who) {
     SYN3R_REQUIRE(p.A && p.W && p.out, "%s: null operand", who);
@@ -2060,11 +1653,9 @@ int check_common(const GemmParams& p, const char* who) {
 }  // namespace
 
 extern "C" int syn3r_gemm_set_tile(int bm) {
-    SYN3R_REQUIRE(bm == 0 || bm == 128 || bm == 256 || bm == -128 || bm == -256 || bm == -320 || bm == -321,
-                  "gemm_set_tile: bm must be 0, +-128, +-256, -320 or -321");
-    if (bm == -320 || bm == -321) { g_tile_bm = 0; g_dma_bm = bm; }   // the 256 x 320 / 128 x 320 wide-tile LDS-DMA kernels
-    else if (bm < 0) { g_tile_bm = 0; g_dma_bm = -bm; }     // LDS-DMA kernel with a forced block height
-    else { g_tile_bm = bm; g_dma_bm = 0; }                  // 0: LDS-DMA by shape; > 0: register-staged kernel
+    SYN3R_REQUIRE(bm == 0 || bm == -128 || bm == -256 || bm == -320 || bm == -321,
+                  "gemm_set_tile: bm must be 0, -128, -256, -320 or -321");
+    g_dma_bm = (bm == -128 || bm == -256) ? -bm : bm;        // this thread's launches only (thread_local)
     return SYN3R_OK;
 }
 
@@ -2144,7 +1735,7 @@ extern "C" int syn3r_gemm_f16(const void* A, long long lda, const void* W, void*
     int rc = check_common(p, "gemm_f16");
     if (rc) return rc;
     SYN3R_REQUIRE(lda % 8 == 0 && lda >= K, "gemm_f16: lda=%lld must be >= K and a multiple of 8", lda);
-    if (M <= SKINNY_MAX_M && !p.rowvec && !p.residual && !p.aux && g_tile_bm == 0 && g_dma_bm == 0)
+    if (M <= SKINNY_MAX_M && !p.rowvec && !p.residual && !p.aux && g_dma_bm == 0)
         return launch_skinny(p, (hipStream_t)stream);
     return launch<MODE_DENSE>(p, (hipStream_t)stream);
 }
@@ -2195,7 +1786,6 @@ extern "C" int syn3r_feedforward_f16(const void* x, long long ldx, const void* w
     SYN3R_REQUIRE(x && w1_packed && b1_packed && w2 && out, "feedforward_f16: null operand");
     SYN3R_REQUIRE(M > 0 && D > 0 && D % BK == 0 && C_in > 0 && C_out > 0, "feedforward_f16: bad sizes M=%d D=%d C_in=%d C_out=%d (D must be a multiple of %d)",
                   M, D, C_in, C_out, BK);
-    SYN3R_REQUIRE(g_tile_bm == 0, "feedforward_f16: the register-staged tuning kernel does not read the tiled intermediate");
     const size_t need = syn3r_feedforward_workspace_bytes(M, D);
     if (!workspace || workspace_bytes < need) {
         set_error("feedforward_f16: workspace %zu < %zu", workspace_bytes, need);
@@ -2289,7 +1879,7 @@ extern "C" int syn3r_tconv3_f16(const void* X, const void* W, void* out, long lo
 }
 
 #ifdef SYN3R_TIMING
-// developer hook (tools/wide_timing.py): the segment sums the last k_gemm_wide launch left behind
+// developer hook (tools/wide_timing.py): the segment sums the last timed launch left behind
 extern "C" __attribute__((visibility("default"))) int syn3r_debug_wide_timing(unsigned long long* out64) {
     return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_wide_timing), sizeof(unsigned long long) * 64);
 }

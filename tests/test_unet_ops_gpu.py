@@ -209,13 +209,13 @@ def test_ops_reject_bad_input(gpu):
 @pytest.fixture
 def every_contraction_kernel():
     """Run a test body once per contraction kernel: the per-shape default and every forced variant of
-    `syn3r_gemm_set_tile` (register-staged 128/256, LDS-DMA 128/256, 256x320 and 128x320 wide tiles)."""
+    `syn3r_gemm_set_tile` (LDS-DMA 128/256, persistent 256x320 and 128x320 wide tiles)."""
     from syn3r_amd import _lib
     lib = _lib.load()
 
     def run(body):
         try:
-            for tile in (0, 128, 256, -128, -256, -320, -321):
+            for tile in (0, -128, -256, -320, -321):
                 _lib.check(lib.syn3r_gemm_set_tile(tile), "set_tile")
                 body(tile)
         finally:
