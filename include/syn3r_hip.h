@@ -52,10 +52,16 @@ const char* syn3r_arch(void);
  * syn3r_trace_report synchronises them, writes one "kernel calls total_ms"
  * line per kernel into buf and clears the trace.  on = 2 additionally puts
  * the contraction shape into the kernel name (per-shape tuning tables).
- * The switch, the filter and the recorded spans belong to the CALLING THREAD
- * (thread-local): a thread traces and reports its own launches only.
+ * The switch, the filter and the recorded spans form a SESSION owned by the
+ * thread that called syn3r_trace_enable; there is no process-wide switch.
+ * Another thread records into that session only after syn3r_trace_attach
+ * (session) with the pointer syn3r_trace_session() returned on the owner
+ * (NULL detaches) - e.g. PyTorch's autograd thread around a backward launch.
+ * syn3r_trace_report reports the calling thread's own session.
  */
 int syn3r_trace_enable(int on);
+void* syn3r_trace_session(void);
+int syn3r_trace_attach(void* session);
 /* restrict the tracer to kernels whose name contains one of the comma-separated substrings ("" = all):
  * two event records per launch cost a few microseconds, which matters for 30-microsecond kernels */
 int syn3r_trace_filter(const char* substrings);

@@ -34,6 +34,8 @@ SIGNATURES = {
     "syn3r_trace_enable": (c_i, [c_i]),
     "syn3r_trace_filter": (c_i, [C.c_char_p]),
     "syn3r_trace_report": (c_i, [C.c_char_p, c_sz]),
+    "syn3r_trace_session": (c_p, []),
+    "syn3r_trace_attach": (c_i, [c_p]),
     "syn3r_inverse_warp_workspace_bytes": (c_sz, [c_i]),
     "syn3r_inverse_warp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i,
                                  c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
@@ -192,6 +194,16 @@ def workspace(dev: torch.device, nbytes: int, tag: str = "") -> torch.Tensor:
     return buf
 
 
+_active_trace = None     # the session of the running `kernel_trace` block (a pointer), for threads that want to join it
+
+
+def join_active_trace() -> None:
+    """Called at the top of autograd `backward` functions (they run on PyTorch's autograd thread): record this thread's
+    launches into the trace session a `kernel_trace` block opened on another thread - or detach when none is open.  The
+    library itself keeps no process-wide trace switch (include/syn3r_hip.h)."""
+    load().syn3r_trace_attach(_active_trace)
+
+
 class kernel_trace:
     """Context manager: per-kernel HIP-event timing of everything launched inside.
     `.result` maps kernel name -> (calls, total_ms)."""
@@ -201,13 +213,18 @@ class kernel_trace:
         self.detail = detail    # contraction launches are reported per shape
 
     def __enter__(self):
-        load().syn3r_trace_filter(self.only.encode())
-        load().syn3r_trace_enable(2 if self.detail else 1)
+        global _active_trace
+        lib = load()
+        lib.syn3r_trace_filter(self.only.encode())
+        lib.syn3r_trace_enable(2 if self.detail else 1)
+        _active_trace = lib.syn3r_trace_session()       # other threads join with join_active_trace()
         self.result = {}
         return self
 
     def __exit__(self, *exc):
+        global _active_trace
         lib = load()
+        _active_trace = None
         lib.syn3r_trace_enable(0)
         buf = C.create_string_buffer(1 << 18)
         lib.syn3r_trace_report(buf, len(buf))

@@ -17,77 +17,107 @@ extern "C" int syn3r_version(void) { return 100; }
 extern "C" const char* syn3r_arch(void) { return "gfx950"; }
 
 // ---------------------------------------------------------------- kernel tracer
-// State is PER CALLING THREAD (thread_local): a thread that enables tracing times ITS OWN launches and reads its own
-// report; other threads' launches are untouched (no global mutable state, no lock on the launch path).
+// A trace SESSION (switch, filter, recorded spans) is an object owned by the thread that enabled tracing; which session a
+// thread's launches record into is a thread-local pointer.  There is no process-global switch: a thread that never
+// enabled or attached to a session is untouched by another thread's tracing.  A second thread joins a
+// session explicitly - syn3r_trace_attach(session) - which is how the launches PyTorch's autograd thread makes for the
+// rasteriser's backward reach the report of the thread that asked for the trace.
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
 namespace syn3r {
 namespace {
 struct Span { std::string name; hipEvent_t a, b; };
-thread_local bool g_on = false;
-thread_local bool g_detail = false;
-thread_local std::string g_filter;   // comma-separated substrings; empty = every kernel
-thread_local std::vector<Span> g_spans;
-thread_local std::vector<hipEvent_t> g_pool;
-hipEvent_t get_event() {
-    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
-    hipEvent_t e;
-    hipEventCreate(&e);
-    return e;
+struct Session {
+    std::mutex mu;                 // spans / pool: the owner and attached threads may launch concurrently
+    bool on = false, detail = false;
+    std::string filter;            // comma-separated substrings; empty = every kernel
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get_event() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    bool wanted(const char* name) const {
+        if (filter.empty()) return true;
+        size_t pos = 0;
+        while (pos <= filter.size()) {
+            size_t end = filter.find(',', pos);
+            if (end == std::string::npos) end = filter.size();
+            if (end > pos && strstr(name, filter.substr(pos, end - pos).c_str())) return true;
+            pos = end + 1;
+        }
+        return false;
+    }
+};
+thread_local std::unique_ptr<Session> tl_own;     // the session this thread created (lives as long as the thread)
+thread_local Session* tl_cur = nullptr;           // the session this thread's launches record into
+Session* own_session() {
+    if (!tl_own) tl_own.reset(new Session());
+    return tl_own.get();
 }
 }  // namespace
 
-bool trace_on() { return g_on; }
-bool trace_detail() { return g_detail; }
-static bool wanted(const char* name) {
-    if (g_filter.empty()) return true;
-    size_t pos = 0;
-    while (pos <= g_filter.size()) {
-        size_t end = g_filter.find(',', pos);
-        if (end == std::string::npos) end = g_filter.size();
-        if (end > pos && strstr(name, g_filter.substr(pos, end - pos).c_str())) return true;
-        pos = end + 1;
-    }
-    return false;
-}
+bool trace_on() { return tl_cur && tl_cur->on; }
+bool trace_detail() { return tl_cur && tl_cur->detail; }
 bool trace_open(const char* name, hipEvent_t* start, hipEvent_t* stop) {
-    if (!wanted(name)) return false;
-    Span s{name, get_event(), get_event()};
-    *start = s.a;
-    *stop = s.b;
-    g_spans.push_back(s);
+    Session* s = tl_cur;
+    if (!s) return false;
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!s->on || !s->wanted(name)) return false;
+    Span sp{name, s->get_event(), s->get_event()};
+    *start = sp.a;
+    *stop = sp.b;
+    s->spans.push_back(sp);
     return true;
 }
 }  // namespace syn3r
 
 extern "C" int syn3r_trace_enable(int on) {
-    syn3r::g_on = on != 0;
-    syn3r::g_detail = on == 2;
+    syn3r::Session* s = syn3r::own_session();
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->on = on != 0;
+    s->detail = on == 2;
+    syn3r::tl_cur = s;
     return SYN3R_OK;
 }
 
 extern "C" int syn3r_trace_filter(const char* substrings) {
-    syn3r::g_filter = substrings ? substrings : "";
+    syn3r::Session* s = syn3r::own_session();
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->filter = substrings ? substrings : "";
     return SYN3R_OK;
 }
 
-// Synchronises the recorded events, aggregates per kernel name and writes
+extern "C" void* syn3r_trace_session(void) { return syn3r::tl_cur; }
+
+extern "C" int syn3r_trace_attach(void* session) {
+    syn3r::tl_cur = (syn3r::Session*)session;       // null detaches
+    return SYN3R_OK;
+}
+
+// Synchronises the recorded events of the calling thread's OWN session, aggregates per kernel name and writes
 // "name calls total_ms\n" lines into buf (truncated to cap); clears the trace.
 extern "C" int syn3r_trace_report(char* buf, size_t cap) {
+    syn3r::Session* s = syn3r::own_session();
+    std::lock_guard<std::mutex> lk(s->mu);
     std::map<std::string, std::pair<long long, double>> agg;
-    for (auto& s : syn3r::g_spans) {
+    for (auto& sp : s->spans) {
         float ms = 0.f;
-        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
-            auto& e = agg[s.name];
+        if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            auto& e = agg[sp.name];
             e.first += 1;
             e.second += ms;
         }
-        syn3r::g_pool.push_back(s.a);
-        syn3r::g_pool.push_back(s.b);
+        s->pool.push_back(sp.a);
+        s->pool.push_back(sp.b);
     }
-    syn3r::g_spans.clear();
+    s->spans.clear();
     size_t off = 0;
     if (buf && cap) buf[0] = 0;
     for (auto& kv : agg) {

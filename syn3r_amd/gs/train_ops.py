@@ -29,6 +29,7 @@ class _L1Loss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_loss: torch.Tensor):
+        L.join_active_trace()
         image, target = ctx.saved_tensors
         lib = L.load()
         go = grad_loss.to(torch.float32).contiguous()
@@ -66,6 +67,7 @@ class _PhotoLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_loss: torch.Tensor, _grad_parts):
+        L.join_active_trace()
         image, target, ws = ctx.saved_tensors
         lam, weight = ctx.args
         C_, H_, W_ = image.shape

@@ -217,6 +217,7 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_color, g_radii, g_depth, g_alpha):
+        L.join_active_trace()        # autograd thread: record into the caller's kernel_trace session, if one is open
         m3, sc, ro, op, sh, cf, radii, geom, binning, image = ctx.saved_tensors
         s = ctx.settings
         lib = L.load()
