@@ -45,6 +45,20 @@ def _resize_nearest(x: np.ndarray, height: int, width: int) -> np.ndarray:
     return x[ys][:, xs]
 
 
+def _resize_linear_t(x: torch.Tensor, height: int, width: int) -> torch.Tensor:
+    """`_resize_linear` on a device tensor ([H,W] or [C,H,W]), result on the device."""
+    chw = x[None, None] if x.dim() == 2 else x[None]
+    out = torch.nn.functional.interpolate(chw.float(), size=(height, width), mode="bilinear", align_corners=False)
+    return out[0, 0] if x.dim() == 2 else out[0]
+
+
+def _resize_nearest_t(x: torch.Tensor, height: int, width: int) -> torch.Tensor:
+    """`_resize_nearest` on a device tensor [H,W] (same source-index rule)."""
+    ys = torch.from_numpy(np.minimum((np.arange(height) * (x.shape[0] / height)).astype(np.int64), x.shape[0] - 1)).to(x.device)
+    xs = torch.from_numpy(np.minimum((np.arange(width) * (x.shape[1] / width)).astype(np.int64), x.shape[1] - 1)).to(x.device)
+    return x.index_select(0, ys).index_select(1, xs)
+
+
 class DiffusionGS:
     def __init__(self, GSTrainer, num_input_views=12, save_dir=None, diffusion_type="2Pass", interp_type="forward_warp",
                  debug=False, input_args=None, svd_components: Optional[dict] = None, num_inference_steps: int = 100,
@@ -113,6 +127,18 @@ class DiffusionGS:
             return pose, image, depth, res["alpha"].detach().squeeze().cpu().numpy()
         return pose, image, depth
 
+    def _render_device(self, pose):
+        """`render_GS(pose=...)` without the host round trip: (render [3,H,W] in [0,1], depth [H,W]) as device tensors.
+        The reference copies every render to numpy (diffusionGS.py:168-169) and back (:1438-1441); with ~350 renders per
+        view pair at the scene's resolution those copies were most of the orchestrator's own time (tools/pair_profile.py)."""
+        tpl = self.get_TrainCameras()[0]
+        cam = Camera(colmap_id=-1, R=pose[:3, :3].T, T=pose[:3, 3], FoVx=tpl.FoVx, FoVy=tpl.FoVy, image=None,
+                     gt_alpha_mask=None, image_name=None, uid=None, data_device=self.device, cam_confidence=1.0)
+        cam.image_height, cam.image_width = self.gs_height, self.gs_width
+        with torch.no_grad():
+            res = self.gsTrainer.render_view(cam)
+        return res["render"].detach(), res["depth"].detach()[0]
+
     # ------------------------------------------------------------------ SVD side
     def svd_render(self, image_l, image_r, masks, cond_image, output_path, lambda_ts, num_frames=25, save_prefix=""):
         """diffusionGS.py:1088-1116.  The reference re-downloads the checkpoint by model name on every call; here the
@@ -135,18 +161,19 @@ class DiffusionGS:
         pose1, image1, depth1 = self.render_GS(idx1)
         pose2, image2, depth2 = self.render_GS(idx2)
         interpolated_poses = list(O.pose_interpolation(pose1, pose2))
-        render = lambda p: self.render_GS(pose=p)[1:]
         if perturb_interp_poses:
-            sel = O._perturb_and_select_interp_poses(
-                interpolated_poses, [pose1, pose2], K=self.gs_intrinsics,
-                render=lambda p: (render(p)[0].transpose(1, 2, 0), render(p)[1]), perturb_num=5, device=self.device)
+            sel = O._perturb_and_select_interp_poses(interpolated_poses, [pose1, pose2], K=self.gs_intrinsics,
+                                                     render=self._render_device, perturb_num=5, device=self.device)
             interpolated_poses = [pose1] + sel[1:-1] + [pose2]
         Hd, Wd = self.diffusion_height, self.diffusion_width
-        pseudo_images, pseudo_depths = [], []
-        for p in interpolated_poses:
-            _, im, dp = self.render_GS(pose=p)
-            pseudo_images.append(_resize_linear(im.transpose([1, 2, 0]), Hd, Wd))
-            pseudo_depths.append(_resize_linear(dp, Hd, Wd))
+        # the 25 pseudo-views at the diffusion resolution (cv2.resize INTER_LINEAR of render and depth, :800-805), kept on
+        # the device: HWC images / HW depths
+        pseudo_images, pseudo_depths, depth_dev = [], [], {}
+        for k, p in enumerate(interpolated_poses):
+            im, dp = self._render_device(p)
+            pseudo_images.append(_resize_linear_t(im, Hd, Wd).permute(1, 2, 0).contiguous())
+            pseudo_depths.append(_resize_linear_t(dp, Hd, Wd))
+            depth_dev[id(p)] = dp
         rs = lambda x: _resize_nearest(x, Hd, Wd)
         if self.interp_type == "forward_warp":
             return self._finish_forward_warp(interpolated_poses, image1, image2, depth1, depth2, pseudo_images, replace)
@@ -155,10 +182,10 @@ class DiffusionGS:
         # device tensors
         wd = O.warp_images_bw_device(
             self.diffusion_intrinsics, interpolated_poses, rs(image1), rs(image2), rs(depth1), rs(depth2),
-            render_depth=lambda p: _resize_nearest(self.render_GS(pose=p)[2], Hd, Wd), device=self.device,
+            render_depth=lambda p: _resize_nearest_t(depth_dev[id(p)], Hd, Wd), device=self.device,      # (rendered above)
             h=Hd // 8, w=Wd // 8)
         image_o, image_o2 = rs(image1) / 255.0, rs(image2) / 255.0
-        gs_images = np.stack(pseudo_images[1:-1])
+        gs_images = torch.stack(pseudo_images[1:-1])
         masks, cond_dev, _ = O.fuse_uncertainty_device(wd["cond_images_ori"], gs_images, wd["soft_masks_reproj_ori"],
                                                        h=Hd // 8, w=Wd // 8)
         masks = masks.cpu()
@@ -176,17 +203,19 @@ class DiffusionGS:
         n = len(frames)
         if replace:
             frames[0], frames[-1] = image_o, image_o2
-        out = []
-        for k, fr in enumerate(frames):
-            v = np.clip(np.asarray(fr) * 255.0, 0, 255)              # in the frame's own dtype, as the reference
+        def one(k):
+            v = np.clip(np.asarray(frames[k]) * 255.0, 0, 255)       # in the frame's own dtype, as the reference
             # diffused frames reach the reference as PIL images made by `(f * 255).round()` (tensor2vid / numpy_to_pil);
             # only the two replaced end frames are truncated, `(image_o * 255).astype(np.uint8)` (diffusionGS.py:909-911)
             u8 = v.astype(np.uint8) if (replace and k in (0, n - 1)) else np.rint(v).astype(np.uint8)
             im = PIL.Image.fromarray(u8)
             if (im.height, im.width) != (self.gs_height, self.gs_width):
                 im = im.resize((self.gs_width, self.gs_height))
-            out.append(torch.from_numpy(np.array(im)).permute(2, 0, 1) / 255.0)
-        return out
+            return torch.from_numpy(np.array(im)).permute(2, 0, 1) / 255.0
+
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(8) as ex:                            # PIL's resize releases the GIL: the frames in parallel
+            return list(ex.map(one, range(n)))
 
     def _finish_forward_warp(self, interpolated_poses, image1, image2, depth1, depth2, pseudo_images, replace):
         """`--interp_type forward_warp` (diffusionGS.py:814-815 -> warp_images, :1512).  In the reference this branch
