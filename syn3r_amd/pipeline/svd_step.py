@@ -137,8 +137,9 @@ class SvdStepBench:
         flops = self.flops_per_unit[cand[best]] * units
         ach = flops / (ms / 1e3) / 1e12
         traffic, source = _pmc_traffic(best)
+        busy, _ = _pmc_traffic(best, field="mfma_busy")
         return dict(bound="mfma", kernel=best, achieved=round(ach, 1), peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / MFMA_F16_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=source,
+                    frac=round(ach / MFMA_F16_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=source, mfma_busy=busy,
                     avg_ms=round(ms / calls, 4), calls=calls, algorithmic_flops_per_unit=self.flops_per_unit)
 
 
@@ -155,7 +156,7 @@ def source_id() -> str:
     return h.hexdigest()[:16]
 
 
-def _pmc_traffic(kernel: str):
+def _pmc_traffic(kernel: str, field: str = "hbm_bytes_per_launch"):
     """(HBM bytes per launch of `kernel`, where the number comes from) out of the committed rocprofv3 PMC passes
     (profiles/*/traffic.json; bench.py cannot run the profiler on itself).  The file records the `source_id` of the
     kernel sources it profiled: if that differs from the running build the number is STALE and (None, reason) is
@@ -171,12 +172,12 @@ def _pmc_traffic(kernel: str):
         except (OSError, ValueError):
             continue
         rec = doc.get(kernel)
-        if not rec:
+        if not rec or field not in rec:
             continue
         if doc.get("_source_id") != cur:
             stale = stale or (f"{f.relative_to(root.parent)} was measured on kernel sources {doc.get('_source_id', 'unrecorded')}, "
                               f"the running build is {cur}: not reported")
             continue
-        return rec["hbm_bytes_per_launch"], (f"{f.relative_to(root.parent)} (sources {cur}): PMC FETCH_SIZE x2 (gfx950 correction) + "
+        return rec[field], (f"{f.relative_to(root.parent)} (sources {cur}): PMC FETCH_SIZE x2 (gfx950 correction) + "
                                              "WRITE_SIZE, averaged over the launches of the profiled run")
     return None, stale

@@ -1,6 +1,7 @@
 """Build profiles/rNN/traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the bench.
 
-usage: python tools/traffic_json.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+usage: python tools/traffic_json.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [<pmc_families.json>]
+(the optional fourth file, written by tools/pmc_families.py from the SQ / GRBM passes of the same build, adds `mfma_busy`)
 
 Corrections follow MI355X_MICROARCH.md (HBM): counters are in KB; on gfx950 FETCH_SIZE tallies the 128-byte
 requests of 16 B/lane streaming reads at 64 B, so it is doubled; WRITE_SIZE is exact for 16 B/lane streaming
@@ -43,5 +44,16 @@ for fam in sorted(set(fetch) | set(write)):
     f_kb, w_kb = fetch[fam][1] / max(fetch[fam][0], 1), write[fam][1] / max(write[fam][0], 1)
     out[fam] = {"launches": n, "fetch_kb_raw": round(f_kb, 1), "write_kb": round(w_kb, 1),
                 "hbm_bytes_per_launch": int((2.0 * f_kb + w_kb) * 1024)}
+if len(sys.argv) > 4:
+    fam = json.load(open(sys.argv[4]))
+    gemm = [v for k, v in fam.items() if k.startswith("k_gemm") or k == "k_ffn320"]
+    # MFMA busy of the whole contraction family: launch-weighted by the chip-active cycles of each member
+    num = sum(v["per_launch"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * v["launches"] for v in gemm)
+    den = sum(v["per_launch"].get("GRBM_GUI_ACTIVE", 0.0) * v["launches"] for v in gemm) / 8.0 * 1024.0
+    if den > 0 and "k_gemm" in out:
+        out["k_gemm"]["mfma_busy"] = round(num / den, 4)
+    for name in ("k_attn_spatial", "k_render_bwd", "k_render"):
+        if name in out and name in fam and "mfma_busy" in fam[name]:
+            out[name]["mfma_busy"] = fam[name]["mfma_busy"]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
