@@ -471,6 +471,31 @@ int syn3r_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 size_t syn3r_knn3_workspace_bytes(int n);
 int syn3r_knn3_mean_dist2(const float* points, int n, float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * LPIPS (VGG16) perceptual loss term of the trainer (the reference raises `opt.use_lpips_loss` around every refine,
+ * model/diffusionGS.py:1690,1697; the loss lives in un-vendored FSGS and calls the `lpips` package: the PUBLISHED
+ * definition is restated, csrc/lpips.hip).  Activations are channels-last fp16 [H*W, C].
+ * ------------------------------------------------------------------------ */
+/* 3x3 convolution, stride 1, padding 1, + bias, with the activation options VGG needs: relu != 0: out = max(out, 0);
+ * relu_mask (nullable) [NB*Hi*Wi, Cout]: out zeroed where mask <= 0 (the ReLU backward of the layer below, fused into the
+ * backward-data convolution, which is this same kernel on the transposed, flipped weights).  Cin % 64 == 0, Cout % 8 == 0. */
+int syn3r_conv2d3x3_act_f16(const void* X, const void* W, void* out, const void* bias, int relu, const void* relu_mask,
+                            int NB, int Hi, int Wi, int Cin, int Cout, void* stream);
+/* image [3,H,W] fp32 in [0,1] -> LPIPS input scaling ((2x-1) - shift) / scale -> [H*W, 64] fp16 (channels 3..63 zero) */
+int syn3r_lpips_image_f16(const float* img, int H, int W, void* out, void* stream);
+/* gradient wrt that [H*W, 64] tensor (carrying loss_scale) -> d loss / d image [3,H,W] fp32 */
+int syn3r_lpips_image_bwd(const void* grad64, int H, int W, float loss_scale, float* d_img, void* stream);
+/* nn.MaxPool2d(2, 2) on [H,W,C] fp16 -> [H/2,W/2,C], and its backward (gradient to the first maximum of each window) */
+int syn3r_maxpool2_f16(const void* x, int H, int W, int C, void* y, void* stream);
+int syn3r_maxpool2_bwd_f16(const void* x, const void* gy, int H, int W, int C, void* gx, void* stream);
+/* One LPIPS layer: value[0] (=, or += with accumulate) mean_p sum_c w_c (a_c/(|a|+1e-10) - b_c/(|b|+1e-10))^2 for feature
+ * maps a, b [P, C] fp16, C in {64,128,256,512}, w [C] fp32 device; and its gradient wrt a times gscale into grad_a [P, C]. */
+size_t syn3r_lpips_layer_workspace_bytes(long long P, int C);
+int syn3r_lpips_layer_f16(const void* a, const void* b, const float* w, long long P, int C, int accumulate, float* value,
+                          void* ws, size_t ws_bytes, void* stream);
+int syn3r_lpips_layer_bwd_f16(const void* a, const void* b, const float* w, long long P, int C, float gscale, int accumulate,
+                              void* grad_a, void* stream);
+
 /* Statistical outlier removal of a point cloud: what model/diffusionGS.py:321 asks of open3d
  * (`down_pcd.remove_statistical_outlier(nb_neighbors=20, std_ratio=3.0)`; open3d 0.17.0 is not in the reference tree, the
  * published algorithm is restated in csrc/knn.hip).  points [n,3] float64 (open3d holds doubles).  Outputs, all device

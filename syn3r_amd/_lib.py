@@ -96,6 +96,14 @@ SIGNATURES = {
     "syn3r_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_i, c_p]),
     "syn3r_knn3_workspace_bytes": (c_sz, [c_i]),
     "syn3r_knn3_mean_dist2": (c_i, [c_p, c_i, c_p, c_p, c_sz, c_p]),
+    "syn3r_conv2d3x3_act_f16": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "syn3r_lpips_image_f16": (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    "syn3r_lpips_image_bwd": (c_i, [c_p, c_i, c_i, c_f, c_p, c_p]),
+    "syn3r_maxpool2_f16": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "syn3r_maxpool2_bwd_f16": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "syn3r_lpips_layer_workspace_bytes": (c_sz, [c_ll, c_i]),
+    "syn3r_lpips_layer_f16": (c_i, [c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_sz, c_p]),
+    "syn3r_lpips_layer_bwd_f16": (c_i, [c_p, c_p, c_p, c_ll, c_i, c_f, c_i, c_p, c_p]),
     "syn3r_pcd_outlier_workspace_bytes": (c_sz, [c_i]),
     "syn3r_pcd_statistical_outlier": (c_i, [c_p, c_i, c_i, c_d, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "syn3r_flow_cycle_mask": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),

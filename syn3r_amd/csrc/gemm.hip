@@ -83,6 +83,9 @@ struct GemmParams {
     // Two-source A (k_gemm_widep only): columns [0, K1) of a row come from A (stride lda), columns [K1, K) from A2
     // (stride lda2) - the channel concatenation [A | A2] the up blocks' shortcut projection reads is never written.
     const __half* A2; long long lda2; int K1;     // A2 = null: one source
+    // VGG-style activation options of the GENERAL epilogue (gemm_epilogue; the convolution kernels use it):
+    int relu;                             // result = max(result, 0)
+    const __half* relu_mask;              // [M][ldc]: result zeroed where mask <= 0 (ReLU backward: grad * (activation > 0))
 };
 
 // element offset of (row m, column d) in the A-tiled layout of a matrix with D columns
@@ -178,7 +181,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
             }
             half4e o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (_Float16)((acc[i][j][r] + add[r]) * p.s_acc);
+            for (int r = 0; r < 4; ++r) {
+                float v = (acc[i][j][r] + add[r]) * p.s_acc;
+                if (p.relu) v = fmaxf(v, 0.0f);
+                o[r] = (_Float16)v;
+            }
             *(half4e*)(st + row * EPI_LD + col) = o;
         }
     }
@@ -241,6 +248,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (_Float16)f[e];
+        }
+        if (p.relu_mask && n + 8 <= p.N) {
+            const half8 mk = *(const half8*)(p.relu_mask + (long long)m * p.ldc + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.0f ? v[e] : (_Float16)0.0f;
         }
 #ifdef SYN3R_EXP_NOSTORE
         if ((float)v[0] != 12345.678f) continue;
@@ -1856,6 +1868,25 @@ extern "C" int syn3r_conv2d3x3_f16(const void* X, const void* W, void* out, long
     p.M = (int)M; p.N = Cout; p.K = 9 * Cin;
     int rc = check_common(p, "conv2d3x3");
     if (rc) return rc;
+    return launch<MODE_CONV2D>(p, (hipStream_t)stream);
+}
+
+extern "C" int syn3r_conv2d3x3_act_f16(const void* X, const void* W, void* out, const void* bias, int relu, const void* relu_mask,
+                                       int NB, int Hi, int Wi, int Cin, int Cout, void* stream) {
+    SYN3R_REQUIRE(NB > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv2d3x3_act: bad sizes");
+    SYN3R_REQUIRE(Cin % BK == 0 && Cout % 8 == 0, "conv2d3x3_act: Cin=%d must be a multiple of %d, Cout=%d of 8", Cin, BK, Cout);
+    GemmParams p{};
+    p.A = (const __half*)X; p.W = (const __half*)W; p.out = (__half*)out; p.ldc = Cout; p.bias = (const __half*)bias;
+    p.s_acc = 1.0f; p.s_res = 0.f; p.s_aux = 0.f;
+    p.relu = relu ? 1 : 0; p.relu_mask = (const __half*)relu_mask;
+    p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.stride = 1; p.ups = 0; p.pad = 1; p.Ho = Hi; p.Wo = Wi;
+    long long M = (long long)NB * Hi * Wi;
+    SYN3R_REQUIRE(M < (1ll << 31), "conv2d3x3_act: too many output pixels");
+    p.M = (int)M; p.N = Cout; p.K = 9 * Cin;
+    int rc = check_common(p, "conv2d3x3_act");
+    if (rc) return rc;
+    SYN3R_REQUIRE(((uintptr_t)relu_mask % 16) == 0, "conv2d3x3_act: mask must be 16-byte aligned");
+    // the persistent kernels have their own (lean) epilogue: the convolution modes never use them (launch_dma_bm)
     return launch<MODE_CONV2D>(p, (hipStream_t)stream);
 }
 

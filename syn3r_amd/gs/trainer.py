@@ -249,6 +249,7 @@ class GSTrainer:
         self.scene = _Scene(train_cameras, model_path)
         self.dust3r = None                # injected: to(device) / [make_pairs] / run(frames, c2w_poses=, intrinsics=, preset_pairs=)
         self.flow_net = None              # injected: flow_net(image_a [3,H,W], image_b [3,H,W]) -> flow a->b [2,H,W] (GMFlow's role)
+        self.lpips = None                 # injected: syn3r_amd.gs.lpips.LPIPS with loaded weights (the `lpips` package's role)
         self.checkpoint_iterations: List[int] = list(checkpoint_iterations or [])
         self.iteration = 0
         self.densify = False              # adaptive density control inside train_step (training / finetune set it)
@@ -369,17 +370,21 @@ class GSTrainer:
     def evaluate(self, cams: Optional[Sequence[Camera]] = None) -> dict:
         """PSNR / SSIM of the current Gaussians over held-out (or the training) cameras, computed on the device
         (`train_ops.image_metrics`): the psnr / ssim columns of the per-scene record (SURVEY.md §8e;
-        scripts/summarize_dl3dv.py:11-80 tabulates them).  LPIPS needs the pretrained VGG weights (absent offline):
-        reported as NaN."""
+        scripts/summarize_dl3dv.py:11-80 tabulates them).  LPIPS is reported when the trainer holds an `lpips` model
+        (weights supplied by the caller), NaN otherwise."""
         cams = list(cams) if cams is not None else self.scene.getTrainCameras()
-        ps, ss = [], []
+        ps, ss, ls = [], [], []
         with torch.no_grad():
             for cam in cams:
-                m = image_metrics(self.render_view(cam)["render"].clamp(0, 1), cam.original_image)
+                img = self.render_view(cam)["render"].clamp(0, 1)
+                m = image_metrics(img, cam.original_image)
                 ps.append(m[0])
                 ss.append(m[1])
+                if self.lpips is not None:
+                    ls.append(self.lpips(img, cam.original_image))
         p, s_ = torch.stack(ps).mean(), torch.stack(ss).mean()
-        return {"psnr": float(p), "ssim": float(s_), "lpips": float("nan"), "n": len(cams)}
+        lp = float(torch.stack(ls).mean()) if ls else float("nan")
+        return {"psnr": float(p), "ssim": float(s_), "lpips": lp, "n": len(cams)}
 
     # ------------------------------------------------------------------ adaptive density control (SURVEY.md 8f N4)
     # FSGS' training loop (un-vendored) densifies with the published 3DGS clone / split / prune rules plus its own
@@ -528,14 +533,20 @@ class GSTrainer:
     def train_step(self, cam: Optional[Camera] = None) -> torch.Tensor:
         """One optimisation step; returns the loss as a DEVICE scalar (no host synchronisation: the loop queues
         iterations back to back, `float(loss)` is the caller's choice).  `opt.use_lpips_loss` (set by the orchestrator
-        around refine_GS, diffusionGS.py:1690,1697) is accepted but inert: the LPIPS term of FSGS' loss needs the
-        pretrained VGG weights, which are not reachable offline (DESIGN.md out of scope)."""
+        around refine_GS, diffusionGS.py:1690,1697) adds `opt.lpips_weight` x LPIPS-VGG (`syn3r_amd.gs.lpips`, HIP) when the
+        trainer has been given an `lpips` model with weights (the pretrained ones are not reachable offline: the caller
+        loads them, as for CLIP / VAE / UNet); without one the switch is inert."""
         cam = cam or self._pick_camera()
         out = self.render_view(cam)
         if self.opt.lambda_dssim > 0.0:
             loss = photometric_loss(out["render"], cam.original_image, self.opt.lambda_dssim, float(cam.cam_confidence))
         else:
             loss = l1_loss(out["render"], cam.original_image, weight=float(cam.cam_confidence))
+        if self.opt.use_lpips_loss and self.opt.lpips_weight > 0.0 and self.lpips is not None:
+            # the perceptual term of the refine stage (diffusionGS.py:1690,1697; `--lpips_weight`): published LPIPS-VGG on the
+            # whole render, weighted like the photometric term by the camera confidence.  How FSGS applies it is not visible
+            # (un-vendored): UNPINNED.
+            loss = loss + (self.opt.lpips_weight * float(cam.cam_confidence)) * self.lpips(out["render"].clamp(0, 1), cam.original_image)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         changed = False

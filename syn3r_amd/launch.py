@@ -55,6 +55,10 @@ def parse(argv: Optional[Sequence[str]] = None) -> argparse.Namespace:
     ap.add_argument("--checkpoint_iterations", nargs="+", type=int, default=[])
     ap.add_argument("--iterations", type=int, default=10_000)
     ap.add_argument("--lambda_dssim", type=float, default=0.2)
+    ap.add_argument("--lpips_weight", type=float, default=0.0,
+                    help="weight of the LPIPS term during refines (bash_scripts/batch_dl3dv_train.sh:84-87 passes 1); needs --lpips_weights")
+    ap.add_argument("--lpips_weights", type=str, default=None,
+                    help="local state_dict file of lpips.LPIPS(net='vgg') (torch.save format); the package's download is not reachable offline")
     ap.add_argument("--num_inference_steps", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args(argv)
@@ -133,6 +137,12 @@ def run_scene(name: str, args, device, factory: Callable) -> List[float]:
             from .unet.model import UNetSpatioTemporalConditionModel
             comps = dict(comps, unet=UNetSpatioTemporalConditionModel.from_pretrained(os.path.join(args.svd_dir, "unet"), device),
                          dtype=torch.float16)
+    trainer.opt.lpips_weight = float(getattr(args, "lpips_weight", 0.0))
+    if sc.get("lpips") is not None:
+        trainer.lpips = sc["lpips"]
+    elif getattr(args, "lpips_weights", None):
+        from .gs.lpips import LPIPS
+        trainer.lpips = LPIPS().load_state_dict(torch.load(args.lpips_weights, map_location="cpu", weights_only=True), device)
     runner = DiffusionGS(trainer, num_input_views=sc["num_input_views"], save_dir=trainer.scene.model_path,
                          diffusion_type=args.diffusion_type, interp_type=args.interp_type, input_args=args,
                          svd_components=comps, num_inference_steps=args.num_inference_steps,
