@@ -149,7 +149,8 @@ __global__ void __launch_bounds__(1024) k_lpips_finish(const float* __restrict__
 
 // Backward of one layer wrt a: with n = a / r, r = |a| + eps, e_c = 2 w_c (n_c - b_c / (|b| + eps)) / P,
 //   d value / d a_k = e_k / r - (sum_c e_c a_c) a_k / (r^2 |a|)
-// written (accumulate = 0) or added (1) to ga [P, C] fp16, multiplied by `gscale` (upstream gradient x loss scale).
+// written (accumulate = 0) or added (1) to ga [P, C] fp16, multiplied by `gscale` (upstream gradient x loss scale); the sum
+// is then masked by a > 0 (the feature map is the output of a ReLU: what leaves is the gradient wrt its pre-activation).
 template <int LPR>
 __global__ void __launch_bounds__(256) k_lpips_layer_bwd(const __half* __restrict__ a, const __half* __restrict__ b, const float* __restrict__ w,
                                                         long long P, float gscale, int accumulate, __half* __restrict__ ga) {
@@ -179,7 +180,8 @@ __global__ void __launch_bounds__(256) k_lpips_layer_bwd(const __half* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float g = ev[e] * ra - k2 * (float)av[e];
-        o[e] = (_Float16)((accumulate ? (float)o[e] : 0.0f) + g);
+        // `a` is a post-ReLU activation: the total gradient passes its ReLU here (zero where the activation is zero)
+        o[e] = (float)av[e] > 0.0f ? (_Float16)((accumulate ? (float)o[e] : 0.0f) + g) : (_Float16)0.0f;
     }
     *(half8*)(ga + p * C + sub * 8) = o;
 }

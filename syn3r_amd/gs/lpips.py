@@ -207,9 +207,7 @@ class _LpipsFn(torch.autograd.Function):
             # back through the slice's convolutions: g is d/d(post-ReLU output of conv n) -> mask by (output > 0) -> backward-data
             # convolution -> d/d(input of conv n) = d/d(post-ReLU output of conv n-1), whose own mask is applied in the epilogue
             nconv = len(model.bwd[k])
-            # the mask of the LAST conv's own ReLU: applied by multiplying in place through a masked identity is wasteful;
-            # instead the head gradient is masked here once (the feature IS the post-ReLU activation: grad flows only where > 0)
-            g = torch.where(feat > 0, g, torch.zeros_like(g))
+            # (the ReLU of the slice's LAST convolution has been applied by the layer kernel: its output is the feature map)
             for n in range(nconv - 1, -1, -1):
                 below = acts[k][n]                     # input of conv n (post-ReLU of conv n-1, or the slice input)
                 mask = below if n > 0 else None        # the slice input is a pooled map / the image tensor: no ReLU of its own
