@@ -241,6 +241,33 @@ def gen_vae_full():
     np.savez_compressed(GOLD / "vae_full.npz", **out)
 
 
+def _reference_pipe(cls, unet, vae=None):
+    """An instance of the reference pipeline class `cls` with the given modules as plain attributes (DiffusionPipeline's
+    register_modules / device bookkeeping skipped): mock CLIP, mock VAE unless one is passed, the reference scheduler."""
+    from diffusers import EulerDiscreteScheduler
+    from diffusers.image_processor import VaeImageProcessor
+    from oracle import pipeline_mocks as PM
+
+    class Pipe(cls):
+        def __init__(self):
+            self.vae, self.image_encoder, self.unet = (vae if vae is not None else PM.MockVAE()), PM.MockImageEncoder(), unet
+            self.scheduler = EulerDiscreteScheduler(**GI.SCHED_CONFIG)
+            self.feature_extractor = None
+            self.vae_scale_factor = 8
+            self.image_processor = VaeImageProcessor(vae_scale_factor=8)
+
+        @property
+        def _execution_device(self):
+            return torch.device("cpu")
+
+        def check_inputs(self, *a, **k):
+            return None
+
+        def maybe_free_model_hooks(self):
+            return None
+    return Pipe()
+
+
 def gen_pipeline():
     """Run the REFERENCE pipeline classes' own __call__ (both variants) on the CPU with mock CLIP / VAE /
     UNet (oracle/pipeline_mocks.py), 3 denoise steps, output_type='latent'."""
@@ -253,25 +280,7 @@ def gen_pipeline():
 
     inp = PM.pipeline_inputs(seed=0)
 
-    def make(cls):
-        class Pipe(cls):
-            def __init__(self):           # skip DiffusionPipeline.register_modules: plain attributes suffice
-                self.vae, self.image_encoder, self.unet = PM.MockVAE(), PM.MockImageEncoder(), PM.MockUNet()
-                self.scheduler = EulerDiscreteScheduler(**GI.SCHED_CONFIG)
-                self.feature_extractor = None
-                self.vae_scale_factor = 8
-                self.image_processor = VaeImageProcessor(vae_scale_factor=8)
-
-            @property
-            def _execution_device(self):
-                return torch.device("cpu")
-
-            def check_inputs(self, *a, **k):
-                return None
-
-            def maybe_free_model_hooks(self):
-                return None
-        return Pipe()
+    make = lambda cls: _reference_pipe(cls, PM.MockUNet())
 
     out = {}
     orig_cuda = torch.Tensor.cuda
@@ -308,25 +317,7 @@ def gen_pipeline_one_pass():
 
     inp = PM.pipeline_inputs(seed=0)
 
-    def make(cls):
-        class Pipe(cls):
-            def __init__(self):
-                self.vae, self.image_encoder, self.unet = PM.MockVAE(), PM.MockImageEncoder(), PM.MockUNet()
-                self.scheduler = EulerDiscreteScheduler(**GI.SCHED_CONFIG)
-                self.feature_extractor = None
-                self.vae_scale_factor = 8
-                self.image_processor = VaeImageProcessor(vae_scale_factor=8)
-
-            @property
-            def _execution_device(self):
-                return torch.device("cpu")
-
-            def check_inputs(self, *a, **k):
-                return None
-
-            def maybe_free_model_hooks(self):
-                return None
-        return Pipe()
+    make = lambda cls: _reference_pipe(cls, PM.MockUNet())
 
     out = {}
     orig_cuda, orig_linspace = torch.Tensor.cuda, torch.linspace
@@ -378,25 +369,7 @@ def gen_pipeline_real_unet():
     unet.eval()
     inp = PM.pipeline_inputs(seed=1)
 
-    def make(cls):
-        class Pipe(cls):
-            def __init__(self):
-                self.vae, self.image_encoder, self.unet = PM.MockVAE(), PM.MockImageEncoder(), unet
-                self.scheduler = EulerDiscreteScheduler(**GI.SCHED_CONFIG)
-                self.feature_extractor = None
-                self.vae_scale_factor = 8
-                self.image_processor = VaeImageProcessor(vae_scale_factor=8)
-
-            @property
-            def _execution_device(self):
-                return torch.device("cpu")
-
-            def check_inputs(self, *a, **k):
-                return None
-
-            def maybe_free_model_hooks(self):
-                return None
-        return Pipe()
+    make = lambda cls: _reference_pipe(cls, unet)
 
     out = {}
     orig_cuda = torch.Tensor.cuda
@@ -421,6 +394,48 @@ def gen_pipeline_real_unet():
     np.savez_compressed(GOLD / "pipeline_unet.npz", **out)
 
 
+def gen_pipeline_full():
+    """FULL SIZE: the reference `SVD_2pass_prob_uncertain.StableVideoDiffusionPipeline.__call__` ("Replace") driving the
+    reference UNetSpatioTemporalConditionModel() in its default = SVD-XT configuration (1.52 B parameters, CPU fp32, the
+    name-keyed seeded weights of gen_unet_full), mock CLIP / VAE, ONE denoising step (both passes: two CFG forwards at
+    [2,25,8,72,128]), output_type='latent'.  ~30 min of CPU.  The Post variant is not generated at this size: the reference
+    builds an autograd graph through each guidance-tile UNet forward (…post.py:727-774), which at full width needs more
+    host memory than this container has (62 GB, no swap); its loop is pinned at the reduced width (gen_pipeline_real_unet)
+    and its tile forwards at full width (gen_unet_full b1f25_40x72 / b1f25_48x72)."""
+    import time
+    from diffusers import EulerDiscreteScheduler
+    from diffusers.image_processor import VaeImageProcessor
+    from diffusers.models import UNetSpatioTemporalConditionModel
+    from oracle import pipeline_mocks as PM
+    from oracle import unet_weights as UW
+    import model.SVD_2pass_prob_uncertain as P2
+    unet = UNetSpatioTemporalConditionModel()
+    shapes = {k: tuple(v.shape) for k, v in unet.state_dict().items()}
+    unet.load_state_dict(UW.make_state_dict(shapes, seed=5))
+    unet.eval()
+    inp = PM.pipeline_inputs(seed=6)
+
+    Pipe = lambda: _reference_pipe(P2.StableVideoDiffusionPipeline, unet, None)
+
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    orig = P2.randn_tensor
+    P2.randn_tensor = lambda shape, **k: inp["noise"].clone() if tuple(shape) == tuple(inp["noise"].shape) else orig(shape, **k)
+    t0 = time.time()
+    try:
+        with torch.no_grad():
+            res = Pipe()(inp["image"], temp_cond=inp["temp_cond"], mask=inp["mask"].clone(), lambda_ts=inp["lambda_ts"],
+                         num_frames=25, decode_chunk_size=8, num_inference_steps=1, latent_num=1,
+                         latents=inp["latents"].clone(), output_type="latent")
+    finally:
+        P2.randn_tensor = orig
+        torch.Tensor.cuda = orig_cuda
+    lat = res.frames.float().numpy()
+    print("pipeline_full replace", lat.shape, float(np.abs(lat).mean()), f"{time.time() - t0:.0f} s", flush=True)
+    np.savez_compressed(GOLD / "pipeline_unet_full.npz", replace=lat[..., ::2, ::2], mean_abs=np.float64(np.abs(lat).mean()),
+                        std=np.float64(lat.std()))
+
+
 def gen_pipeline_real_unet_vae():
     """As gen_pipeline_real_unet, 'replace' variant, with the REFERENCE AutoencoderKLTemporalDecoder too (reduced
     four-level configuration) and output_type='np': the pipelines' VAE plumbing (scaled / noised condition encodes,
@@ -442,23 +457,7 @@ def gen_pipeline_real_unet_vae():
     unet.eval(); vae.eval()
     inp = PM.pipeline_inputs(seed=2)
 
-    class Pipe(P2.StableVideoDiffusionPipeline):
-        def __init__(self):
-            self.vae, self.image_encoder, self.unet = vae, PM.MockImageEncoder(), unet
-            self.scheduler = EulerDiscreteScheduler(**GI.SCHED_CONFIG)
-            self.feature_extractor = None
-            self.vae_scale_factor = 8
-            self.image_processor = VaeImageProcessor(vae_scale_factor=8)
-
-        @property
-        def _execution_device(self):
-            return torch.device("cpu")
-
-        def check_inputs(self, *a, **k):
-            return None
-
-        def maybe_free_model_hooks(self):
-            return None
+    Pipe = lambda: _reference_pipe(P2.StableVideoDiffusionPipeline, unet, vae)
 
     orig_cuda = torch.Tensor.cuda
     torch.Tensor.cuda = lambda self, *a, **k: self
@@ -607,6 +606,8 @@ def main():
         gen_pipeline_one_pass()
     if "pipeline_unet" in which:          # ~5 min of CPU: not part of the default set
         gen_pipeline_real_unet()
+    if "pipeline_full" in which:          # ~30 min of CPU, 1.52 B parameters
+        gen_pipeline_full()
     if "pipeline_unet_vae" in which:      # ~10 min of CPU
         gen_pipeline_real_unet_vae()
     if "orch" in which:
