@@ -436,6 +436,40 @@ def gen_pipeline_full():
                         std=np.float64(lat.std()))
 
 
+def gen_pipeline_full_post():
+    """As gen_pipeline_full for the Post variant (`SVD_2pass_prob_uncertain_post`): the reference runs the four guidance-tile
+    UNet forwards of each pass under autograd (…post.py:727-774), whose graph at full width takes tens of GB of host
+    memory: run with an address-space limit (`ulimit -v 58000000`) so that running out raises instead of invoking the
+    kernel's OOM killer.  Writes tests/golden/pipeline_unet_full_post.npz."""
+    import time
+    from diffusers.models import UNetSpatioTemporalConditionModel
+    from oracle import pipeline_mocks as PM
+    from oracle import unet_weights as UW
+    import model.SVD_2pass_prob_uncertain_post as P1
+    unet = UNetSpatioTemporalConditionModel()
+    shapes = {k: tuple(v.shape) for k, v in unet.state_dict().items()}
+    unet.load_state_dict(UW.make_state_dict(shapes, seed=5))
+    unet.eval()
+    inp = PM.pipeline_inputs(seed=6)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    orig = P1.randn_tensor
+    P1.randn_tensor = lambda shape, **k: inp["noise"].clone() if tuple(shape) == tuple(inp["noise"].shape) else orig(shape, **k)
+    t0 = time.time()
+    try:
+        with torch.no_grad():
+            res = _reference_pipe(P1.StableVideoDiffusionPipeline, unet)(
+                inp["image"], temp_cond=inp["temp_cond"], mask=inp["mask"].clone(), lambda_ts=inp["lambda_ts"], num_frames=25,
+                decode_chunk_size=8, num_inference_steps=1, latent_num=1, latents=inp["latents"].clone(), output_type="latent")
+    finally:
+        P1.randn_tensor = orig
+        torch.Tensor.cuda = orig_cuda
+    lat = res.frames.float().numpy()
+    print("pipeline_full post", lat.shape, float(np.abs(lat).mean()), f"{time.time() - t0:.0f} s", flush=True)
+    np.savez_compressed(GOLD / "pipeline_unet_full_post.npz", post=lat[..., ::2, ::2], mean_abs=np.float64(np.abs(lat).mean()),
+                        std=np.float64(lat.std()))
+
+
 def gen_pipeline_real_unet_vae():
     """As gen_pipeline_real_unet, 'replace' variant, with the REFERENCE AutoencoderKLTemporalDecoder too (reduced
     four-level configuration) and output_type='np': the pipelines' VAE plumbing (scaled / noised condition encodes,
@@ -606,8 +640,10 @@ def main():
         gen_pipeline_one_pass()
     if "pipeline_unet" in which:          # ~5 min of CPU: not part of the default set
         gen_pipeline_real_unet()
-    if "pipeline_full" in which:          # ~30 min of CPU, 1.52 B parameters
+    if "pipeline_full" in which:          # ~15 min of CPU, 1.52 B parameters
         gen_pipeline_full()
+    if "pipeline_full_post" in which:     # the Post variant at full size: run under `ulimit -v` (see gen_pipeline_full_post)
+        gen_pipeline_full_post()
     if "pipeline_unet_vae" in which:      # ~10 min of CPU
         gen_pipeline_real_unet_vae()
     if "orch" in which:
