@@ -440,7 +440,10 @@ def gen_pipeline_full_post():
     """As gen_pipeline_full for the Post variant (`SVD_2pass_prob_uncertain_post`): the reference runs the four guidance-tile
     UNet forwards of each pass under autograd (…post.py:727-774), whose graph at full width takes tens of GB of host
     memory: run with an address-space limit (`ulimit -v 58000000`) so that running out raises instead of invoking the
-    kernel's OOM killer.  Writes tests/golden/pipeline_unet_full_post.npz."""
+    kernel's OOM killer.  Writes tests/golden/pipeline_unet_full_post.npz.
+    Round 3, this container (62 GB, no swap), `ulimit -v 58000000`: the FIRST guidance-tile forward fails to allocate a
+    737 MB GEGLU activation with the graph's saved tensors at ~55 GB - the fixture cannot be generated here; kept for a
+    larger host."""
     import time
     from diffusers.models import UNetSpatioTemporalConditionModel
     from oracle import pipeline_mocks as PM
