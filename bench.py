@@ -363,6 +363,10 @@ def sub_benchmarks(args, dev, loop_a, loop_b, log):
         del b25
         torch.cuda.empty_cache()
         log("sub-benchmarks: SVD units done")
+    # HOT LOOP A alone: the headline's raster iteration (render, fused L1, backward) back to back, no SVD unit in between
+    it_ms = wall_ms(loop_a.iteration, 100)
+    out["raster_only_iters_per_s"] = round(1e3 / it_ms, 1)
+    out["raster_only_iteration_us"] = round(1e3 * it_ms, 1)
     out["raster_full_iteration_per_s"] = round(loop_a.full_iteration_rate(50), 1)
     out["raster_full_iteration_note"] = "render + (0.8 L1 + 0.2 (1-SSIM)) + backward + fused Adam on 5 parameter groups, no host sync"
     if loop_b is not None and not args.no_end_to_end:
