@@ -37,6 +37,10 @@ fi
 # per-shape / per-kernel breakdowns of the same build (developer tools; failures here do not fail the collection)
 ( timeout -k 10 200 python3 "$R/tools/unet_breakdown.py" 14 detail 2>/dev/null | grep -v amdgpu.ids > "$OUT/unet_shapes.txt" ) || true
 ( timeout -k 10 100 python3 "$R/tools/raster_breakdown.py" 2>/dev/null | grep -v amdgpu.ids > "$OUT/raster_breakdown.txt" ) || true
+( timeout -k 10 200 python3 "$R/tools/merge_units.py" 25 2>/dev/null | grep -v amdgpu.ids > "$OUT/merge_units.txt" ) || true
+( timeout -k 10 100 python3 "$R/tools/norm_bench.py" 2>/dev/null | grep -v amdgpu.ids > "$OUT/norm_bench.txt" ) || true
+( timeout -k 10 100 python3 "$R/tools/lpips_bench.py" 2>/dev/null | grep -v amdgpu.ids > "$OUT/lpips_bench.txt" ) || true
+( timeout -k 10 200 python3 "$R/tools/pair_profile.py" 2>/dev/null | grep -v amdgpu.ids | head -40 > "$OUT/pair_profile.txt" ) || true
 rm -rf "$OUT/fetch/p_kernel_trace.csv" "$OUT/write/p_kernel_trace.csv" "$OUT/stats/bench_kernel_trace.csv" "$OUT/sqa/p_kernel_trace.csv" "$OUT/sqb/p_kernel_trace.csv"
 # the raw per-dispatch counter files are large: keep the per-kernel summaries only
 rm -f "$OUT"/sqa/p_counter_collection.csv "$OUT"/sqb/p_counter_collection.csv "$OUT"/fetch/p_counter_collection.csv "$OUT"/write/p_counter_collection.csv
