@@ -1,6 +1,7 @@
 """Per-(step, pass) unit times at F frames: pass-by-pass against both passes stacked (merge_passes)."""
 import sys, time
-sys.path.insert(0, ".")
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from syn3r_amd.pipeline.svd_step import SvdStepBench
 
