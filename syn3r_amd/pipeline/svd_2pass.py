@@ -92,6 +92,8 @@ class StableVideoDiffusionPipeline:
         self.device = torch.device(device)
         self.vae_scale_factor = 8
         self._guidance_scale = None
+        import os
+        self.use_graphs = os.environ.get("SYN3R_UNET_GRAPH", "0") == "1"     # replay captured UNet launch sequences (hipGraph)
 
     @property
     def guidance_scale(self):
@@ -135,6 +137,8 @@ class StableVideoDiffusionPipeline:
 
     # ------------------------------------------------------------------ the hot loop
     def _unet(self, x, t, ehs, added, **kw):
+        if self.use_graphs and hasattr(self.unet, "forward_graphed"):      # captured launch sequence per (shape, context)
+            return self.unet.forward_graphed(x, t, ehs, added, **kw)[0]
         return self.unet(x, t, encoder_hidden_states=ehs, added_time_ids=added, return_dict=False, **kw)[0]
 
     def _cfg(self, noise_pred, do_cfg):

@@ -53,7 +53,8 @@ class SvdStepBench:
         x = torch.cat([self.latents] * 2)
         x = self.sch.scale_model_input(x, t, step_i=i).half()
         x = torch.cat([x, self.image_latents], dim=2)
-        noise_pred = self.unet(x, t, self.ehs, self.added)[0]
+        fwd = self.unet.forward_graphed if getattr(self, "use_graphs", False) else self.unet
+        noise_pred = fwd(x, t, self.ehs, self.added)[0]
         noise_pred = cfg_combine(noise_pred, self.guidance)
         out = self.sch.step_interp_prob_uncertain(noise_pred, t, self.latents, self.temp_cond, self.mask,
                                                   self.lambda_ts, step_i=i)

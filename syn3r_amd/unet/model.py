@@ -557,4 +557,44 @@ class UNetSpatioTemporalConditionModel:
             return SimpleNamespace(sample=y)
         return (y,)
 
+    # ------------------------------------------------------------------ captured forward (hipGraph)
+    # A forward is ~350 launches per batch-of-2 call at F = 14, each a Python -> ctypes call of ~5 us: with kernels as short as
+    # the level-3 ones the launch queue runs dry (3 % of the unit at F = 14, 0.5 % at F = 25: bench.py `denoise_host_gap`).
+    # `forward_graphed` captures the launch sequence of one (shape, context) once - torch.cuda.CUDAGraph, i.e. a hipGraph on
+    # the capture stream the operators already launch on - and replays it: same kernels, same order, same buffers (the
+    # graph's private pool), bit-identical results.  Inputs are copied into static buffers; the timestep is a device scalar.
+    def forward_graphed(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, added_time_ids: torch.Tensor,
+                        ctx_group: Optional[int] = None):
+        if L._active_trace is not None:                 # per-kernel timing brackets every launch with events: run eagerly
+            return self.forward(sample, timestep, encoder_hidden_states, added_time_ids, ctx_group=ctx_group)
+        dev = L.require_gpu(sample, encoder_hidden_states, added_time_ids)
+        ehs = encoder_hidden_states
+        key = (tuple(sample.shape), ctx_group, ehs.untyped_storage().data_ptr(), ehs.storage_offset(), tuple(ehs.shape),
+               tuple(ehs.stride()), ehs._version, tuple(added_time_ids.shape))
+        graphs = self.__dict__.setdefault("_graphs", {})
+        ent = graphs.get(key)
+        ts = timestep if torch.is_tensor(timestep) else torch.tensor([float(timestep)])
+        ts = ts.reshape(-1)[:1].to(device=dev, dtype=torch.float32)
+        if ent is None:
+            if len(graphs) >= 8:
+                graphs.pop(next(iter(graphs)))
+            s_in, t_in, a_in = sample.to(H).clone(), ts.clone(), added_time_ids.clone()
+            # warm-up on the capture stream's side: workspaces, folded contexts, position embeddings, kernel attributes
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.forward(s_in, t_in, ehs, a_in, ctx_group=ctx_group)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                y = self.forward(s_in, t_in, ehs, a_in, ctx_group=ctx_group)[0]
+            ent = graphs[key] = (g, s_in, t_in, a_in, y, ehs)
+        g, s_in, t_in, a_in, y, _ = ent
+        s_in.copy_(sample)
+        t_in.copy_(ts)
+        a_in.copy_(added_time_ids)
+        g.replay()
+        return (y.clone(),)
+
     __call__ = forward

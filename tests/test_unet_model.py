@@ -142,3 +142,24 @@ def test_ctx_group_stack_equals_separate_calls(gpu):
         assert close(ones[k:k + 1], model(s[k:k + 1].contiguous(), t, e[k:k + 1].contiguous(), a[:1])[0])
     with pytest.raises(ValueError):
         model(s, t, e, a, ctx_group=3)
+
+
+@pytest.mark.gpu
+def test_captured_forward_replays_bit_identical(gpu):
+    """`forward_graphed`: the launch sequence of one (shape, context) captured into a hipGraph and replayed gives the eager
+    forward bit for bit, also after the inputs and the timestep change; a new shape gets its own graph."""
+    from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel
+    model = UNetSpatioTemporalConditionModel(**UW.SMALL_CONFIG)
+    model.load_state_dict(UW.make_state_dict(model.parameter_shapes()), gpu)
+    sample, t, ehs, added = UW.make_inputs(2, 5, 16, 24, seed=8)
+    s, e, a = sample.half().to(gpu), ehs.half().to(gpu), added.to(gpu)
+    for tt, scale in ((t, 1.0), (0.37, 0.5), (torch.tensor(1.2, device=gpu), 2.0)):
+        x = (s * scale).contiguous()
+        assert torch.equal(model.forward_graphed(x, tt, e, a)[0], model(x, tt, e, a)[0])
+    assert len(model._graphs) == 1
+    x2 = s[..., :16].contiguous()                      # 16 x 16: an even pixel count at the coarsest level too
+    assert torch.equal(model.forward_graphed(x2, t, e, a)[0], model(x2, t, e, a)[0]) and len(model._graphs) == 2
+    s4 = torch.cat([s, s * 0.7])
+    e4 = torch.cat([e, e.flip(0)]).contiguous()
+    a4 = torch.cat([a, a])
+    assert torch.equal(model.forward_graphed(s4, t, e4, a4, ctx_group=2)[0], model(s4, t, e4, a4, ctx_group=2)[0])
