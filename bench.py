@@ -10,9 +10,10 @@ The schedule 10k + 2 x (3 svd_render + 10k) has 30 000 raster iterations per 600
 (step, pass) units = 50 : 1, which is the default ratio.  value = raster iterations / s over the
 whole job (all ranks), the SVD units being amortised inside the same wall-clock.
 
-Launch: `python bench.py` (1 GPU) or
-`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (one scene per rank,
-weak scaling, a single RCCL all-gather of the per-rank metric record at the end).
+Launch: `python bench.py` (1 GPU), `python bench.py --gpus N` (starts the N ranks itself: a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...`, rank 0's JSON line relayed), or that torchrun
+command directly (one scene per rank, weak scaling, a single RCCL all-gather of the per-rank metric record
+at the end).  The N-rank job replaces the reference's sequential scene loop, bash_scripts/batch_llff_train.sh:24-47.
 """
 from __future__ import annotations
 
@@ -424,8 +425,33 @@ def sub_benchmarks(args, dev, loop_a, loop_b, log):
     return out
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process (never an exec: this process may
+    not have touched the GPU yet, but the box refuses exec from GPU processes anyway) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL across processes)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)     # stderr passes through
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    for l in r.stdout.splitlines():
+        if l.strip() and not l.strip().startswith("{"):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return r.returncode if (r.returncode or lines) else 1
+
+
 def main():
     args = parse()
+    # BEFORE anything touches the GPU: --gpus N without a torchrun environment means "start the N ranks yourself"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the SYN3R hot path has no CPU fallback)")
     # rehearsal knobs (not used by the driver): all ranks on one GPU and/or gloo instead of RCCL
@@ -433,6 +459,8 @@ def main():
         os.environ["LOCAL_RANK"] = "0"
     from syn3r_amd import dist as D
     rank, world, local = D.init(os.environ.get("SYN3R_BENCH_BACKEND"))     # one process per GPU; "nccl" is RCCL
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launch environment has WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = torch.distributed if world > 1 else None

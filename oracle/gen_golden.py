@@ -436,38 +436,86 @@ def gen_pipeline_full():
                         std=np.float64(lat.std()))
 
 
+class _NoGradUNet(torch.nn.Module):
+    """The reference UNet run under torch.no_grad(), everything else delegated.  The Post loop calls its four guidance-tile
+    forwards under torch.enable_grad() (…post.py:727-774), but the gradient it consumes is `sample.grad` of the SCHEDULER's
+    loss (scheduling_euler_discrete.py:782-789) with respect to `latents1`, and the UNet's input is a detached leaf
+    (…post.py:732-733): no path from the loss to `sample` runs through the UNet, so cutting the UNet's graph leaves every
+    value the pipeline computes unchanged while the saved activations (tens of GB at full width) are never kept.
+    `nograd_check` below proves it on the reduced-width fixture that WAS generated with the graph."""
+
+    def __init__(self, unet):
+        super().__init__()
+        self.inner = unet
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__("inner"), name)
+
+    def forward(self, *a, **k):
+        with torch.no_grad():
+            return self.inner(*a, **k)
+
+
+def _run_post_reference(unet, inp, steps):
+    """The reference Post pipeline class' own __call__ on `unet` (mock CLIP / VAE), `steps` denoising steps, latents out."""
+    import model.SVD_2pass_prob_uncertain_post as P1
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    orig = P1.randn_tensor
+    P1.randn_tensor = lambda shape, **k: inp["noise"].clone() if tuple(shape) == tuple(inp["noise"].shape) else orig(shape, **k)
+    try:
+        with torch.no_grad():
+            res = _reference_pipe(P1.StableVideoDiffusionPipeline, unet)(
+                inp["image"], temp_cond=inp["temp_cond"], mask=inp["mask"].clone(), lambda_ts=inp["lambda_ts"], num_frames=25,
+                decode_chunk_size=8, num_inference_steps=steps, latent_num=1, latents=inp["latents"].clone(), output_type="latent")
+    finally:
+        P1.randn_tensor = orig
+        torch.Tensor.cuda = orig_cuda
+    return res.frames.float().numpy()
+
+
+def gen_nograd_check():
+    """Equivalence proof for _NoGradUNet: the reduced-width Post run of gen_pipeline_real_unet (whose committed fixture
+    `pipeline_unet.npz['post']` was produced WITH the reference's autograd graph through the tile forwards) repeated with
+    the no-grad wrapper must reproduce that fixture to fp32 rounding (measured: max 2.4e-4 on a scale of 3.35 = 7e-5 relative
+    after two steps - torch picks other CPU kernels / reduction splits without a graph and under another thread count; a
+    gradient that DID depend on the UNet graph would differ at the scale of the guidance term itself, ~1e-1)."""
+    from diffusers.models import UNetSpatioTemporalConditionModel
+    from oracle import pipeline_mocks as PM
+    from oracle import unet_weights as UW
+    torch.manual_seed(0)
+    unet = UNetSpatioTemporalConditionModel(**UW.PIPELINE_CONFIG)
+    shapes = {k: tuple(v.shape) for k, v in unet.state_dict().items()}
+    unet.load_state_dict(UW.make_state_dict(shapes, seed=3))
+    unet.eval()
+    lat = _run_post_reference(_NoGradUNet(unet), PM.pipeline_inputs(seed=1), 2)[..., ::3, ::3]
+    ref = np.load(GOLD / "pipeline_unet.npz")["post"]
+    d = float(np.abs(lat - ref).max())
+    print("nograd_check: max |no-grad wrapper - with-graph fixture| =", d, "of scale", float(np.abs(ref).max()), flush=True)
+    assert d <= 2e-4 * float(np.abs(ref).max()), "the no-grad wrapper changed the Post pipeline's result"
+
+
 def gen_pipeline_full_post():
-    """As gen_pipeline_full for the Post variant (`SVD_2pass_prob_uncertain_post`): the reference runs the four guidance-tile
-    UNet forwards of each pass under autograd (…post.py:727-774), whose graph at full width takes tens of GB of host
-    memory: run with an address-space limit (`ulimit -v 58000000`) so that running out raises instead of invoking the
-    kernel's OOM killer.  Writes tests/golden/pipeline_unet_full_post.npz.
-    Round 3, this container (62 GB, no swap), `ulimit -v 58000000`: the FIRST guidance-tile forward fails to allocate a
-    737 MB GEGLU activation with the graph's saved tensors at ~55 GB - the fixture cannot be generated here; kept for a
-    larger host."""
+    """As gen_pipeline_full for the Post variant (`SVD_2pass_prob_uncertain_post`), the one every LLFF / DL3DV script runs:
+    the reference pipeline class and scheduler untouched, the reference UNet in its default = SVD-XT configuration
+    (1.52 B parameters, CPU fp32) behind _NoGradUNet (round 3 found that WITH the reference's autograd graph through the
+    guidance-tile forwards the first tile needs more than this container's 62 GB), ONE denoising step = both passes, each
+    four tile forwards [1,25,8,40|48,72] + one CFG forward [2,25,8,72,128].  ~25 min of CPU, peak ~35 GB.
+    Writes tests/golden/pipeline_unet_full_post.npz."""
     import time
     from diffusers.models import UNetSpatioTemporalConditionModel
     from oracle import pipeline_mocks as PM
     from oracle import unet_weights as UW
-    import model.SVD_2pass_prob_uncertain_post as P1
     unet = UNetSpatioTemporalConditionModel()
     shapes = {k: tuple(v.shape) for k, v in unet.state_dict().items()}
     unet.load_state_dict(UW.make_state_dict(shapes, seed=5))
     unet.eval()
     inp = PM.pipeline_inputs(seed=6)
-    orig_cuda = torch.Tensor.cuda
-    torch.Tensor.cuda = lambda self, *a, **k: self
-    orig = P1.randn_tensor
-    P1.randn_tensor = lambda shape, **k: inp["noise"].clone() if tuple(shape) == tuple(inp["noise"].shape) else orig(shape, **k)
     t0 = time.time()
-    try:
-        with torch.no_grad():
-            res = _reference_pipe(P1.StableVideoDiffusionPipeline, unet)(
-                inp["image"], temp_cond=inp["temp_cond"], mask=inp["mask"].clone(), lambda_ts=inp["lambda_ts"], num_frames=25,
-                decode_chunk_size=8, num_inference_steps=1, latent_num=1, latents=inp["latents"].clone(), output_type="latent")
-    finally:
-        P1.randn_tensor = orig
-        torch.Tensor.cuda = orig_cuda
-    lat = res.frames.float().numpy()
+    lat = _run_post_reference(_NoGradUNet(unet), inp, 1)
     print("pipeline_full post", lat.shape, float(np.abs(lat).mean()), f"{time.time() - t0:.0f} s", flush=True)
     np.savez_compressed(GOLD / "pipeline_unet_full_post.npz", post=lat[..., ::2, ::2], mean_abs=np.float64(np.abs(lat).mean()),
                         std=np.float64(lat.std()))
@@ -645,7 +693,9 @@ def main():
         gen_pipeline_real_unet()
     if "pipeline_full" in which:          # ~15 min of CPU, 1.52 B parameters
         gen_pipeline_full()
-    if "pipeline_full_post" in which:     # the Post variant at full size: run under `ulimit -v` (see gen_pipeline_full_post)
+    if "nograd_check" in which:           # ~5 min of CPU: the no-grad UNet wrapper reproduces the with-graph Post fixture
+        gen_nograd_check()
+    if "pipeline_full_post" in which:     # ~25 min of CPU: the Post variant at full size behind the no-grad wrapper
         gen_pipeline_full_post()
     if "pipeline_unet_vae" in which:      # ~10 min of CPU
         gen_pipeline_real_unet_vae()

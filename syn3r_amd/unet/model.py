@@ -341,8 +341,10 @@ class UNetSpatioTemporalConditionModel:
         return ent[1]
 
     def invalidate_context_cache(self) -> None:
-        """Forget every folded cross-attention vector (see `_context_cache`)."""
+        """Forget every folded cross-attention vector (see `_context_cache`) and every captured graph (their launches
+        read those vectors by address: a graph must not outlive the context it was captured with)."""
         self.__dict__.setdefault("_ctx_store", {}).clear()
+        self.__dict__.setdefault("_graphs", {}).clear()
 
     def w(self, name: str) -> torch.Tensor:
         return self.packed.get(name, self.p.t.get(name))
@@ -569,12 +571,13 @@ class UNetSpatioTemporalConditionModel:
             return self.forward(sample, timestep, encoder_hidden_states, added_time_ids, ctx_group=ctx_group)
         dev = L.require_gpu(sample, encoder_hidden_states, added_time_ids)
         ehs = encoder_hidden_states
+        # the timestep exactly as `forward` builds it (a Python float is a float64 scalar there): same embedding, bit for bit
+        ts = timestep if torch.is_tensor(timestep) else torch.tensor([timestep], dtype=torch.float64)
+        ts = ts.reshape(-1)[:1].to(dev)
         key = (tuple(sample.shape), ctx_group, ehs.untyped_storage().data_ptr(), ehs.storage_offset(), tuple(ehs.shape),
-               tuple(ehs.stride()), ehs._version, tuple(added_time_ids.shape))
+               tuple(ehs.stride()), ehs._version, tuple(added_time_ids.shape), ts.dtype)
         graphs = self.__dict__.setdefault("_graphs", {})
         ent = graphs.get(key)
-        ts = timestep if torch.is_tensor(timestep) else torch.tensor([float(timestep)])
-        ts = ts.reshape(-1)[:1].to(device=dev, dtype=torch.float32)
         if ent is None:
             if len(graphs) >= 8:
                 graphs.pop(next(iter(graphs)))
@@ -589,8 +592,16 @@ class UNetSpatioTemporalConditionModel:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
                 y = self.forward(s_in, t_in, ehs, a_in, ctx_group=ctx_group)[0]
-            ent = graphs[key] = (g, s_in, t_in, a_in, y, ehs)
-        g, s_in, t_in, a_in, y, _ = ent
+            # Everything the captured launches address that lives OUTSIDE the graph's private pool is pinned by the entry:
+            # the folded cross-attention vectors (allocated by the warm-up; `_ctx_store` evicts FIFO and is cleared by
+            # invalidate_context_cache) and the scratch buffers `L.workspace` handed out on the capture stream (replaced
+            # when a larger request arrives on a recycled stream handle).  The stream object stays too, so its handle
+            # is not given to another stream while this graph lives.
+            shared_ctx = sample.shape[0] == 1 or ehs.stride(0) == 0          # as `forward` keys its context cache
+            pinned = (self._context_cache(ehs, shared_ctx),
+                      [buf for (di, st_, _tag), buf in L._ws_cache.items() if di == dev.index and st_ == side.cuda_stream], side)
+            ent = graphs[key] = (g, s_in, t_in, a_in, y, ehs, pinned)
+        g, s_in, t_in, a_in, y = ent[:5]
         s_in.copy_(sample)
         t_in.copy_(ts)
         a_in.copy_(added_time_ids)

@@ -58,3 +58,20 @@ def test_two_rank_job_on_one_device(gpu, tmp_path):
     assert b["n_gpus"] == 2 and len(b["per_rank"]) == 2 and [row[0] for row in b["per_rank"]] == [0.0, 1.0]
     assert all(row[-1] == 1.0 and row[-2] == 0.0 for row in b["per_rank"])
     assert abs(b["value"] - 2 * 5 * 1000.0 / b["ms_per_step"]) < 0.02 * b["value"]       # whole-job iterations / max-over-ranks time
+
+
+def test_gpus_flag_starts_the_ranks_itself(gpu):
+    """`python bench.py --gpus 2` with no torchrun around it (how the driver runs `--gpus 1`): bench.py starts the two ranks
+    as a child torchrun job and relays ONE line with n_gpus = 2 (replaces bash_scripts/batch_llff_train.sh:24-47)."""
+    import os
+    env = dict(os.environ, SYN3R_BENCH_SINGLE_DEVICE="1", SYN3R_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--raster-iters", "5",
+                        "--svd", "off", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and len(b["per_rank"]) == 2 and [row[0] for row in b["per_rank"]] == [0.0, 1.0]
+    assert abs(b["value"] - 2 * 5 * 1000.0 / b["ms_per_step"]) < 0.02 * b["value"]

@@ -156,7 +156,19 @@ def test_captured_forward_replays_bit_identical(gpu):
     for tt, scale in ((t, 1.0), (0.37, 0.5), (torch.tensor(1.2, device=gpu), 2.0)):
         x = (s * scale).contiguous()
         assert torch.equal(model.forward_graphed(x, tt, e, a)[0], model(x, tt, e, a)[0])
-    assert len(model._graphs) == 1
+    assert len(model._graphs) == 2                     # one per timestep dtype (float64 scalars, the float32 tensor)
+    # the graph entry pins what its launches address outside the graph's pool: drop the model's context store and the
+    # library's scratch cache, churn the allocator, replay - the result is still the eager one
+    from syn3r_amd import _lib as L
+    ref = model(s, t, e, a)[0]
+    model._ctx_store.clear()
+    L._ws_cache.clear()
+    junk = [torch.full((1 << 22,), 7.0, device=gpu) for _ in range(8)]
+    assert torch.equal(model.forward_graphed(s, t, e, a)[0], ref)
+    del junk
+    model.invalidate_context_cache()
+    assert len(model._graphs) == 0                     # a graph does not outlive the contexts it was captured with
+    assert torch.equal(model.forward_graphed(s, t, e, a)[0], ref) and len(model._graphs) == 1
     x2 = s[..., :16].contiguous()                      # 16 x 16: an even pixel count at the coarsest level too
     assert torch.equal(model.forward_graphed(x2, t, e, a)[0], model(x2, t, e, a)[0]) and len(model._graphs) == 2
     s4 = torch.cat([s, s * 0.7])
