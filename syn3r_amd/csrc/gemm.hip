@@ -569,6 +569,9 @@ __device__ __forceinline__ void lean_store(const GemmParams& p, float4v (*acc)[T
     constexpr int NQ = NI * 16 * (WN / 8) / 64;   // 10 (NI = 4) or 5 (NI = 2) chunks of 16 bytes per lane
     auto put = [&](int m, int n, const half8& v) {
         if (!(full || (m < p.M && n < N))) return;
+#ifdef Z_EXP_NOSTORE        // timing experiment (wrong results): the epilogue without its global stores
+        if ((float)v[0] != 12345.678f) return;
+#endif
         if (p.out_tiled) OUT_STORE((half8*)(p.out + tiled_off(m, n, N)), v);
         else OUT_STORE((half8*)(p.out + (long long)m * p.ldc + n), v);
     };
@@ -874,6 +877,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm_widep(GemmParams p) {
 #endif
 #undef PSTAMP
 }
+
+#include "gemm_z.h"
 
 // ---------------------------------------------------------------------------------------------
 // PERSISTENT form of the 256-row LDS-DMA kernel (k_gemm_dma<MODE, 256>), used for the temporal convolutions and the dense
@@ -1536,6 +1541,38 @@ int launch_widep(const GemmParams& p, hipStream_t stream) {
     return SYN3R_OK;
 }
 
+int launch_z(const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_z<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Z_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_z<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Z_LDS);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_z)");
+        attr_set = true;
+    }
+    int tiles = ((p.M + WBM - 1) / WBM) * ((p.N + WBN - 1) / WBN);
+    const int blocks = std::min(tiles, persistent_blocks());
+    char name[96];
+    if (trace_on()) {
+        if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_z[M%d,N%d,K%d,e%d]", p.M, p.N, p.K, p.geglu_D > 0 ? 2 : (p.residual != nullptr));
+        else snprintf(name, sizeof(name), "k_gemm_z");
+    }
+    if (p.A2) SYN3R_LAUNCH_NAMED(name, k_gemm_z<true>, dim3(blocks), dim3(512), Z_LDS, stream, p);
+    else SYN3R_LAUNCH_NAMED(name, k_gemm_z<false>, dim3(blocks), dim3(512), Z_LDS, stream, p);
+    SYN3R_LAUNCH_CHECK("gemm_z launch");
+    return SYN3R_OK;
+}
+
+// Which of the two persistent 256 x 320 kernels: measured inside the UNet unit on one box (tools/gemm_ab.py SYN3R_GEMM_Z 0 1,
+// profiles/r04/gemm_z_ab.txt) the software-pipelined k_gemm_z is 1.6..3.5 % faster on the gated projections and 1..5 %
+// slower on the residual-add ones, a wash on their sum (74.33 against 74.23 ms): it takes the gated shapes.
+// SYN3R_GEMM_Z overrides (tuning): 0 = never, 1 = every shape the 256 x 320 tile is chosen for.
+int wide_launch(const GemmParams& p, hipStream_t stream) {
+    static int z_env = -2;
+    if (z_env == -2) { const char* e = getenv("SYN3R_GEMM_Z"); z_env = e ? atoi(e) : -1; }
+    const bool z = z_env < 0 ? p.geglu_D > 0 : z_env != 0;
+    return z ? launch_z(p, stream) : launch_widep(p, stream);
+}
+
 // Does the persistent 256 x 320 kernel take this contraction?  Lean epilogue (no row vector together with a gate, aux only
 // with a residual, a gate of whole 16-byte chunks and s_acc = 1), 32-bit byte offsets inside the operands, M and N
 // multiples of 8.  Everything else goes to the 160-column kernels, whose epilogue is general.
@@ -1612,7 +1649,7 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
     if (w128_env == -2) { const char* e = getenv("SYN3R_GEMM_W128"); w128_env = e ? atoi(e) : -1; }
     const bool wide_ok = MODE == MODE_DENSE && widep_admits(p);
     if (g_dma_bm == -321) { if constexpr (MODE == MODE_DENSE) return launch_w128(p, stream); }   // syn3r_gemm_set_tile(-321)
-    if (g_dma_bm == -320 && wide_ok) return launch_widep(p, stream);                              // syn3r_gemm_set_tile(-320)
+    if (g_dma_bm == -320 && wide_ok) return wide_launch(p, stream);                               // syn3r_gemm_set_tile(-320)
     if (g_dma_bm == 0 && wide_env != 0 && wide_ok) {
         // measured on MI355X inside the UNet (tools/gemm_ab.py, same box): the 256 x 320 tile is 7..14 % faster on
         // the dense contractions whenever its tiles fill the 256 CUs (last round >= 80 % full), except the
@@ -1632,7 +1669,7 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
             // (round 2, persistent 256-row kernel with the lean epilogue: it now wins the K = 320 shapes of one or two tile
             // columns by 12..20 % and ties on qkv, N = 960, which stays here)
             if constexpr (MODE == MODE_DENSE) { if (w128_env == 1 || (w128_env != 0 && p.K <= 320 && p.N > 640)) return launch_w128(p, stream); }
-            return launch_widep(p, stream);
+            return wide_launch(p, stream);
         }
     }
     // 256-row blocks (eight wavefronts, wavefronts 4-7 staggered by half a k-tile against their SIMD partners) against
@@ -1765,7 +1802,7 @@ extern "C" int syn3r_gemm_2src_f16(const void* A1, long long lda1, int K1, const
     // only the persistent 256 x 320 kernel reads two sources; syn3r_gemm_2src_supported() is its admission test
     SYN3R_REQUIRE(syn3r_gemm_2src_supported(M, N, K1, K2, lda1, lda2) != 0,
                   "gemm_2src: shape M=%d N=%d not served by the two-source kernel (concatenate and call syn3r_gemm_f16)", M, N);
-    return launch_widep(p, (hipStream_t)stream);
+    return wide_launch(p, (hipStream_t)stream);
 }
 
 extern "C" int syn3r_gemm_geglu_f16(const void* A, long long lda, const void* Wpacked, const void* bias_packed, void* out,

@@ -1,0 +1,373 @@
+// k_gemm_z: the persistent 256 x 320 dense contraction with a SOFTWARE-PIPELINED main loop (round 4).  Included by gemm.hip
+// (inside its anonymous namespace, after GemmParams / rowvec_index / tiled_off / OUT_STORE / the LDS-DMA typedefs).
+//
+// What it replaces and why: k_gemm_widep opened every k-tile with
+// `s_waitcnt vmcnt(0)` + barrier and only THEN read its fragments - all eight wavefronts at once, 14 x ds_read_b128 drained by
+// lgkmcnt(0) in front of each block of 40 MFMAs - so a wavefront never overlapped its own LDS reads with its own MFMAs
+// (4 100 cycles per k-tile for 2 560 of matrix work, MFMA busy 0.39).  Here the same tile, ring and DMA pieces run as three
+// streams per wavefront that only meet at ONE barrier per k-tile:
+//   read stream   the B (weight) fragment of MFMA group Q + 3 is requested before group Q's four MFMAs issue (ring of four
+//                 fragment registers, counted lgkmcnt), the four A fragments of the next k-half land in a second register set
+//                 while the current k-half multiplies: 160 accumulators + 32 + 16 fragment registers;
+//   MFMA stream   20 groups of 4 per k-tile (weight fragment j against the four row fragments), never waiting for more than
+//                 the one fragment it is about to use;
+//   DMA stream    the nine LDS-DMA pieces of the NEXT k-tile go out one per group in groups 0-8, into the ring slot the
+//                 previous barrier released, and have until group 17 to land.
+// The barrier sits where the READ stream crosses from k-tile G to G + 1 (group 17): in front of it `lgkmcnt(0)` (this
+// wavefront has no read of slot G left: WAR for the DMA that refills it) and `vmcnt(0)` (its pieces of k-tile G + 1 have
+// landed - they were requested >= 8 groups earlier; behind the barrier everybody's have: RAW); behind it the first reads of
+// k-tile G + 1, while the MFMAs of groups 18-19 still run from registers.  Nothing is drained in front of matrix work.
+// The DMA cursor runs on across tile boundaries (stage 0 of the next tile is requested during this tile's last k-tile and is
+// landed and visible when the epilogue ends); the epilogue (k_gemm_widep's lean_store) stages through the ring slot that was
+// read last plus a 16 KB gap between the slots, and the output stores are acknowledged under the next tile's k-loop (their
+// vmcnt is first waited for at that tile's group 17).
+// Reference semantics: nn.Linear / 1x1 convolutions / GEGLU of diffusers attention.py:608-665, resnet.py:316,
+// activations.py GEGLU.forward - identical arithmetic to k_gemm_widep (same MFMA order per accumulator: k ascending).
+
+// LDS: [slot 0: 73,728 B][gap 16,384 B][slot 1: 73,728 B] = 163,840 B.  The epilogue stages a tile's accumulators through the
+// slot whose k-tile was read last plus the gap (8 x 11,264 B = 90,112 B contiguous either way: slot 0 + gap or gap + slot 1).
+constexpr int Z_SLOT1 = W_STAGE + 16384;          // 90,112: byte offset of ring slot 1
+constexpr int Z_LDS = Z_SLOT1 + W_STAGE;          // 163,840
+
+#define Z_DS_READ128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
+
+// Pieces of the main loop as function templates (inline asm in a generic lambda does not capture its operands with this
+// compiler): fragment reads, the MFMA group, the counted wait.  Everything is forced inline; the arrays are the kernel's.
+template <int KH>
+__device__ __forceinline__ void z_read_a(half8 (&af)[2][TM], const unsigned (&ra)[2]) {
+    Z_DS_READ128(af[KH][0], ra[KH], 0); Z_DS_READ128(af[KH][1], ra[KH], 2048);
+    Z_DS_READ128(af[KH][2], ra[KH], 4096); Z_DS_READ128(af[KH][3], ra[KH], 6144);
+}
+template <int Q, int RB>      // weight fragment of group Q (0..19) of the k-tile the read cursor is in
+__device__ __forceinline__ void z_read_b(half8 (&bf)[RB], const unsigned (&rb)[2]) {
+    Z_DS_READ128(bf[Q % RB], rb[Q / 10], (Q % 10) * 2048);
+}
+template <int Q, int RB>
+__device__ __forceinline__ void z_mma(float4v (&acc)[2][TM][TN], half8 (&af)[2][TM], half8 (&bf)[RB]) {
+    constexpr int kh = Q / 10, j = Q % 10;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+        acc[j / TN][i][j % TN] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[Q % RB], af[kh][i], acc[j / TN][i][j % TN], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+// wait until at most N LDS reads are outstanding; the group's fragment registers are then valid (ties its MFMAs behind the wait)
+template <int Q, int RB, int N>
+__device__ __forceinline__ void z_wait(half8 (&af)[2][TM], half8 (&bf)[RB]) {
+    constexpr int kh = Q / 10, j = Q % 10;
+    if constexpr (j == 0)
+        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(bf[Q % RB]), "+v"(af[kh][0]), "+v"(af[kh][1]), "+v"(af[kh][2]), "+v"(af[kh][3]) : "i"(N));
+    else
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bf[Q % RB]) : "i"(N));
+}
+
+// TWOSRC: the A columns from K1 on come from a second tensor (GemmParams::A2; the up blocks' shortcut projections)
+template <bool TWOSRC>
+__global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int tiles_n = (p.N + WBN - 1) / WBN;
+    const int tiles_m = (p.M + WBM - 1) / WBM;
+    const unsigned nblk = (unsigned)(tiles_m * tiles_n);
+    const unsigned xcd = blockIdx.x % 8, q8 = nblk / 8, r8 = nblk % 8;
+    const unsigned t_start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const unsigned t_len = q8 + (xcd < r8 ? 1u : 0u);
+    const unsigned t_stride = (gridDim.x - xcd + 7) / 8;
+    const int nkt = p.K / BK;
+    // tile order: bands of 4 tile columns, row-major inside a band (as k_gemm_widep: the 32 tiles an XCD holds at a time are
+    // 8 rows x 4 columns and the band's weight panel is what that XCD's L2 keeps)
+    const unsigned bw = tiles_n >= 4 ? 4u : (unsigned)tiles_n;
+    const unsigned band_sz = (unsigned)tiles_m * bw, full_bands = (unsigned)tiles_n / bw;
+    auto tile_origin = [&](unsigned tile, int& m0, int& n0, int& tn) {
+        unsigned b = tile / band_sz, w = bw, t2 = tile - b * band_sz;
+        if (b >= full_bands) { b = full_bands; t2 = tile - full_bands * band_sz; w = (unsigned)tiles_n - full_bands * bw; }
+        tn = (int)(b * bw + t2 % w);
+        m0 = (int)(t2 / w) * WBM; n0 = tn * WBN;
+    };
+
+    // ---- DMA cursor (scalar state): the k-tile stage that is requested next, numbered through the block's whole tile list.
+    // The cursor never runs dry inside the loop: once the list is exhausted (only the block's very last k-tile iteration gets
+    // there) it keeps re-requesting the last stage - valid addresses, into the slot nobody reads again - so that the main loop
+    // has no "is there a next stage" branch around its nine DMA instructions.
+    unsigned oa[4], ob[5];                                     // byte offsets of this wavefront's 4 A and 5 B pieces
+    const unsigned a_step = p.a_tiled ? 16384u : 2u * BK;
+    const char* abase = (const char*)p.A;
+    const int kt_switch = TWOSRC ? p.K1 / BK : 0x7fffffff;
+    unsigned c_tl = blockIdx.x / 8;                            // cursor: position in the tile list ...
+    int c_ks = 0, c_m0 = 0;                                    // ... k-tile inside that tile, its row origin
+    unsigned c_slot = 0;                                       // ring slot (byte offset) of the stage being requested
+    unsigned voff_a, voff_a2 = 0, voff_b;                      // per-lane byte offset inside a piece
+    {
+        const int prow = lane >> 3, csrc = (lane & 7) ^ prow;
+        voff_a = p.a_tiled ? (unsigned)((prow * 64 + csrc * 8) * 2) : (unsigned)(prow * (int)p.lda + csrc * 8) * 2u;
+        if constexpr (TWOSRC) voff_a2 = (unsigned)(prow * (int)p.lda2 + csrc * 8) * 2u;
+        voff_b = (unsigned)(prow * p.K + csrc * 8) * 2u;
+    }
+    bool second = false;                                       // the stage being requested reads the second source
+    auto cursor_begin = [&]() {
+        if (c_tl >= t_len) return;                             // exhausted: the previous stage's offsets again
+        if (c_ks == 0) {
+            int n0_, tn_;
+            tile_origin(t_start + c_tl, c_m0, n0_, tn_);
+            abase = (const char*)p.A;
+            second = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int r = c_m0 + wv * 32 + i * 8;
+                r = r < p.M - 8 ? r : p.M - 8;
+                if (p.a_tiled) oa[i] = 2u * ((unsigned)(r >> 7) * (unsigned)(p.K >> 6) * 8192u + (unsigned)(r & 127) * 64u);
+                else oa[i] = 2u * (unsigned)r * (unsigned)p.lda;
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                int n = n0_ + (wv * 5 + j) * 8;
+                n = n < p.N - 8 ? n : p.N - 8;
+                ob[j] = 2u * (unsigned)n * (unsigned)p.K;
+            }
+        } else if (TWOSRC && c_ks == kt_switch) {              // from here on the A columns come from the second source
+            abase = (const char*)p.A2;
+            second = true;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int r = c_m0 + wv * 32 + i * 8;
+                r = r < p.M - 8 ? r : p.M - 8;
+                oa[i] = 2u * (unsigned)r * (unsigned)p.lda2;
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) ob[j] += 2u * BK;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) oa[i] += a_step;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) ob[j] += 2u * BK;
+        }
+        if (++c_ks == nkt) { c_ks = 0; c_tl += t_stride; }
+    };
+    auto cursor_end = [&]() { c_slot = c_slot ? 0u : (unsigned)Z_SLOT1; };
+    // piece IDX of the stage the cursor points at: 0-3 = A, 4-8 = B
+    auto piece = [&](auto IDX) {
+        constexpr int idx = decltype(IDX)::value;
+#ifdef Z_EXP_NODMA          // timing experiment (wrong results): the main loop without its DMA stream
+        if (c_tl != 0xffffffffu) return;
+#endif
+#ifdef Z_EXP_DMAHOT         // timing experiment (wrong results): every piece re-reads ONE cache-resident KiB (issue + LDS write only)
+        if (c_tl != 0xffffffffu) {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.W + (size_t)voff_b), (lds_void_t*)(smem_raw + c_slot + (wv * 9 + idx) * 1024), 16, 0, 0);
+            return;
+        }
+#endif
+        char* st = smem_raw + c_slot;
+#ifdef Z_EXP_HALFISSUE      // timing experiment (M % 256 == 0 shapes): wavefronts 0-3 issue their SIMD partners' pieces too, 4-7 none
+        if (wv >= 4) return;
+        if constexpr (idx < 4) {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase + (size_t)(oa[idx] + voff_a)), (lds_void_t*)(st + (wv * 4 + idx) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase + (size_t)(oa[idx] + 256u * (unsigned)p.lda + voff_a)), (lds_void_t*)(st + ((wv + 4) * 4 + idx) * 1024), 16, 0, 0);
+        } else {
+            constexpr int j = idx - 4;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.W + (size_t)(ob[j] + voff_b)), (lds_void_t*)(st + W_A_BYTES + (wv * 5 + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.W + (size_t)(ob[j] + 320u * (unsigned)p.K + voff_b)), (lds_void_t*)(st + W_A_BYTES + ((wv + 4) * 5 + j) * 1024), 16, 0, 0);
+        }
+        return;
+#endif
+        if constexpr (idx < 4) {
+            const unsigned va = (TWOSRC && second) ? voff_a2 : voff_a;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase + (size_t)(oa[idx] + va)), (lds_void_t*)(st + (wv * 4 + idx) * 1024), 16, 0, 0);
+        } else {
+            constexpr int j = idx - 4;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.W + (size_t)(ob[j] + voff_b)), (lds_void_t*)(st + W_A_BYTES + (wv * 5 + j) * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addressing: [k-half] byte addresses inside the slot being READ
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
+    unsigned ra[2], rb[2];
+    {
+        const int fr = lane & 15, fq = lane >> 4;
+        const unsigned a_row = (unsigned)((wm * WM + fr) * 128), b_row = (unsigned)(W_A_BYTES + (wn * 160 + fr) * 128);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const unsigned sw = (unsigned)(((kh * 4 + fq) ^ (fr & 7)) << 4);
+            ra[kh] = lds0 + a_row + sw; rb[kh] = lds0 + b_row + sw;
+        }
+    }
+    unsigned rslot = 0;                                        // 0 / Z_SLOT1: the slot ra / rb point into
+    auto flip_read_slot = [&]() {
+        const unsigned d = rslot ? (unsigned)(-Z_SLOT1) : (unsigned)Z_SLOT1;
+        ra[0] += d; ra[1] += d; rb[0] += d; rb[1] += d;
+        rslot = rslot ? 0u : (unsigned)Z_SLOT1;
+    };
+
+    // ---- the three streams of a k-tile, as compile-time schedules (Z_LA: how many weight fragments the read stream runs ahead)
+#ifndef Z_LA
+#define Z_LA 3
+#endif
+    constexpr int LA = Z_LA, RB = LA + 1;             // B-fragment ring; 20 % RB == 0 keeps the ring index a function of the group
+    static_assert(20 % RB == 0 && LA >= 3 && LA <= 9, "ring of 4, 5 or 10 weight fragments");
+    float4v acc[2][TM][TN];               // [column half][row tile][column tile]: halves are 80 columns each
+    half8 af[2][TM], bf[RB];              // A fragments of the two k-halves; ring of weight fragments
+
+    // ---- kernel prologue: stage 0 of the first tile, complete and visible before the first read
+    cursor_begin();
+    piece(std::integral_constant<int, 0>{}); piece(std::integral_constant<int, 1>{}); piece(std::integral_constant<int, 2>{});
+    piece(std::integral_constant<int, 3>{}); piece(std::integral_constant<int, 4>{}); piece(std::integral_constant<int, 5>{});
+    piece(std::integral_constant<int, 6>{}); piece(std::integral_constant<int, 7>{}); piece(std::integral_constant<int, 8>{});
+    cursor_end();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // group q of the steady stream (q <= 16): [DMA piece] [the A fragments of k-half 1 at q = 7] the weight fragment LA groups
+    // ahead, the counted wait for this group's own fragment, four MFMAs.  Outstanding reads allowed at the wait = the reads
+    // issued after the one the group needs: LA (fewer at the tail), + 4 while the A reads of group 7 are among them.
+    auto group_piece = [&](auto QC) {
+        constexpr int q = decltype(QC)::value;
+        constexpr int order[9] = {0, 4, 1, 5, 2, 6, 3, 7, 8};     // A and B pieces alternate
+        if constexpr (q < 9) piece(std::integral_constant<int, order[q < 9 ? q : 0]>{});
+        if constexpr (q == 8) cursor_end();
+    };
+#define Z_YOUNGER(q) ((19 - (q) < LA ? 19 - (q) : LA) + (((q) >= 7 && (q) < 7 + LA && (q) != 10) ? 4 : 0))
+// (group 10 also needs the A reads of group 7: allowed = the weight reads issued behind them, B(7 + LA) .. B(min(10 + LA, 19)))
+#define Z_NWAIT(q) ((q) == 10 ? (LA < 4 ? LA : ((10 + LA < 19 ? 10 + LA : 19) - (7 + LA) + 1)) : Z_YOUNGER(q))
+#ifdef Z_PIECE_AFTER        // the group's DMA piece behind its MFMAs instead of in front of its reads
+#define Z_GROUP(q) do { \
+        if constexpr ((q) == 7) z_read_a<1>(af, ra); \
+        if constexpr ((q) + LA <= 19) z_read_b<((q) + LA <= 19 ? (q) + LA : 0), RB>(bf, rb); \
+        z_wait<(q), RB, Z_NWAIT(q)>(af, bf); \
+        z_mma<(q), RB>(acc, af, bf); \
+        group_piece(ZQ(q)); } while (0)
+#else
+#define Z_GROUP(q) do { \
+        group_piece(ZQ(q)); \
+        if constexpr ((q) == 7) z_read_a<1>(af, ra); \
+        if constexpr ((q) + LA <= 19) z_read_b<((q) + LA <= 19 ? (q) + LA : 0), RB>(bf, rb); \
+        z_wait<(q), RB, Z_NWAIT(q)>(af, bf); \
+        z_mma<(q), RB>(acc, af, bf); } while (0)
+#endif
+#define ZQ(q) std::integral_constant<int, q>{}
+
+#ifdef SYN3R_TIMING         // tools/z_timing.py: s_memtime ticks per segment of the k-tile loop, summed per wavefront of one block
+    unsigned long long zt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, z_a = __builtin_amdgcn_s_memtime();
+#define ZSTAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); zt[i] += t_ - z_a; z_a = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ZSTAMP(i)
+#endif
+    for (unsigned tl = blockIdx.x / 8; tl < t_len; tl += t_stride) {
+        int m0, n0, tile_n;
+        tile_origin(t_start + tl, m0, n0, tile_n);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[hh][i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+        // (the fragment registers are outputs of asm reads: redefined per tile, or they all stay live through the epilogue)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { asm volatile("" : "=v"(af[0][i])); asm volatile("" : "=v"(af[1][i])); }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) asm volatile("" : "=v"(bf[j]));
+        // read prologue of the tile: the first k-half's A fragments and the first LA weight fragments (landed and visible)
+        z_read_a<0>(af, ra);
+        z_read_b<0, RB>(bf, rb); z_read_b<1, RB>(bf, rb); z_read_b<2, RB>(bf, rb);
+        if constexpr (LA >= 4) z_read_b<3, RB>(bf, rb);
+        if constexpr (LA >= 9) { z_read_b<4, RB>(bf, rb); z_read_b<5, RB>(bf, rb); z_read_b<6, RB>(bf, rb); z_read_b<7, RB>(bf, rb); z_read_b<8, RB>(bf, rb); }
+        for (int kt = 0; kt < nkt; ++kt) {
+            // groups 0-8 carry the nine DMA pieces of the NEXT stage (into the slot the previous barrier released)
+            ZSTAMP(5);
+            cursor_begin();
+            Z_GROUP(0); Z_GROUP(1); Z_GROUP(2); Z_GROUP(3); Z_GROUP(4); Z_GROUP(5); Z_GROUP(6); Z_GROUP(7);
+            Z_GROUP(8);
+            ZSTAMP(0);
+            Z_GROUP(9); Z_GROUP(10); Z_GROUP(11); Z_GROUP(12); Z_GROUP(13); Z_GROUP(14); Z_GROUP(15);
+            Z_GROUP(16);
+            ZSTAMP(1);
+            // group 17: the read stream leaves this k-tile.  Everything this wavefront read from the slot has arrived
+            // (lgkmcnt(0): the slot may be refilled), its pieces of the next stage have landed (vmcnt(0)); barrier.
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[17 % RB]), "+v"(bf[18 % RB]), "+v"(bf[19 % RB]));
+            z_mma<17, RB>(acc, af, bf);
+            ZSTAMP(2);
+#ifndef Z_EXP_NOVMWAIT      // timing experiment (wrong results): what the wait for the next stage's DMA costs
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            ZSTAMP(3);
+            __builtin_amdgcn_s_barrier();
+            ZSTAMP(4);
+            flip_read_slot();
+#ifdef SYN3R_TIMING
+            ++zt[7];
+#endif
+            // the first reads of the next k-tile, while groups 18 and 19 still multiply from registers (not behind a tile's
+            // last k-tile: the epilogue wants the registers; the next tile starts with the read prologue above)
+            if (kt + 1 < nkt) {
+                z_read_a<0>(af, ra);
+                z_read_b<0, RB>(bf, rb);
+                if constexpr (LA >= 9) { z_read_b<1, RB>(bf, rb); z_read_b<2, RB>(bf, rb); }
+                z_mma<18, RB>(acc, af, bf);
+                if constexpr (LA >= 9) { z_read_b<3, RB>(bf, rb); z_read_b<4, RB>(bf, rb); z_read_b<5, RB>(bf, rb); }
+                else z_read_b<1, RB>(bf, rb);
+                z_mma<19, RB>(acc, af, bf);
+                if constexpr (LA >= 9) { z_read_b<6, RB>(bf, rb); z_read_b<7, RB>(bf, rb); z_read_b<8, RB>(bf, rb); }
+                else z_read_b<2, RB>(bf, rb);
+                if constexpr (LA == 4) z_read_b<3, RB>(bf, rb);
+            } else {
+                z_mma<18, RB>(acc, af, bf);
+                z_mma<19, RB>(acc, af, bf);
+            }
+        }
+        ZSTAMP(5);
+        // ---- epilogue.  Staging = the slot read last (the read cursor has already moved on to the other one) + the gap.
+        // Lane-derived indices behind an opaque copy of the lane id: hoisted out of the tile loop they would be carried
+        // through the k-loop in registers the accumulators do not leave.
+        int le = lane;
+        asm volatile("" : "+v"(le));
+#ifdef Z_EXP_NOEPI          // timing experiment (wrong results): no epilogue at all
+        if (p.M > 0) { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][3][4])); __builtin_amdgcn_s_barrier(); continue; }
+#endif
+        char* const epi = smem_raw + (rslot ? 0 : W_STAGE);
+        const int gm0 = m0 + wm * WM;
+        if (p.geglu_D > 0) {
+            // GEGLU.forward: hidden * gelu(gate) on the fp16-rounded projection output; the wavefront's 160 columns are one
+            // packed group [80 hidden | 80 gate]
+            const int fq = le >> 4;
+            const int gn = n0 + wn * 160;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = gn + j * 16 + fq * 4;
+                float bh[4], bg[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bh[r] = (p.bias && n + r < p.N) ? __half2float(p.bias[n + r]) : 0.f;
+                    bg[r] = (p.bias && n + 80 + r < p.N) ? __half2float(p.bias[n + 80 + r]) : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const syn3r_f2 hv = (syn3r_f2){(float)(_Float16)(acc[0][i][j][r] + bh[r]), (float)(_Float16)(acc[0][i][j][r + 1] + bh[r + 1])};
+                        const syn3r_f2 gv = (syn3r_f2){(float)(_Float16)(acc[1][i][j][r] + bg[r]), (float)(_Float16)(acc[1][i][j][r + 1] + bg[r + 1])};
+                        const syn3r_f2 y = hv * gelu_pk(gv);
+                        acc[0][i][j][r] = y.x; acc[0][i][j][r + 1] = y.y;
+                    }
+            }
+            const int go0 = tile_n * 160 + wn * WN;
+            const bool full = gm0 + WM <= p.M && go0 + WN <= p.geglu_D;
+            widep_store(p, acc[0], epi, le, wv, gm0, go0, p.geglu_D, nullptr, nullptr, nullptr, full);
+        } else {
+            const int gn0 = n0 + wn * 160;
+            const bool full = gm0 + WM <= p.M && gn0 + 160 <= p.N;
+            widep_store(p, acc[0], epi, le, wv, gm0, gn0, p.N, p.bias, p.residual, p.aux, full);
+            widep_store(p, acc[1], epi, le, wv, gm0, gn0 + WN, p.N, p.bias, p.residual, p.aux, full);
+        }
+        // every wavefront is done with the staging area before the next tile's first DMA piece refills that slot
+        __builtin_amdgcn_s_barrier();
+        ZSTAMP(6);
+    }
+#ifdef SYN3R_TIMING
+    if (blockIdx.x == gridDim.x / 2 && lane == 0)
+        for (int i = 0; i < 8; ++i) g_wide_timing[wv * 8 + i] = zt[i];
+#endif
+#undef ZSTAMP
+#undef ZQ
+#undef Z_GROUP
+#undef Z_NWAIT
+#undef Z_YOUNGER
+}
