@@ -562,6 +562,26 @@ def gen_pipeline_real_unet_vae():
     np.savez_compressed(GOLD / "pipeline_unet_vae.npz", frames=frames[:, ::16, ::16])
 
 
+def gen_clip_preprocess():
+    """The reference pipelines' CLIP preprocessing (`_encode_image`, …post.py:229-258): [-1,1], `_resize_with_antialiasing` to
+    224 x 224 (the reference's own function, imported), back to [0,1], the feature extractor's mean / std normalisation written
+    out as the arithmetic it is (transformers' CLIPImageProcessor with resize / crop / rescale switched off).  Two seeded
+    images (golden_inputs.clip_image): 576 x 1024 (the pipelines' size) and 378 x 504 (an LLFF-like aspect); every second
+    pixel of the 224 x 224 result is stored."""
+    import model.SVD_2pass_prob_uncertain_post as P1
+    out = {}
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(1, 3, 1, 1)
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(1, 3, 1, 1)
+    for tag, (h, w) in GI.CLIP_CASES.items():
+        img8 = torch.from_numpy(GI.clip_image(h, w)).float().div(255).permute(2, 0, 1)[None]      # pil_to_numpy / numpy_to_pt
+        x = (P1._resize_with_antialiasing(img8 * 2.0 - 1.0, (224, 224)) + 1.0) / 2.0
+        px = ((x - mean) / std).numpy()
+        out[f"px_{tag}"] = px[..., ::2, ::2]
+        out[f"mean_abs_{tag}"] = np.float64(np.abs(px).mean())
+        print("clip", tag, px.shape, float(np.abs(px).mean()))
+    np.savez_compressed(GOLD / "clip_preprocess.npz", **out)
+
+
 def gen_orchestrator():
     """Pure-numpy methods of the reference's DiffusionGS (model/diffusionGS.py:1120-1296).  The module
     imports packages that are absent here (FSGS submodule, cv2, open3d, trimesh); they are not touched by
@@ -699,6 +719,8 @@ def main():
         gen_pipeline_full_post()
     if "pipeline_unet_vae" in which:      # ~10 min of CPU
         gen_pipeline_real_unet_vae()
+    if "clip" in which:
+        gen_clip_preprocess()
     if "orch" in which:
         gen_orchestrator()
     if "n2" in which:

@@ -162,3 +162,16 @@ N2_CASES = {
 def n2_mask_means(n, seed=0):
     """Mean of the mock correspondence mask per candidate frame (the keep rule thresholds it at 0.3, diffusionGS.py:385)."""
     return np.random.default_rng(200 + seed).random(n).astype(np.float32)
+
+
+def clip_image(h: int, w: int):
+    """Seeded smooth-plus-noise HWC uint8 image, as the orchestrator hands views to the pipeline (oracle/gen_golden.py clip)."""
+    import torch
+    g = torch.Generator().manual_seed(h)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    img = torch.stack([0.5 + 0.4 * torch.sin(xs / (11 + 3 * c)) * torch.cos(ys / (7 + 2 * c)) for c in range(3)])
+    img = (img + 0.1 * torch.rand(3, h, w, generator=g)).clamp(0, 1)
+    return (img.permute(1, 2, 0) * 255).round().to(torch.uint8).numpy()
+
+
+CLIP_CASES = {"a": (576, 1024), "b": (378, 504)}

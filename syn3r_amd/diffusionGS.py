@@ -144,11 +144,21 @@ class DiffusionGS:
         """diffusionGS.py:1088-1116.  The reference re-downloads the checkpoint by model name on every call; here the
         modules are supplied once (`svd_components`: vae, image_encoder, unet) and stay resident."""
         if not self.svd_components:
-            raise RuntimeError("svd_render needs svd_components={'vae':…, 'image_encoder':…, 'unet':…} (local modules; "
-                               "the reference fetches stabilityai/stable-video-diffusion-img2vid-xt by name)")
+            raise RuntimeError("svd_render needs svd_components: a local checkpoint directory (str / Path: loaded once with "
+                               "StableVideoDiffusionPipeline.from_pretrained) or {'vae':…, 'image_encoder':…, 'unet':…} "
+                               "modules; the reference fetches stabilityai/stable-video-diffusion-img2vid-xt by name")
         c = self.svd_components
-        pipe = StableVideoDiffusionPipeline(c["vae"], c["image_encoder"], c["unet"],
-                                            EulerDiscreteScheduler(**SVD_XT_SCHEDULER_CONFIG), variant=self.variant,
+        if isinstance(c, (str, os.PathLike)):
+            # model/diffusionGS.py:1089 with a local directory; loaded on the first call, the modules stay resident
+            loaded = StableVideoDiffusionPipeline.from_pretrained(c, torch_dtype=torch.float16, variant="fp16",
+                                                                  pipeline=self.variant, device=self.device)
+            c = self.svd_components = dict(vae=loaded.vae, image_encoder=loaded.image_encoder, unet=loaded.unet,
+                                           dtype=torch.float16, scheduler_config=loaded.scheduler_config)
+        # a fresh scheduler per call (the reference builds a fresh pipeline per call), from the checkpoint's own
+        # scheduler/scheduler_config.json when the components came from a directory (SURVEY 8c), else the SVD-XT values
+        sched = (EulerDiscreteScheduler.from_config(c["scheduler_config"]) if c.get("scheduler_config")
+                 else EulerDiscreteScheduler(**SVD_XT_SCHEDULER_CONFIG))
+        pipe = StableVideoDiffusionPipeline(c["vae"], c["image_encoder"], c["unet"], sched, variant=self.variant,
                                             device=self.device)
         assert isinstance(cond_image, list)
         frames = pipe([image_l], temp_cond=cond_image + [image_r], mask=masks, lambda_ts=lambda_ts, num_frames=num_frames,

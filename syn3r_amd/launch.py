@@ -13,7 +13,7 @@ Rank r takes scenes r, r + world, ... (`dist.assign_scenes`); there is no data-p
 comes from a factory `f(name, args, device) -> dict(trainer=GSTrainer, num_input_views=int, test_cameras=[Camera],
 svd_components=dict|None)`: dataset IO (COLMAP / LLFF readers) is outside this repository's scope, so the built-in
 factory is the seeded synthetic scene the tests use (`synthetic:<seed>`), with stand-in SVD modules unless a local
-checkpoint directory is given (`--svd_dir`, loaded by `UNetSpatioTemporalConditionModel.from_pretrained`).
+checkpoint directory is given (`--svd_dir`, loaded by `StableVideoDiffusionPipeline.from_pretrained`: UNet, VAE, scheduler, CLIP).
 A scene that raises is recorded with NaN metrics and ok = 0; the other ranks are unaffected.
 """
 from __future__ import annotations
@@ -39,7 +39,7 @@ def parse(argv: Optional[Sequence[str]] = None) -> argparse.Namespace:
     ap.add_argument("--scene-factory", type=str, default="syn3r_amd.launch:synthetic_scene",
                     help="module:function building one scene (see the module docstring)")
     ap.add_argument("--model_path", type=str, default="output", help="per-scene artefacts go to <model_path>/<scene>")
-    ap.add_argument("--svd_dir", type=str, default=None, help="local SVD checkpoint directory (unet/ sub-directory)")
+    ap.add_argument("--svd_dir", type=str, default=None, help="local SVD checkpoint directory in the diffusers layout (unet/, vae/, scheduler/, image_encoder/, feature_extractor/)")
     ap.add_argument("--backend", type=str, default=None, help="torch.distributed backend (default: nccl = RCCL on a GPU box)")
     # scripts/train.py:50-66
     ap.add_argument("--diffusion_type", type=str, default="2PassProbUncertainPost")
@@ -132,11 +132,10 @@ def run_scene(name: str, args, device, factory: Callable) -> List[float]:
     trainer = sc["trainer"]
     comps = sc.get("svd_components")
     if comps is None and args.refine_cycle_num > 0:
-        comps = _stand_in_svd(device)
-        if args.svd_dir:
-            from .unet.model import UNetSpatioTemporalConditionModel
-            comps = dict(comps, unet=UNetSpatioTemporalConditionModel.from_pretrained(os.path.join(args.svd_dir, "unet"), device),
-                         dtype=torch.float16)
+        # --svd_dir: the whole pipeline from a local diffusers-layout checkpoint (unet/, vae/, scheduler/, image_encoder/,
+        # feature_extractor/), loaded by DiffusionGS.svd_render through StableVideoDiffusionPipeline.from_pretrained
+        # (model/diffusionGS.py:1089); without it the plumbing stand-ins
+        comps = args.svd_dir if args.svd_dir else _stand_in_svd(device)
     trainer.opt.lpips_weight = float(getattr(args, "lpips_weight", 0.0))
     if sc.get("lpips") is not None:
         trainer.lpips = sc["lpips"]

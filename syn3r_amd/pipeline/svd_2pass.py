@@ -95,6 +95,44 @@ class StableVideoDiffusionPipeline:
         import os
         self.use_graphs = os.environ.get("SYN3R_UNET_GRAPH", "0") == "1"     # replay captured UNet launch sequences (hipGraph)
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype: torch.dtype = torch.float16, variant: Optional[str] = "fp16",
+                        *, pipeline: str = "post", device: Union[str, torch.device] = "cuda:0", **_ignored):
+        """The loader call of the reference, `StableVideoDiffusionPipeline.from_pretrained("stabilityai/stable-video-diffusion-
+        img2vid-xt", torch_dtype=torch.float16, variant="fp16")` (model/diffusionGS.py:1089), for a LOCAL diffusers-layout
+        directory (there is no fetch by name here):
+            unet/            config.json + diffusion_pytorch_model[.fp16].safetensors   -> HIP UNetSpatioTemporalConditionModel
+            vae/             config.json + diffusion_pytorch_model[.fp16].safetensors   -> HIP AutoencoderKLTemporalDecoder
+            scheduler/       scheduler_config.json                                      -> EulerDiscreteScheduler.from_config
+            image_encoder/   CLIP vision tower (through `transformers`, SURVEY section 2: out of the HIP scope)
+            feature_extractor/preprocessor_config.json  (CLIP mean / std)
+        `variant` picks `*.{variant}.safetensors` first, as diffusers does; `pipeline` = "post" | "replace" selects which of the
+        reference's two pipeline modules this instance mirrors.  The scheduler's configuration is kept (`scheduler_config`) so
+        callers can build a fresh scheduler per call, as the reference builds a fresh pipeline per `svd_render`."""
+        import json
+        from pathlib import Path
+        from ..schedulers.scheduling_euler_discrete import EulerDiscreteScheduler
+        from ..unet.model import UNetSpatioTemporalConditionModel
+        from ..vae.model import AutoencoderKLTemporalDecoder
+        from .clip import ClipImageEncoder
+        d = Path(pretrained_model_name_or_path)
+        if not d.is_dir():
+            raise FileNotFoundError(f"{d} is not a local checkpoint directory (this build never fetches "
+                                    "'stabilityai/stable-video-diffusion-img2vid-xt' by name: download it and pass the path)")
+        missing = [n for n in ("unet", "vae", "scheduler", "image_encoder") if not (d / n).is_dir()]
+        if missing:
+            raise FileNotFoundError(f"{d}: missing sub-directories {missing} (diffusers layout expected)")
+        if torch_dtype != torch.float16:
+            raise NotImplementedError("the HIP UNet / VAE store fp16 (torch_dtype=torch.float16, as the reference passes)")
+        dev = torch.device(device)
+        unet = UNetSpatioTemporalConditionModel.from_pretrained(str(d / "unet"), dev, variant=variant)
+        vae = AutoencoderKLTemporalDecoder.from_pretrained(str(d / "vae"), dev, variant=variant)
+        sched_cfg = json.loads((d / "scheduler" / "scheduler_config.json").read_text())
+        enc = ClipImageEncoder.from_pretrained(d / "image_encoder", d / "feature_extractor", dev, torch_dtype)
+        pipe = cls(vae, enc, unet, EulerDiscreteScheduler.from_config(sched_cfg), variant=pipeline, device=dev)
+        pipe.scheduler_config = sched_cfg
+        return pipe
+
     @property
     def guidance_scale(self):
         return self._guidance_scale

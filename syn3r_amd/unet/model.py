@@ -252,7 +252,7 @@ class UNetSpatioTemporalConditionModel:
         return self.load_state_dict(sd, dev)
 
     @classmethod
-    def from_pretrained(cls, directory: str, device, **kw):
+    def from_pretrained(cls, directory: str, device, variant: Optional[str] = "fp16", **kw):
         """Load `<directory>/config.json` + `diffusion_pytorch_model[.fp16].safetensors` (local files only;
         the reference fetches by model name at model/diffusionGS.py:1089)."""
         import json
@@ -264,10 +264,11 @@ class UNetSpatioTemporalConditionModel:
                 "addition_time_embed_dim projection_class_embeddings_input_dim layers_per_block cross_attention_dim "
                 "transformer_layers_per_block num_attention_heads num_frames").split()
         model = cls(**{k: cfg[k] for k in keys if k in cfg})
-        for name in ("diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors"):
+        names = ([f"diffusion_pytorch_model.{variant}.safetensors"] if variant else []) + ["diffusion_pytorch_model.safetensors"]
+        for name in names:
             if (d / name).exists():
                 return model.load_state_dict(load_file(str(d / name)), device)
-        raise FileNotFoundError(f"no safetensors weights under {d}")
+        raise FileNotFoundError(f"no safetensors weights under {d} (looked for {names})")
 
     def _pack(self):
         """Kernel-side layouts: OHWI conv weights, fused QKV, (3,1,1) convs as [Cout,3,Cin]."""

@@ -174,7 +174,7 @@ class AutoencoderKLTemporalDecoder:
         return self.load_state_dict(sd, dev)
 
     @classmethod
-    def from_pretrained(cls, path: str, device) -> "AutoencoderKLTemporalDecoder":
+    def from_pretrained(cls, path: str, device, variant: Optional[str] = "fp16") -> "AutoencoderKLTemporalDecoder":
         """`path`: a local diffusers `vae/` directory (config.json + *.safetensors)."""
         from safetensors.torch import load_file
         d = Path(path)
@@ -182,10 +182,11 @@ class AutoencoderKLTemporalDecoder:
         keys = ("in_channels out_channels down_block_types block_out_channels layers_per_block latent_channels "
                 "sample_size scaling_factor force_upcast").split()
         model = cls(**{k: cfg[k] for k in keys if k in cfg})
-        for name in ("diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors"):
+        names = ([f"diffusion_pytorch_model.{variant}.safetensors"] if variant else []) + ["diffusion_pytorch_model.safetensors"]
+        for name in names:
             if (d / name).exists():
                 return model.load_state_dict(load_file(str(d / name)), device)
-        raise FileNotFoundError(f"no safetensors weights under {d}")
+        raise FileNotFoundError(f"no safetensors weights under {d} (looked for {names})")
 
     def _pack(self):
         """Kernel-side layouts: OHWI 3x3 weights (Cin padded to 64, Cout to 8), 1x1 convs as matrices,
