@@ -64,8 +64,8 @@ def test_from_pretrained_runs_a_step(gpu, tmp_path):
     from syn3r_amd.schedulers.scheduling_euler_discrete import EulerDiscreteScheduler
     d = TC.write(tmp_path / "svd")
     pipe = StableVideoDiffusionPipeline.from_pretrained(d, torch_dtype=torch.float16, variant="fp16", pipeline="replace", device=gpu)
-    assert pipe.variant == "replace" and abs(float(pipe.scheduler.sigmas.max()) - 500.0) < 1.0 and pipe.scheduler_config["sigma_max"] == 500.0
-    h, w = 64, 96
+    assert pipe.variant == "replace" and pipe.scheduler_config["sigma_max"] == 500.0
+    h, w = 64, 128          # 8 x 16 latents: the VAE attention kernels want a multiple of 64 tokens
     g = torch.Generator().manual_seed(0)
     imgs = [torch.rand(3, h, w, generator=g) for _ in range(25)]
     mask = (torch.rand(23, h // 8, w // 8, generator=g) > 0.5).float()
@@ -75,6 +75,7 @@ def test_from_pretrained_runs_a_step(gpu, tmp_path):
               aug_noise=torch.randn(1, 3, h, w, generator=g), latents=torch.randn(1, 25, 4, h // 8, w // 8, generator=g))
     a = pipe([imgs[0]], **kw).frames.float()
     assert a.shape == (1, 25, 4, h // 8, w // 8) and bool(torch.isfinite(a).all())
+    assert abs(float(pipe.scheduler.sigmas[0]) - 500.0) < 1e-3          # the call ran on the directory's schedule (set_timesteps(2))
     hand = StableVideoDiffusionPipeline(pipe.vae, pipe.image_encoder, pipe.unet, EulerDiscreteScheduler.from_config(pipe.scheduler_config),
                                         variant="replace", device=gpu)
     assert torch.equal(hand([imgs[0]], **kw).frames.float(), a)
