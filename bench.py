@@ -195,9 +195,10 @@ def cpu_baseline_raster(args):
 
 def cpu_baseline_unet(args):
     """Oracle (oracle/unet_oracle.py, torch fp32 on the host cores, kind='port') on a bounded sample of HOT LOOP B:
-    the FULL SVD-XT UNet configuration (1.52 B seeded weights) on a CFG batch of 2 frames at 24x32 latents; the
-    time is scaled to the benchmark unit by the token ratio (every contraction is linear in B*F*h*w; the
-    attention's quadratic term is under-counted at the small size, so this over-states the CPU's throughput)."""
+    the FULL SVD-XT UNet configuration (1.52 B seeded weights) on a CFG batch of 2 frames at 72x64 latents (1/14 of the
+    unit's tokens, the full latent height); the time is scaled to the benchmark unit by the token ratio (every contraction
+    is linear in B*F*h*w; the spatial attention's quadratic term is under-counted at half the width, so this still
+    over-states the CPU's throughput)."""
     from oracle.unet_oracle import UNetOracle
     from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel      # parameter table only
     shapes = UNetSpatioTemporalConditionModel().parameter_shapes()
@@ -216,7 +217,7 @@ def cpu_baseline_unet(args):
             sd[k] = (pool.repeat((n + pool.numel() - 1) // pool.numel())[:n].view(shape)
                      * min(0.02, math.prod(shape[1:]) ** -0.5))
     orc = UNetOracle(sd, {})
-    B, F, h, w = 2, 2, 24, 32
+    B, F, h, w = 2, 2, 72, 64                      # 18 432 tokens = 1/14 of the benchmark unit's [2,14,8,72,128]
     x = torch.randn(B, F, 8, h, w, generator=g)
     ehs = torch.randn(B, 1, 1024, generator=g)
     added = torch.tensor([[6.0, 127.0, 0.02]] * B)
@@ -249,10 +250,13 @@ def cpu_baseline_geometry_scheduler(dev):
     rgb = np.random.default_rng(0).random((3, H, W), dtype=np.float32)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
-    def host_s(fn):
-        t0 = time.perf_counter()
-        fn()
-        return time.perf_counter() - t0
+    def host_s(fn):                       # median of three runs
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[1]
 
     def dev_us(fn, n=5):
         fn()
@@ -294,7 +298,7 @@ def cpu_baseline_geometry_scheduler(dev):
                                                                       c["lambda_ts"][i], sig, i)), 3),
         gpu_device_us=round(dev_us(lambda: sch.step_interp_prob_uncertain(g["model_output"], ts, g["sample"], g["temp_cond"], g["mask"], lam,
                                                                           step_i=i)), 1))
-    out["note"] = ("cpu_port_s: oracle/warp_oracle.py / oracle/scheduler_oracle.py (numpy, one run each, host cores as numpy uses them); "
+    out["note"] = ("cpu_port_s: oracle/warp_oracle.py / oracle/scheduler_oracle.py (numpy, median of 3 runs, host cores as numpy uses them); "
                    "gpu_device_us: sum of kernel time of the HIP path on the same inputs.  Reference-run timings of the same functions "
                    "in the build container (8 cores): BASELINE.md section 3")
     return out
@@ -579,8 +583,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 of the single-GPU run only
             log("cpu baseline (oracle on the host cores, bounded sample) ...")
             out["cpu_baseline"] = cpu_baseline(args, loop_b is not None)
-            out["cpu_baseline"]["sample_note"] = ("thin samples: ONE oracle run per leg (raster at 1/4 of the pixels, UNet at 1/84 of the "
-                                                  "tokens), extrapolated linearly; kind 'port' because reference Python does not travel to the GPU box")
+            out["cpu_baseline"]["sample_note"] = ("bounded samples: one oracle run of the raster leg (1/4 of the pixels) and of the UNet leg (1/14 of "
+                                                  "the tokens), extrapolated linearly; geometry / scheduler legs: median of 3; kind 'port' because "
+                                                  "reference Python does not travel to the GPU box")
             out["cpu_baseline"]["geometry_and_scheduler"] = cpu_baseline_geometry_scheduler(dev)
         print(json.dumps(out))
     if dist is not None:

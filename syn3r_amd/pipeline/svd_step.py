@@ -139,8 +139,11 @@ class SvdStepBench:
         ach = flops / (ms / 1e3) / 1e12
         traffic, source = _pmc_traffic(best)
         busy, _ = _pmc_traffic(best, field="mfma_busy")
+        ratio, _ = _pmc_traffic(best, field="traffic_ratio")       # counted HBM bytes / algorithmic bytes: family and worst kernel
+        alg_b, _ = _pmc_traffic(best, field="algorithmic_bytes_per_launch")
         return dict(bound="mfma", kernel=best, achieved=round(ach, 1), peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / MFMA_F16_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=source, mfma_busy=busy,
+                    traffic_ratio=ratio, algorithmic_bytes_per_launch=alg_b,
                     avg_ms=round(ms / calls, 4), calls=calls, algorithmic_flops_per_unit=self.flops_per_unit)
 
 

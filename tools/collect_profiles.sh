@@ -29,13 +29,13 @@ if [ -n "$SQ_FILES" ]; then
   echo "[profiles] SQ passes summarised"
 fi
 cp "$OUT/stats/bench_kernel_stats.csv" "$OUT/bench_kernel_stats.csv"
+( timeout -k 10 200 python3 "$R/tools/unet_breakdown.py" 14 detail 2>/dev/null | grep -v amdgpu.ids > "$OUT/unet_shapes.txt" ) || true
 if [ -f "$OUT/fetch/p_counter_collection.csv" ] && [ -f "$OUT/write/p_counter_collection.csv" ]; then
-  python3 "$R/tools/traffic_json.py" "$OUT/fetch/p_counter_collection.csv" "$OUT/write/p_counter_collection.csv" "$OUT/traffic.json" $( [ -f "$OUT/pmc_counters_by_kernel.json" ] && echo "$OUT/pmc_counters_by_kernel.json" ) > /dev/null
+  python3 "$R/tools/traffic_json.py" "$OUT/fetch/p_counter_collection.csv" "$OUT/write/p_counter_collection.csv" "$OUT/traffic.json" $( [ -f "$OUT/pmc_counters_by_kernel.json" ] && echo "$OUT/pmc_counters_by_kernel.json" ) $( [ -s "$OUT/unet_shapes.txt" ] && echo "$OUT/unet_shapes.txt" ) > /dev/null
   python3 "$R/tools/pmc_by_kernel.py" "$OUT/fetch/p_counter_collection.csv" FETCH_SIZE > "$OUT/bench_FETCH_SIZE_by_kernel.csv"
   python3 "$R/tools/pmc_by_kernel.py" "$OUT/write/p_counter_collection.csv" WRITE_SIZE > "$OUT/bench_WRITE_SIZE_by_kernel.csv"
 fi
 # per-shape / per-kernel breakdowns of the same build (developer tools; failures here do not fail the collection)
-( timeout -k 10 200 python3 "$R/tools/unet_breakdown.py" 14 detail 2>/dev/null | grep -v amdgpu.ids > "$OUT/unet_shapes.txt" ) || true
 ( timeout -k 10 100 python3 "$R/tools/raster_breakdown.py" 2>/dev/null | grep -v amdgpu.ids > "$OUT/raster_breakdown.txt" ) || true
 ( timeout -k 10 200 python3 "$R/tools/merge_units.py" 25 2>/dev/null | grep -v amdgpu.ids > "$OUT/merge_units.txt" ) || true
 ( timeout -k 10 100 python3 "$R/tools/norm_bench.py" 2>/dev/null | grep -v amdgpu.ids > "$OUT/norm_bench.txt" ) || true
