@@ -59,7 +59,9 @@ def remove_statistical_outlier(points: np.ndarray, nb_neighbors: int = 20, std_r
     """-> (inlier indices, avg distances, (mean, std, threshold))."""
     avg = knn_mean_distance(points, nb_neighbors) if avg is None else np.asarray(avg, dtype=np.float64)
     valid = avg > 0
-    nv = int(valid.sum())
+    # open3d divides by `valid_distances`: every point whose neighbour query returned anything (all of them: a query returns
+    # at least the point itself), while the sums skip the non-positive averages (PointCloud::RemoveStatisticalOutliers)
+    nv = int(avg.shape[0])
     mean = float(np.sum(avg[valid]) / nv)
     sq = float(np.sum((avg[valid] - mean) ** 2))
     std = float(np.sqrt(sq / (nv - 1)))

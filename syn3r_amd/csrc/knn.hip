@@ -311,8 +311,11 @@ __global__ void __launch_bounds__(kThreads) k_knn_mean64(const double4* __restri
     }
 }
 
-// ONE block: mean and (n-1) standard deviation of the positive entries, threshold = mean + ratio * std.  Thread-strided
-// partial sums + a fixed tree: the result does not depend on scheduling.  stats = {mean, std, threshold, valid count}
+// ONE block: mean and standard deviation as open3d's PointCloud::RemoveStatisticalOutliers takes them, threshold = mean +
+// ratio * std.  The SUMS run over the positive entries only, the DIVISORS are `valid_distances` = the number of points whose
+// neighbour query returned anything - every point here (a query returns at least the point itself) - and that count - 1:
+// a cluster of more than nb_neighbors coincident points (average distance 0) lowers the mean instead of dropping out of it.
+// Thread-strided partial sums + a fixed tree: the result does not depend on scheduling.  stats = {mean, std, threshold, n}
 __global__ void __launch_bounds__(1024) k_outlier_stats(const double* __restrict__ avg, int n, double ratio, double* __restrict__ stats) {
     __shared__ double red[1024];
     __shared__ double mean_s;
@@ -332,7 +335,9 @@ __global__ void __launch_bounds__(1024) k_outlier_stats(const double* __restrict
         __syncthreads();
         return r;
     };
-    const double total = reduce(s), valid = reduce(c);
+    const double total = reduce(s);
+    (void)c;
+    const double valid = (double)n;
     if (threadIdx.x == 0) mean_s = total / valid;
     __syncthreads();
     const double mean = mean_s;

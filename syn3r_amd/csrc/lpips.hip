@@ -180,8 +180,11 @@ __global__ void __launch_bounds__(256) k_lpips_layer_bwd(const __half* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float g = ev[e] * ra - k2 * (float)av[e];
-        // `a` is a post-ReLU activation: the total gradient passes its ReLU here (zero where the activation is zero)
-        o[e] = (float)av[e] > 0.0f ? (_Float16)((accumulate ? (float)o[e] : 0.0f) + g) : (_Float16)0.0f;
+        // `a` is a post-ReLU activation: the total gradient passes its ReLU here (zero where the activation is zero).
+        // The gradient carries the loss scale (1024 H W / P_k) and a factor 1 / |a|: a pixel whose feature norm is tiny would
+        // overflow fp16 to inf and the backward convolutions would spread inf / NaN into the image gradient - saturate.
+        const float t = fminf(fmaxf((accumulate ? (float)o[e] : 0.0f) + g, -65504.0f), 65504.0f);
+        o[e] = (float)av[e] > 0.0f ? (_Float16)t : (_Float16)0.0f;
     }
     *(half8*)(ga + p * C + sub * 8) = o;
 }

@@ -38,6 +38,24 @@ def test_statistical_outlier_vs_oracle(gpu, n, seed):
     assert 0 < len(ind) < n or n < 50
 
 
+def test_statistical_outlier_with_coincident_points(gpu):
+    """More than nb_neighbors coincident points have average neighbour distance 0: open3d leaves them out of the SUMS but keeps
+    them in the divisors (`valid_distances` counts every point whose query returned neighbours), and drops them from the
+    inliers (0 < avg is required).  Kernel and oracle follow that rule: the statistics divide by n, not by the positive count."""
+    from syn3r_amd import pcd as P
+    pts = _cloud(4000, 5, strays=20)
+    pts[100:130] = pts[100]                                    # 30 copies of one point
+    keep, avg, stats = P.statistical_outlier(torch.from_numpy(pts).to(gpu), 20, 3.0)
+    ind, oavg, (mean, std, thr) = PO.remove_statistical_outlier(pts, 20, 3.0)
+    a = avg.cpu().numpy()
+    assert (a[100:130] == 0).all() and (oavg[100:130] == 0).all()
+    pos = oavg > 0
+    assert abs(mean - oavg[pos].sum() / 4000) < 1e-12 and mean < oavg[pos].mean()        # divisor n, not the positive count
+    np.testing.assert_allclose(stats.cpu().numpy(), [mean, std, thr, 4000.0], rtol=1e-12)
+    np.testing.assert_array_equal(np.nonzero(keep.cpu().numpy())[0], ind)
+    assert not set(range(100, 130)) & set(ind.tolist())
+
+
 def test_filter_dense_cloud_vs_oracle_and_ply(gpu, tmp_path):
     """model/diffusionGS.py:314-336 at the reference's size: 230 000 dust3r-like points -> stride 2 -> outlier removal;
     the written .ply holds the inliers."""
