@@ -1541,11 +1541,12 @@ int launch_widep(const GemmParams& p, hipStream_t stream) {
     return SYN3R_OK;
 }
 
+template <int MODE = MODE_DENSE>
 int launch_z(const GemmParams& p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_z<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Z_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_z<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Z_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_z<false, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, Z_LDS);
+        if (e == hipSuccess && MODE == MODE_DENSE) e = hipFuncSetAttribute((const void*)k_gemm_z<true, MODE_DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, Z_LDS);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_z)");
         attr_set = true;
     }
@@ -1553,11 +1554,13 @@ int launch_z(const GemmParams& p, hipStream_t stream) {
     const int blocks = std::min(tiles, persistent_blocks());
     char name[96];
     if (trace_on()) {
-        if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_z[M%d,N%d,K%d,e%d]", p.M, p.N, p.K, p.geglu_D > 0 ? 2 : (p.residual != nullptr));
-        else snprintf(name, sizeof(name), "k_gemm_z");
+        if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_z<%d>[M%d,N%d,K%d,e%d]", MODE, p.M, p.N, p.K, p.geglu_D > 0 ? 2 : (p.residual != nullptr));
+        else snprintf(name, sizeof(name), "k_gemm_z<%d>", MODE);
     }
-    if (p.A2) SYN3R_LAUNCH_NAMED(name, k_gemm_z<true>, dim3(blocks), dim3(512), Z_LDS, stream, p);
-    else SYN3R_LAUNCH_NAMED(name, k_gemm_z<false>, dim3(blocks), dim3(512), Z_LDS, stream, p);
+    if constexpr (MODE == MODE_DENSE) {
+        if (p.A2) { SYN3R_LAUNCH_NAMED(name, (k_gemm_z<true, MODE_DENSE>), dim3(blocks), dim3(512), Z_LDS, stream, p); SYN3R_LAUNCH_CHECK("gemm_z launch"); return SYN3R_OK; }
+    }
+    SYN3R_LAUNCH_NAMED(name, (k_gemm_z<false, MODE>), dim3(blocks), dim3(512), Z_LDS, stream, p);
     SYN3R_LAUNCH_CHECK("gemm_z launch");
     return SYN3R_OK;
 }
@@ -1570,7 +1573,7 @@ int wide_launch(const GemmParams& p, hipStream_t stream) {
     static int z_env = -2;
     if (z_env == -2) { const char* e = getenv("SYN3R_GEMM_Z"); z_env = e ? atoi(e) : -1; }
     const bool z = z_env < 0 ? p.geglu_D > 0 : z_env != 0;
-    return z ? launch_z(p, stream) : launch_widep(p, stream);
+    return z ? launch_z<MODE_DENSE>(p, stream) : launch_widep(p, stream);
 }
 
 // Does the persistent 256 x 320 kernel take this contraction?  Lean epilogue (no row vector together with a gate, aux only
@@ -1671,6 +1674,27 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
             if constexpr (MODE == MODE_DENSE) { if (w128_env == 1 || (w128_env != 0 && p.K <= 320 && p.N > 640)) return launch_w128(p, stream); }
             return wide_launch(p, stream);
         }
+    }
+    // Convolutions on the 256 x 320 tile (round 4, k_gemm_z<MODE>): lean epilogue (no ReLU options, aux only with a residual),
+    // whole 16-byte column chunks, 32-bit byte offsets into the input, and a grid that fills the chip as the dense rule
+    // above asks (M = 4 032 at level 3 gives 64 tiles: those stay on the 160-column tile, 128 blocks).  Measured inside the
+    // UNet unit, same box (tools/gemm_ab.py SYN3R_CONV_Z 0 1, profiles/r04/conv_z_ab.txt): 3x3 convolutions without a
+    // residual -5..-7 %, with one -1..-3 % at N >= 640 and +3 % at N = 320 (the 160-column kernel's epilogue requests the
+    // residual before it stages the accumulators), the temporal convolutions +-2 % without and +12 % with a residual, the
+    // 8-column output convolution +77 % (one 320-wide tile column for 8 columns): by default only the 3x3 convolutions with
+    // N >= 320 and (no residual or N >= 640).  SYN3R_CONV_Z=0: never; 1: every admissible shape (tests, tuning).
+    if constexpr (MODE != MODE_DENSE) {
+        static int cz_env = -2;
+        if (cz_env == -2) { const char* e = getenv("SYN3R_CONV_Z"); cz_env = e ? atoi(e) : -1; }
+        const long long tiles = (long long)((p.M + WBM - 1) / WBM) * ((p.N + WBN - 1) / WBN);
+        const long long rounds = (tiles + 255) / 256;
+        const bool fills = tiles * 10 >= rounds * 256 * 8;
+        const long long in_bytes = MODE == MODE_CONV2D ? (long long)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2 : (long long)p.M * p.Cin * 2;
+        const bool lean = !p.relu && !p.relu_mask && (!p.aux || p.residual) && p.geglu_D <= 0 && !p.A2 && !p.a_tiled;
+        const bool ok = lean && p.M % 8 == 0 && p.N % 8 == 0 && p.M >= 8 && p.N >= 8 && in_bytes < (1ll << 32) - (1 << 20) &&
+                        (long long)p.N * p.K < (1ll << 31) && p.Cin % BK == 0;
+        const bool pays = MODE == MODE_CONV2D && p.N >= 320 && (!p.residual || p.N >= 640);
+        if (g_dma_bm == 0 && cz_env != 0 && ok && (cz_env == 1 || (fills && pays))) return launch_z<MODE>(p, stream);
     }
     // 256-row blocks (eight wavefronts, wavefronts 4-7 staggered by half a k-tile against their SIMD partners) against
     // two independent 128-row blocks per CU, measured inside the UNet unit on MI355X (tools/unet_breakdown.py with

@@ -33,27 +33,27 @@ constexpr int Z_LDS = Z_SLOT1 + W_STAGE;          // 163,840
 
 // Pieces of the main loop as function templates (inline asm in a generic lambda does not capture its operands with this
 // compiler): fragment reads, the MFMA group, the counted wait.  Everything is forced inline; the arrays are the kernel's.
-template <int KH>
-__device__ __forceinline__ void z_read_a(half8 (&af)[2][TM], const unsigned (&ra)[2]) {
-    Z_DS_READ128(af[KH][0], ra[KH], 0); Z_DS_READ128(af[KH][1], ra[KH], 2048);
-    Z_DS_READ128(af[KH][2], ra[KH], 4096); Z_DS_READ128(af[KH][3], ra[KH], 6144);
+template <int KH, int NAF>    // NAF = 2: one register set per k-half (the next half's reads overlap this half's MFMAs); 1: one set
+__device__ __forceinline__ void z_read_a(half8 (&af)[NAF][TM], const unsigned (&ra)[2]) {
+    Z_DS_READ128(af[KH % NAF][0], ra[KH], 0); Z_DS_READ128(af[KH % NAF][1], ra[KH], 2048);
+    Z_DS_READ128(af[KH % NAF][2], ra[KH], 4096); Z_DS_READ128(af[KH % NAF][3], ra[KH], 6144);
 }
 template <int Q, int RB>      // weight fragment of group Q (0..19) of the k-tile the read cursor is in
 __device__ __forceinline__ void z_read_b(half8 (&bf)[RB], const unsigned (&rb)[2]) {
     Z_DS_READ128(bf[Q % RB], rb[Q / 10], (Q % 10) * 2048);
 }
-template <int Q, int RB>
-__device__ __forceinline__ void z_mma(float4v (&acc)[2][TM][TN], half8 (&af)[2][TM], half8 (&bf)[RB]) {
-    constexpr int kh = Q / 10, j = Q % 10;
+template <int Q, int RB, int NAF>
+__device__ __forceinline__ void z_mma(float4v (&acc)[2][TM][TN], half8 (&af)[NAF][TM], half8 (&bf)[RB]) {
+    constexpr int kh = (Q / 10) % NAF, j = Q % 10;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
         acc[j / TN][i][j % TN] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[Q % RB], af[kh][i], acc[j / TN][i][j % TN], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 }
 // wait until at most N LDS reads are outstanding; the group's fragment registers are then valid (ties its MFMAs behind the wait)
-template <int Q, int RB, int N>
-__device__ __forceinline__ void z_wait(half8 (&af)[2][TM], half8 (&bf)[RB]) {
-    constexpr int kh = Q / 10, j = Q % 10;
+template <int Q, int RB, int N, int NAF>
+__device__ __forceinline__ void z_wait(half8 (&af)[NAF][TM], half8 (&bf)[RB]) {
+    constexpr int kh = (Q / 10) % NAF, j = Q % 10;
     if constexpr (j == 0)
         asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(bf[Q % RB]), "+v"(af[kh][0]), "+v"(af[kh][1]), "+v"(af[kh][2]), "+v"(af[kh][3]) : "i"(N));
     else
@@ -61,7 +61,12 @@ __device__ __forceinline__ void z_wait(half8 (&af)[2][TM], half8 (&bf)[RB]) {
 }
 
 // TWOSRC: the A columns from K1 on come from a second tensor (GemmParams::A2; the up blocks' shortcut projections)
-template <bool TWOSRC>
+// MODE (round 4): MODE_CONV2D / MODE_TCONV run the implicit-GEMM convolutions on this tile too (they lived on the 256 x 160 tile,
+// whose k-loop is LDS-bound: 52 DMA pieces + 144 fragment reads per 1 280 MFMA cycles against 72 + 224 per 2 560 here,
+// tools/ubench/lds_dma_rate.hip).  The A pieces then take a PER-LANE source: the im2col gather of resnet.py:274,290 /
+// downsampling.py:116-148 / upsampling.py:172-183 / the frame shift of resnet.py:571-597, one 32-bit byte offset per piece
+// (or the zero page for padding), re-derived when the filter tap changes and advanced by 128 bytes per k-tile inside a tap.
+template <bool TWOSRC, int MODE>
 __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -105,6 +110,52 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
         voff_b = (unsigned)(prow * p.K + csrc * 8) * 2u;
     }
     bool second = false;                                       // the stage being requested reads the second source
+    // convolution modes: per lane and A piece, where the lane's output pixel sits and the byte offset (from p.A) of the 16-byte
+    // chunk it fetches for the current k-tile; kPad = the chunk is padding (source: the zero page)
+    constexpr unsigned kPad = 0xffffffffu;
+    constexpr int NCV = MODE == MODE_DENSE ? 1 : 4;
+    unsigned cv_off[NCV];
+    int c_tap = 0, c_left = 0;                                 // next filter tap, k-tiles left in the current one (wave-uniform)
+    const int cpb = MODE == MODE_DENSE ? 1 : p.Cin / BK;       // k-tiles per filter tap
+    // m / d for m < 2^24 (launch_dma checks M) by one float multiply and a correction step: the pixel coordinates are rebuilt
+    // at every tap change (4 pieces x 2 divisions per lane, every Cin / 64 k-tiles) instead of living in eight registers
+    auto udiv = [](unsigned m, unsigned d, float rcp, unsigned& rem) -> unsigned {
+        unsigned q = (unsigned)((float)m * rcp);
+        int r = (int)(m - q * d);
+        if (r < 0) { --q; r += (int)d; }
+        if (r >= (int)d) { ++q; r -= (int)d; }
+        rem = (unsigned)r;
+        return q;
+    };
+    const unsigned d_hw = MODE == MODE_CONV2D ? (unsigned)(p.Ho * p.Wo) : (unsigned)(MODE == MODE_TCONV ? p.HW : 1);
+    const unsigned d_w = MODE == MODE_CONV2D ? (unsigned)p.Wo : (unsigned)(MODE == MODE_TCONV ? p.F : 1);
+    const float r_hw = 1.0f / (float)d_hw, r_w = 1.0f / (float)d_w;
+    auto conv_tap = [&](int tap) {                             // the chunk offsets of filter tap `tap` for the tile at c_m0
+        int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(l));
+        const unsigned chunk = (unsigned)(((l & 7) ^ (l >> 3)) * 16);
+#pragma unroll
+        for (int i = 0; i < NCV; ++i) {
+            unsigned m = (unsigned)(c_m0 + wv * 32 + i * 8 + (l >> 3));
+            m = m < (unsigned)p.M ? m : (unsigned)p.M - 1u;
+            if constexpr (MODE == MODE_CONV2D) {
+                unsigned r, x;
+                const unsigned n = udiv(m, d_hw, r_hw, r), y = udiv(r, d_w, r_w, x);
+                const int dy = tap / 3 - p.pad, dx = tap % 3 - p.pad;
+                const int Hg = p.ups ? p.Hi * 2 : p.Hi, Wg = p.ups ? p.Wi * 2 : p.Wi;
+                int yy = (int)y * p.stride + dy, xx = (int)x * p.stride + dx;
+                const bool ok = yy >= 0 && yy < Hg && xx >= 0 && xx < Wg;
+                if (p.ups) { yy >>= 1; xx >>= 1; }
+                cv_off[i] = ok ? ((n * (unsigned)p.Hi + (unsigned)yy) * (unsigned)p.Wi + (unsigned)xx) * (unsigned)p.Cin * 2u + chunk : kPad;
+            } else if constexpr (MODE == MODE_TCONV) {
+                unsigned r, f;
+                const unsigned bf_ = udiv(m, d_hw, r_hw, r);           // m = (b F + f) HW + pixel
+                (void)udiv(bf_, d_w, r_w, f);
+                const int ff = (int)f + tap - 1;
+                cv_off[i] = (ff >= 0 && ff < p.F) ? (unsigned)((int)m + (tap - 1) * p.HW) * (unsigned)p.Cin * 2u + chunk : kPad;
+            }
+        }
+    };
     auto cursor_begin = [&]() {
         if (c_tl >= t_len) return;                             // exhausted: the previous stage's offsets again
         if (c_ks == 0) {
@@ -112,6 +163,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
             tile_origin(t_start + c_tl, c_m0, n0_, tn_);
             abase = (const char*)p.A;
             second = false;
+            if constexpr (MODE != MODE_DENSE) { c_tap = 0; c_left = 0; }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int r = c_m0 + wv * 32 + i * 8;
@@ -142,6 +194,14 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) ob[j] += 2u * BK;
         }
+        if constexpr (MODE != MODE_DENSE) {
+            if (c_left == 0) { conv_tap(c_tap); ++c_tap; c_left = cpb; }
+            else {
+#pragma unroll
+                for (int i = 0; i < NCV; ++i) cv_off[i] = cv_off[i] == kPad ? kPad : cv_off[i] + 2u * BK;
+            }
+            --c_left;
+        }
         if (++c_ks == nkt) { c_ks = 0; c_tl += t_stride; }
     };
     auto cursor_end = [&]() { c_slot = c_slot ? 0u : (unsigned)Z_SLOT1; };
@@ -170,7 +230,11 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
         }
         return;
 #endif
-        if constexpr (idx < 4) {
+        if constexpr (idx < 4 && MODE != MODE_DENSE) {
+            const unsigned o = cv_off[idx < NCV ? idx : 0];
+            const char* src = o == kPad ? (const char*)g_zero_page : (const char*)p.A + (size_t)o;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wv * 4 + idx) * 1024), 16, 0, 0);
+        } else if constexpr (idx < 4) {
             const unsigned va = (TWOSRC && second) ? voff_a2 : voff_a;
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase + (size_t)(oa[idx] + va)), (lds_void_t*)(st + (wv * 4 + idx) * 1024), 16, 0, 0);
         } else {
@@ -203,9 +267,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
 #define Z_LA 3
 #endif
     constexpr int LA = Z_LA, RB = LA + 1;             // B-fragment ring; 20 % RB == 0 keeps the ring index a function of the group
-    static_assert(20 % RB == 0 && LA >= 3 && LA <= 9, "ring of 4, 5 or 10 weight fragments");
+    static_assert(20 % RB == 0 && LA >= 3 && LA <= 4, "ring of 4 or 5 weight fragments");
     float4v acc[2][TM][TN];               // [column half][row tile][column tile]: halves are 80 columns each
-    half8 af[2][TM], bf[RB];              // A fragments of the two k-halves; ring of weight fragments
+    // A fragments: one register set per k-half (the next half's four reads overlap this half's MFMAs), or - convolution modes, whose
+    // per-lane gather state needs the registers - ONE set (the next half's reads issue behind the last MFMA group of this one)
+    constexpr int NAF = MODE == MODE_DENSE ? 2 : 1;
+    half8 af[NAF][TM], bf[RB];            // A fragments; ring of weight fragments
 
     // ---- kernel prologue: stage 0 of the first tile, complete and visible before the first read
     cursor_begin();
@@ -225,23 +292,28 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
         if constexpr (q < 9) piece(std::integral_constant<int, order[q < 9 ? q : 0]>{});
         if constexpr (q == 8) cursor_end();
     };
-#define Z_YOUNGER(q) ((19 - (q) < LA ? 19 - (q) : LA) + (((q) >= 7 && (q) < 7 + LA && (q) != 10) ? 4 : 0))
-// (group 10 also needs the A reads of group 7: allowed = the weight reads issued behind them, B(7 + LA) .. B(min(10 + LA, 19)))
-#define Z_NWAIT(q) ((q) == 10 ? (LA < 4 ? LA : ((10 + LA < 19 ? 10 + LA : 19) - (7 + LA) + 1)) : Z_YOUNGER(q))
+#define Z_YOUNGER(q) ((19 - (q) < LA ? 19 - (q) : LA) + ((NAF == 2 && (q) >= 7 && (q) < 7 + LA && (q) != 10) ? 4 : 0))
+// (group 10 also needs the A reads of k-half 1: with two register sets they were issued at group 7 and the allowed count is the
+// weight reads issued behind them; with ONE set they follow group 9's MFMAs: only group 10's own weight read is behind them.
+// Group 0, one set: the A reads follow group 19's MFMAs, with two weight reads behind them.)
+#define Z_NWAIT(q) (NAF == 1 ? ((q) == 10 ? 1 : ((q) == 0 ? 2 : Z_YOUNGER(q))) \
+                             : ((q) == 10 ? (LA < 4 ? LA : ((10 + LA < 19 ? 10 + LA : 19) - (7 + LA) + 1)) : Z_YOUNGER(q)))
 #ifdef Z_PIECE_AFTER        // the group's DMA piece behind its MFMAs instead of in front of its reads
 #define Z_GROUP(q) do { \
-        if constexpr ((q) == 7) z_read_a<1>(af, ra); \
+        if constexpr (NAF == 2 && (q) == 7) z_read_a<1, NAF>(af, ra); \
         if constexpr ((q) + LA <= 19) z_read_b<((q) + LA <= 19 ? (q) + LA : 0), RB>(bf, rb); \
-        z_wait<(q), RB, Z_NWAIT(q)>(af, bf); \
-        z_mma<(q), RB>(acc, af, bf); \
+        z_wait<(q), RB, Z_NWAIT(q), NAF>(af, bf); \
+        z_mma<(q), RB, NAF>(acc, af, bf); \
+        if constexpr (NAF == 1 && (q) == 9) z_read_a<1, NAF>(af, ra); \
         group_piece(ZQ(q)); } while (0)
 #else
 #define Z_GROUP(q) do { \
         group_piece(ZQ(q)); \
-        if constexpr ((q) == 7) z_read_a<1>(af, ra); \
+        if constexpr (NAF == 2 && (q) == 7) z_read_a<1, NAF>(af, ra); \
         if constexpr ((q) + LA <= 19) z_read_b<((q) + LA <= 19 ? (q) + LA : 0), RB>(bf, rb); \
-        z_wait<(q), RB, Z_NWAIT(q)>(af, bf); \
-        z_mma<(q), RB>(acc, af, bf); } while (0)
+        z_wait<(q), RB, Z_NWAIT(q), NAF>(af, bf); \
+        z_mma<(q), RB, NAF>(acc, af, bf); \
+        if constexpr (NAF == 1 && (q) == 9) z_read_a<1, NAF>(af, ra); } while (0)
 #endif
 #define ZQ(q) std::integral_constant<int, q>{}
 
@@ -262,14 +334,20 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
                 for (int j = 0; j < TN; ++j) acc[hh][i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
         // (the fragment registers are outputs of asm reads: redefined per tile, or they all stay live through the epilogue)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) { asm volatile("" : "=v"(af[0][i])); asm volatile("" : "=v"(af[1][i])); }
+        for (int i = 0; i < TM; ++i) { asm volatile("" : "=v"(af[0][i])); asm volatile("" : "=v"(af[NAF - 1][i])); }
 #pragma unroll
         for (int j = 0; j < RB; ++j) asm volatile("" : "=v"(bf[j]));
-        // read prologue of the tile: the first k-half's A fragments and the first LA weight fragments (landed and visible)
-        z_read_a<0>(af, ra);
-        z_read_b<0, RB>(bf, rb); z_read_b<1, RB>(bf, rb); z_read_b<2, RB>(bf, rb);
-        if constexpr (LA >= 4) z_read_b<3, RB>(bf, rb);
-        if constexpr (LA >= 9) { z_read_b<4, RB>(bf, rb); z_read_b<5, RB>(bf, rb); z_read_b<6, RB>(bf, rb); z_read_b<7, RB>(bf, rb); z_read_b<8, RB>(bf, rb); }
+        // read prologue of the tile: the first k-half's A fragments and the first LA weight fragments (landed and visible);
+        // with one A set in the order the steady stream leaves them in (two weight reads, the A reads, one weight read)
+        if constexpr (NAF == 1) {
+            z_read_b<0, RB>(bf, rb); z_read_b<1, RB>(bf, rb);
+            z_read_a<0, NAF>(af, ra);
+            z_read_b<2, RB>(bf, rb);
+        } else {
+            z_read_a<0, NAF>(af, ra);
+            z_read_b<0, RB>(bf, rb); z_read_b<1, RB>(bf, rb); z_read_b<2, RB>(bf, rb);
+            if constexpr (LA >= 4) z_read_b<3, RB>(bf, rb);
+        }
         for (int kt = 0; kt < nkt; ++kt) {
             // groups 0-8 carry the nine DMA pieces of the NEXT stage (into the slot the previous barrier released)
             ZSTAMP(5);
@@ -283,7 +361,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
             // group 17: the read stream leaves this k-tile.  Everything this wavefront read from the slot has arrived
             // (lgkmcnt(0): the slot may be refilled), its pieces of the next stage have landed (vmcnt(0)); barrier.
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[17 % RB]), "+v"(bf[18 % RB]), "+v"(bf[19 % RB]));
-            z_mma<17, RB>(acc, af, bf);
+            z_mma<17, RB, NAF>(acc, af, bf);
             ZSTAMP(2);
 #ifndef Z_EXP_NOVMWAIT      // timing experiment (wrong results): what the wait for the next stage's DMA costs
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -298,19 +376,25 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
             // the first reads of the next k-tile, while groups 18 and 19 still multiply from registers (not behind a tile's
             // last k-tile: the epilogue wants the registers; the next tile starts with the read prologue above)
             if (kt + 1 < nkt) {
-                z_read_a<0>(af, ra);
-                z_read_b<0, RB>(bf, rb);
-                if constexpr (LA >= 9) { z_read_b<1, RB>(bf, rb); z_read_b<2, RB>(bf, rb); }
-                z_mma<18, RB>(acc, af, bf);
-                if constexpr (LA >= 9) { z_read_b<3, RB>(bf, rb); z_read_b<4, RB>(bf, rb); z_read_b<5, RB>(bf, rb); }
-                else z_read_b<1, RB>(bf, rb);
-                z_mma<19, RB>(acc, af, bf);
-                if constexpr (LA >= 9) { z_read_b<6, RB>(bf, rb); z_read_b<7, RB>(bf, rb); z_read_b<8, RB>(bf, rb); }
-                else z_read_b<2, RB>(bf, rb);
-                if constexpr (LA == 4) z_read_b<3, RB>(bf, rb);
+                if constexpr (NAF == 1) {
+                    z_read_b<0, RB>(bf, rb);
+                    z_mma<18, RB, NAF>(acc, af, bf);
+                    z_read_b<1, RB>(bf, rb);
+                    z_mma<19, RB, NAF>(acc, af, bf);
+                    z_read_a<0, NAF>(af, ra);
+                    z_read_b<2, RB>(bf, rb);
+                } else {
+                    z_read_a<0, NAF>(af, ra);
+                    z_read_b<0, RB>(bf, rb);
+                    z_mma<18, RB, NAF>(acc, af, bf);
+                    z_read_b<1, RB>(bf, rb);
+                    z_mma<19, RB, NAF>(acc, af, bf);
+                    z_read_b<2, RB>(bf, rb);
+                    if constexpr (LA == 4) z_read_b<3, RB>(bf, rb);
+                }
             } else {
-                z_mma<18, RB>(acc, af, bf);
-                z_mma<19, RB>(acc, af, bf);
+                z_mma<18, RB, NAF>(acc, af, bf);
+                z_mma<19, RB, NAF>(acc, af, bf);
             }
         }
         ZSTAMP(5);
