@@ -307,7 +307,8 @@ int syn3r_gemm_2src_f16(const void* A1, long long lda1, int K1, const void* A2, 
 /* Test / tuning hook, PER CALLING THREAD (thread-local: the library holds no state shared between host threads): the
  * contraction kernel family this thread's next launches use.  0 = chosen per shape (default); -128 / -256 = the 160-column
  * LDS-DMA kernel of that block height; -320 = the persistent 256 x 320 kernel wherever it admits the shape; -321 = the
- * 128 x 320 two-blocks-per-CU kernel (dense contractions; the convolutions keep the default). */
+ * 128 x 320 two-blocks-per-CU kernel (dense contractions; the convolutions keep the default); -322 = the software-pipelined
+ * persistent 256 x 320 kernel (round 4: dense, two-source and implicit-GEMM convolution modes) wherever it admits the shape. */
 int syn3r_gemm_set_tile(int bm);
 
 /*

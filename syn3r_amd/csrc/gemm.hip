@@ -1565,6 +1565,9 @@ int launch_z(const GemmParams& p, hipStream_t stream) {
     return SYN3R_OK;
 }
 
+// Kernel family forced by the CALLING THREAD (syn3r_gemm_set_tile, see launch_dma); thread_local: no state shared between host threads
+thread_local int g_dma_bm = 0;
+
 // Which of the two persistent 256 x 320 kernels: measured inside the UNet unit on one box (tools/gemm_ab.py SYN3R_GEMM_Z 0 1,
 // profiles/r04/gemm_z_ab.txt) the software-pipelined k_gemm_z is 1.6..3.5 % faster on the gated projections and 1..5 %
 // slower on the residual-add ones, a wash on their sum (74.33 against 74.23 ms): it takes the gated shapes.
@@ -1572,7 +1575,7 @@ int launch_z(const GemmParams& p, hipStream_t stream) {
 int wide_launch(const GemmParams& p, hipStream_t stream) {
     static int z_env = -2;
     if (z_env == -2) { const char* e = getenv("SYN3R_GEMM_Z"); z_env = e ? atoi(e) : -1; }
-    const bool z = z_env < 0 ? p.geglu_D > 0 : z_env != 0;
+    const bool z = g_dma_bm == -322 ? true : (g_dma_bm == -320 ? false : (z_env < 0 ? p.geglu_D > 0 : z_env != 0));
     return z ? launch_z<MODE_DENSE>(p, stream) : launch_widep(p, stream);
 }
 
@@ -1587,9 +1590,8 @@ bool widep_admits(const GemmParams& p) {
 }
 
 // Kernel family forced by the CALLING THREAD (syn3r_gemm_set_tile; tests and tuning tools): 0 = by shape, 128 / 256 = the
-// 160-column LDS-DMA kernel of that block height, -320 = the persistent 256 x 320 kernel wherever it admits the shape,
-// -321 = the 128 x 320 kernel.  thread_local: no state shared between host threads.
-thread_local int g_dma_bm = 0;
+// 160-column LDS-DMA kernel of that block height, -320 = the persistent 256 x 320 kernel k_gemm_widep wherever it admits the
+// shape, -321 = the 128 x 320 kernel, -322 = the software-pipelined 256 x 320 kernel k_gemm_z (dense, two-source, convolutions).  thread_local: no state shared between host threads.
 
 template <int MODE>
 int launch_dmap(const GemmParams& p, hipStream_t stream) {
@@ -1652,7 +1654,8 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
     if (w128_env == -2) { const char* e = getenv("SYN3R_GEMM_W128"); w128_env = e ? atoi(e) : -1; }
     const bool wide_ok = MODE == MODE_DENSE && widep_admits(p);
     if (g_dma_bm == -321) { if constexpr (MODE == MODE_DENSE) return launch_w128(p, stream); }   // syn3r_gemm_set_tile(-321)
-    if (g_dma_bm == -320 && wide_ok) return wide_launch(p, stream);                               // syn3r_gemm_set_tile(-320)
+    if (g_dma_bm == -320 && wide_ok) return launch_widep(p, stream);                              // syn3r_gemm_set_tile(-320)
+    if (g_dma_bm == -322 && wide_ok) return launch_z<MODE_DENSE>(p, stream);                      // syn3r_gemm_set_tile(-322)
     if (g_dma_bm == 0 && wide_env != 0 && wide_ok) {
         // measured on MI355X inside the UNet (tools/gemm_ab.py, same box): the 256 x 320 tile is 7..14 % faster on
         // the dense contractions whenever its tiles fill the 256 CUs (last round >= 80 % full), except the
@@ -1694,6 +1697,7 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
         const bool ok = lean && p.M % 8 == 0 && p.N % 8 == 0 && p.M >= 8 && p.N >= 8 && in_bytes < (1ll << 32) - (1 << 20) &&
                         (long long)p.N * p.K < (1ll << 31) && p.Cin % BK == 0;
         const bool pays = MODE == MODE_CONV2D && p.N >= 320 && (!p.residual || p.N >= 640);
+        if (g_dma_bm == -322 && ok) return launch_z<MODE>(p, stream);                             // syn3r_gemm_set_tile(-322)
         if (g_dma_bm == 0 && cz_env != 0 && ok && (cz_env == 1 || (fills && pays))) return launch_z<MODE>(p, stream);
     }
     // 256-row blocks (eight wavefronts, wavefronts 4-7 staggered by half a k-tile against their SIMD partners) against
@@ -1726,8 +1730,8 @@ int check_common(const GemmParams& p, const char* who) {
 }  // namespace
 
 extern "C" int syn3r_gemm_set_tile(int bm) {
-    SYN3R_REQUIRE(bm == 0 || bm == -128 || bm == -256 || bm == -320 || bm == -321,
-                  "gemm_set_tile: bm must be 0, -128, -256, -320 or -321");
+    SYN3R_REQUIRE(bm == 0 || bm == -128 || bm == -256 || bm == -320 || bm == -321 || bm == -322,
+                  "gemm_set_tile: bm must be 0, -128, -256, -320, -321 or -322");
     g_dma_bm = (bm == -128 || bm == -256) ? -bm : bm;        // this thread's launches only (thread_local)
     return SYN3R_OK;
 }

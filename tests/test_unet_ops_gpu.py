@@ -209,13 +209,13 @@ def test_ops_reject_bad_input(gpu):
 @pytest.fixture
 def every_contraction_kernel():
     """Run a test body once per contraction kernel: the per-shape default and every forced variant of
-    `syn3r_gemm_set_tile` (LDS-DMA 128/256, persistent 256x320 and 128x320 wide tiles)."""
+    `syn3r_gemm_set_tile` (LDS-DMA 128/256, the two persistent 256x320 kernels and the 128x320 wide tile)."""
     from syn3r_amd import _lib
     lib = _lib.load()
 
     def run(body):
         try:
-            for tile in (0, -128, -256, -320, -321):
+            for tile in (0, -128, -256, -320, -321, -322):
                 _lib.check(lib.syn3r_gemm_set_tile(tile), "set_tile")
                 body(tile)
         finally:
@@ -267,7 +267,8 @@ def test_gemm_persistent_wide_tile(M, N, K, gpu):
     res, aux = rnd(g, M, N, dev=gpu), rnd(g, M, N, dev=gpu)
     y = x.float() @ w.float().T
     try:
-        _lib.check(lib.syn3r_gemm_set_tile(-320), "set_tile")
+      for forced in (-320, -322):                                        # both persistent 256 x 320 kernels
+        _lib.check(lib.syn3r_gemm_set_tile(forced), "set_tile")
         close(ops.linear(x, w), y)
         close(ops.linear(x, w, b, s_acc=0.5), 0.5 * (y + b.float()))
         close(ops.linear(x, w, b, residual=res), y + b.float() + res.float())
@@ -301,7 +302,7 @@ def test_feedforward_tiled_intermediate(M, C, D, gpu):
     wp, bp, _ = ops.pack_geglu(w1, b1)
     lib = _lib.load()
     try:
-        for tile in (0, -128, -256, -320, -321):
+        for tile in (0, -128, -256, -320, -321, -322):
             _lib.check(lib.syn3r_gemm_set_tile(tile), "set_tile")
             ref = ops.linear(ops.linear_geglu(x, wp, bp, D), w2, b2, residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25)
             out = ops.feedforward(x, wp, bp, D, w2, b2, residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25)
@@ -391,6 +392,8 @@ def test_linear_cat_two_source(M, K1, K2, N, gpu):
         try:                                                    # same kernel, same arithmetic order: identical bits
             _lib.check(lib.syn3r_gemm_set_tile(-320), "set_tile")
             assert torch.equal(got, ops.linear(cat, w, b))
+            _lib.check(lib.syn3r_gemm_set_tile(-322), "set_tile")       # the software-pipelined kernel's two-source form
+            assert torch.equal(ops.linear_cat(x1, x2, w, b), ops.linear(cat, w, b))
         finally:
             lib.syn3r_gemm_set_tile(0)
 
