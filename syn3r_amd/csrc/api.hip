@@ -55,11 +55,20 @@ struct Session {
         return false;
     }
 };
-thread_local std::unique_ptr<Session> tl_own;     // the session this thread created (lives as long as the thread)
+// Sessions are handed to OTHER threads as raw pointers (syn3r_trace_session / syn3r_trace_attach: PyTorch's autograd thread joins
+// the session of the thread that opened the trace), so a session must outlive the thread that created it: sessions live in a
+// process-wide registry and are never freed (a few hundred bytes and a handful of pooled events per thread that ever traced).
+thread_local Session* tl_own = nullptr;           // the session this thread created
 thread_local Session* tl_cur = nullptr;           // the session this thread's launches record into
+std::mutex g_sessions_mu;
+std::vector<Session*> g_sessions;                 // keeps every session reachable for the life of the process
 Session* own_session() {
-    if (!tl_own) tl_own.reset(new Session());
-    return tl_own.get();
+    if (!tl_own) {
+        tl_own = new Session();
+        std::lock_guard<std::mutex> lk(g_sessions_mu);
+        g_sessions.push_back(tl_own);
+    }
+    return tl_own;
 }
 }  // namespace
 

@@ -560,11 +560,17 @@ class GSTrainer:
         return loss.detach()
 
     def _capacity_keys(self):
+        """The (device, N, H, W) keys of the binning capacities the training cameras use; the camera list is walked once per
+        list object and Gaussian count, not per iteration."""
         g = self.gaussians
         dev, n = g._xyz.device, g._xyz.shape[0]
-        shapes = {(int(c.image_height), int(c.image_width)) for c in self.scene.train_cameras[1.0]}
-        from .. import raster
-        return [raster.capacity_key(dev, n, h, w) for h, w in shapes]
+        cams = self.scene.train_cameras[1.0]
+        tag = (id(cams), len(cams), n)
+        if getattr(self, "_ck_tag", None) != tag:
+            from .. import raster
+            shapes = sorted({(int(c.image_height), int(c.image_width)) for c in cams})
+            self._ck_tag, self._ck_keys = tag, [raster.capacity_key(dev, n, h, w) for h, w in shapes]
+        return self._ck_keys
 
     def _loop(self, first_iter: int, n: int) -> float:
         from .. import raster
@@ -590,8 +596,9 @@ class GSTrainer:
                 keys0 = self._capacity_keys() if self.densify else None
                 try:
                     last = self.train_step()
-                except L.Syn3rError as e:            # the truncated image's step has already been applied: counted, reported
-                    late_overflow(e)                 # in the scene record (`truncated_renders`), capacity has been raised
+                except L.Syn3rError as e:            # raised by the render at the TOP of this step, about an earlier render
+                    late_overflow(e)                 # (whose step was applied): counted, reported in the scene record
+                    last = self.train_step()         # (`truncated_renders`), the capacity raised - this iteration runs now
                 if keys0 is not None:
                     keys1 = self._capacity_keys()
                     if keys1 != keys0:               # densification changed N: every (N, H, W) key is new.  Check what

@@ -14,9 +14,9 @@ from oracle import raster_oracle as RO
 pytestmark = pytest.mark.gpu
 
 
-def build(gpu, tmp_path, iterations=20):
+def build(gpu, tmp_path, iterations=20, N=800):
     from syn3r_amd.gs import Camera, GaussianModel, GSTrainer, OptimizationParams
-    N, H, W = 800, 72, 128
+    H, W = 72, 128
     m, s, q, o, sh = RO.synthetic_gaussians(N, seed=5, log_scale_mean=np.log(0.08))
     logit = torch.log(o.clamp(1e-3, 1 - 1e-3) / (1 - o.clamp(1e-3, 1 - 1e-3)))
     gt = GaussianModel(m, torch.log(s), q, logit, sh, device=gpu)
@@ -60,7 +60,7 @@ def _spy_finetune(trainer):
 
 def test_run_without_svd_is_plain_training(gpu, tmp_path):
     from syn3r_amd.diffusionGS import DiffusionGS
-    trainer, args = build(gpu, tmp_path, iterations=10)
+    trainer, args = build(gpu, tmp_path, iterations=10, N=10_000)      # BASELINE config 1: 3 views, 10 k Gaussians, SVD disabled
     before = trainer.gaussians._xyz.detach().clone()
     d = DiffusionGS(trainer, num_input_views=3, save_dir=str(tmp_path), diffusion_type="2PassProbUncertain",
                     interp_type="backward_warp", input_args=args)
