@@ -289,8 +289,21 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
     auto group_piece = [&](auto QC) {
         constexpr int q = decltype(QC)::value;
         constexpr int order[9] = {0, 4, 1, 5, 2, 6, 3, 7, 8};     // A and B pieces alternate
+#ifdef Z_EXP_DEPHASE        // timing experiment (wrong results; build with -DZ_EXP_NOVMWAIT): wavefronts 4-7 issue their pieces in groups 8-16
+        if constexpr (q < 9) { if (wv < 4) piece(std::integral_constant<int, order[q < 9 ? q : 0]>{}); }
+        if constexpr (q >= 8 && q < 17) { if (wv >= 4) piece(std::integral_constant<int, order[(q >= 8 && q < 17) ? q - 8 : 0]>{}); }
+        if constexpr (q == 16) cursor_end();
+#elif defined(Z_BUNCH)      // the nine pieces in the first three groups (three each) instead of one per group
+        if constexpr (q < 3) {
+            piece(std::integral_constant<int, order[q < 3 ? 3 * q : 0]>{});
+            piece(std::integral_constant<int, order[q < 3 ? 3 * q + 1 : 0]>{});
+            piece(std::integral_constant<int, order[q < 3 ? 3 * q + 2 : 0]>{});
+        }
+        if constexpr (q == 2) cursor_end();
+#else
         if constexpr (q < 9) piece(std::integral_constant<int, order[q < 9 ? q : 0]>{});
         if constexpr (q == 8) cursor_end();
+#endif
     };
 #define Z_YOUNGER(q) ((19 - (q) < LA ? 19 - (q) : LA) + ((NAF == 2 && (q) >= 7 && (q) < 7 + LA && (q) != 10) ? 4 : 0))
 // (group 10 also needs the A reads of k-half 1: with two register sets they were issued at group 7 and the allowed count is the

@@ -33,7 +33,10 @@ def ktype(name):
     m = re.search(r"k_gemm\w*(<[^>]*>)?", n)
     if m:
         t = m.group(0)
-        return "k_gemm_z" if t.startswith("k_gemm_z") else ("k_gemm_skinny" if t.startswith("k_gemm_skinny") else t)
+        if t.startswith("k_gemm_z"):                      # k_gemm_z<TWOSRC, MODE[, ...]> -> the tracer's k_gemm_z<MODE>
+            a = re.findall(r"-?\d+|true|false", t[len("k_gemm_z"):])
+            return f"k_gemm_z<{a[1] if len(a) > 1 else 0}>"
+        return "k_gemm_skinny" if t.startswith("k_gemm_skinny") else t
     for pat, fam in OTHER.items():
         if pat in name:
             return fam
@@ -68,7 +71,7 @@ def algorithmic_bytes(shapes_txt):
             b = 2 * (M * 320 * 2 + 3 * D * 320 + (M * 320 if e else 0))
         else:
             N, K = int(f["N"]), int(f["K"])
-            taps = 9 if "<1" in kt else (3 if "<2" in kt else 1)            # implicit GEMM: every input element counted once
+            taps = 9 if "<1" in kt else (3 if "<2" in kt else 1)            # implicit GEMM (MODE 1 / 2): every input element counted once
             b = 2 * (M * (K // taps) + N * K + M * (N // 2 if e == 2 else N) + (M * N if e == 1 else 0))
         acc[kt][0] += n
         acc[kt][1] += float(b) * n
