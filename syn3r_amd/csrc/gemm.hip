@@ -1679,13 +1679,12 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
         }
     }
     // Convolutions on the 256 x 320 tile (round 4, k_gemm_z<MODE>): lean epilogue (no ReLU options, aux only with a residual),
-    // whole 16-byte column chunks, 32-bit byte offsets into the input, and a grid that fills the chip as the dense rule
-    // above asks (M = 4 032 at level 3 gives 64 tiles: those stay on the 160-column tile, 128 blocks).  Measured inside the
-    // UNet unit, same box (tools/gemm_ab.py SYN3R_CONV_Z 0 1, profiles/r04/conv_z_ab.txt): 3x3 convolutions without a
-    // residual -5..-7 %, with one -1..-3 % at N >= 640 and +3 % at N = 320 (the 160-column kernel's epilogue requests the
-    // residual before it stages the accumulators), the temporal convolutions +-2 % without and +12 % with a residual, the
-    // 8-column output convolution +77 % (one 320-wide tile column for 8 columns): by default only the 3x3 convolutions with
-    // N >= 320 and (no residual or N >= 640).  SYN3R_CONV_Z=0: never; 1: every admissible shape (tests, tuning).
+    // whole 16-byte column chunks, 32-bit byte offsets into the input, no fused upsample, and a grid that fills the chip as the
+    // dense rule above asks (M = 4 032 at level 3 gives 64 tiles: +110 % there - those stay on the 160-column tile, 128 blocks).
+    // Measured inside the UNet unit, same box (tools/gemm_ab.py SYN3R_CONV_Z 0 1, profiles/r04/conv_z_ab.txt), with the filter
+    // taps innermost in K: 3x3 convolutions -4..-12 % (isolated +8..+16 %, 1 165-1 352 TFLOP/s), the temporal convolutions +-2 %
+    // without and +12 % with a residual (they stay), the 8-column output convolution +64 % (one 320-wide tile column for 8
+    // columns: stays).  SYN3R_CONV_Z=0: never; 1: every admissible shape (tests, tuning).
     if constexpr (MODE != MODE_DENSE) {
         static int cz_env = -2;
         if (cz_env == -2) { const char* e = getenv("SYN3R_CONV_Z"); cz_env = e ? atoi(e) : -1; }
@@ -1693,10 +1692,11 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
         const long long rounds = (tiles + 255) / 256;
         const bool fills = tiles * 10 >= rounds * 256 * 8;
         const long long in_bytes = MODE == MODE_CONV2D ? (long long)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2 : (long long)p.M * p.Cin * 2;
-        const bool lean = !p.relu && !p.relu_mask && (!p.aux || p.residual) && p.geglu_D <= 0 && !p.A2 && !p.a_tiled;
+        const bool lean = !p.relu && !p.relu_mask && (!p.aux || p.residual) && p.geglu_D <= 0 && !p.A2 && !p.a_tiled &&
+                          !(MODE == MODE_CONV2D && p.ups);      // (the fused nearest-2x upsample is not an affine gather: 160-column kernel)
         const bool ok = lean && p.M % 8 == 0 && p.N % 8 == 0 && p.M >= 8 && p.N >= 8 && in_bytes < (1ll << 32) - (1 << 20) &&
                         (long long)p.N * p.K < (1ll << 31) && p.Cin % BK == 0;
-        const bool pays = MODE == MODE_CONV2D && p.N >= 320 && (!p.residual || p.N >= 640);
+        const bool pays = MODE == MODE_CONV2D && p.N >= 320;
         if (g_dma_bm == -322 && ok) return launch_z<MODE>(p, stream);                             // syn3r_gemm_set_tile(-322)
         if (g_dma_bm == 0 && cz_env != 0 && ok && (cz_env == 1 || (fills && pays))) return launch_z<MODE>(p, stream);
     }

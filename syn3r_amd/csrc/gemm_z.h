@@ -115,10 +115,23 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
     constexpr unsigned kPad = 0xffffffffu;
     constexpr int NCV = MODE == MODE_DENSE ? 1 : 4;
     unsigned cv_off[NCV];
-    int c_tap = 0, c_left = 0;                                 // next filter tap, k-tiles left in the current one (wave-uniform)
+    // MODE_CONV2D walks K as (64-channel chunk, filter tap) with the TAPS INNERMOST - W's [Cout][tap][Cin] rows are read at
+    // (tap Cin + 64 chunk) - so the nine shifted reads of one channel slice of an XCD's band of image rows (64 rows x 128 pixels
+    // x 64 channels = 1 MB) follow each other and hit that XCD's L2; with the taps outermost every tap re-streams the whole
+    // band (5 MB at C = 320) through a 4 MB L2: the PMC passes counted 5.2x the algorithmic bytes (profiles/r04).  The pixel of
+    // each piece (y << 16 | x, byte offset of its image) is kept per lane and tile; a k-tile's source offset is a few integer
+    // operations from it.  MODE_TCONV keeps taps outermost (3 taps, whole rows: nothing to gain).
+    // conv2d per-lane state (no nearest-2x upsample: launch_dma): cv_base[i] = byte offset of the lane's 16-byte chunk at the
+    // pixel its output pixel maps to for the CENTRE-less tap (dy = dx = 0 before the padding shift) - every tap and channel chunk
+    // is that plus a wave-uniform offset - and ONE register of validity bits, six per piece: tap row 0-2 in range, tap column
+    // 0-2 in range.
+    unsigned cv_base[MODE == MODE_CONV2D ? 4 : 1], cv_flags = 0;
+    int c_tap = 0, c_left = 0, c_chunk = 0;                    // filter tap / k-tiles left in it (tconv) / channel chunk (conv2d)
+    unsigned kb = 0;                                           // conv2d: byte offset of the k-tile inside a weight row
+    int tap_off = 0;                                           // conv2d: wave-uniform byte offset of k-tile (chunk, tap) from cv_base
+    unsigned tap_mask = 0;                                     // conv2d: the two validity bits of the current tap (piece 0's position)
     const int cpb = MODE == MODE_DENSE ? 1 : p.Cin / BK;       // k-tiles per filter tap
-    // m / d for m < 2^24 (launch_dma checks M) by one float multiply and a correction step: the pixel coordinates are rebuilt
-    // at every tap change (4 pieces x 2 divisions per lane, every Cin / 64 k-tiles) instead of living in eight registers
+    // m / d for m < 2^24 (launch_dma checks M) by one float multiply and a correction step
     auto udiv = [](unsigned m, unsigned d, float rcp, unsigned& rem) -> unsigned {
         unsigned q = (unsigned)((float)m * rcp);
         int r = (int)(m - q * d);
@@ -130,24 +143,39 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
     const unsigned d_hw = MODE == MODE_CONV2D ? (unsigned)(p.Ho * p.Wo) : (unsigned)(MODE == MODE_TCONV ? p.HW : 1);
     const unsigned d_w = MODE == MODE_CONV2D ? (unsigned)p.Wo : (unsigned)(MODE == MODE_TCONV ? p.F : 1);
     const float r_hw = 1.0f / (float)d_hw, r_w = 1.0f / (float)d_w;
-    auto conv_tap = [&](int tap) {                             // the chunk offsets of filter tap `tap` for the tile at c_m0
-        int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        asm volatile("" : "+v"(l));
-        const unsigned chunk = (unsigned)(((l & 7) ^ (l >> 3)) * 16);
+    auto conv_tile = [&]() {                                   // conv2d: this lane's four output pixels of the tile at c_m0
+        if constexpr (MODE == MODE_CONV2D) {
+            int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(l));
+            const unsigned lanechunk = (unsigned)(((l & 7) ^ (l >> 3)) * 16);
+            cv_flags = 0;
 #pragma unroll
-        for (int i = 0; i < NCV; ++i) {
-            unsigned m = (unsigned)(c_m0 + wv * 32 + i * 8 + (l >> 3));
-            m = m < (unsigned)p.M ? m : (unsigned)p.M - 1u;
-            if constexpr (MODE == MODE_CONV2D) {
+            for (int i = 0; i < 4; ++i) {
+                unsigned m = (unsigned)(c_m0 + wv * 32 + i * 8 + (l >> 3));
+                m = m < (unsigned)p.M ? m : (unsigned)p.M - 1u;
                 unsigned r, x;
                 const unsigned n = udiv(m, d_hw, r_hw, r), y = udiv(r, d_w, r_w, x);
-                const int dy = tap / 3 - p.pad, dx = tap % 3 - p.pad;
-                const int Hg = p.ups ? p.Hi * 2 : p.Hi, Wg = p.ups ? p.Wi * 2 : p.Wi;
-                int yy = (int)y * p.stride + dy, xx = (int)x * p.stride + dx;
-                const bool ok = yy >= 0 && yy < Hg && xx >= 0 && xx < Wg;
-                if (p.ups) { yy >>= 1; xx >>= 1; }
-                cv_off[i] = ok ? ((n * (unsigned)p.Hi + (unsigned)yy) * (unsigned)p.Wi + (unsigned)xx) * (unsigned)p.Cin * 2u + chunk : kPad;
-            } else if constexpr (MODE == MODE_TCONV) {
+                const int y0 = (int)y * p.stride - p.pad, x0 = (int)x * p.stride - p.pad;       // input pixel of tap (0, 0)
+                cv_base[i] = (unsigned)(((int)(n * (unsigned)p.Hi) + y0) * p.Wi + x0) * (unsigned)p.Cin * 2u + lanechunk;
+                unsigned f = 0;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    f |= (unsigned)(y0 + t >= 0 && y0 + t < p.Hi) << t;
+                    f |= (unsigned)(x0 + t >= 0 && x0 + t < p.Wi) << (3 + t);
+                }
+                cv_flags |= f << (6 * i);
+            }
+        }
+    };
+    auto conv_tap = [&](int tap) {                             // tconv: the chunk offsets of frame tap `tap` for the tile at c_m0
+        if constexpr (MODE == MODE_TCONV) {
+            int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(l));
+            const unsigned chunk = (unsigned)(((l & 7) ^ (l >> 3)) * 16);
+#pragma unroll
+            for (int i = 0; i < NCV; ++i) {
+                unsigned m = (unsigned)(c_m0 + wv * 32 + i * 8 + (l >> 3));
+                m = m < (unsigned)p.M ? m : (unsigned)p.M - 1u;
                 unsigned r, f;
                 const unsigned bf_ = udiv(m, d_hw, r_hw, r);           // m = (b F + f) HW + pixel
                 (void)udiv(bf_, d_w, r_w, f);
@@ -163,7 +191,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
             tile_origin(t_start + c_tl, c_m0, n0_, tn_);
             abase = (const char*)p.A;
             second = false;
-            if constexpr (MODE != MODE_DENSE) { c_tap = 0; c_left = 0; }
+            if constexpr (MODE != MODE_DENSE) { c_tap = 0; c_left = 0; c_chunk = 0; }
+            conv_tile();
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int r = c_m0 + wv * 32 + i * 8;
@@ -188,13 +217,19 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
             }
 #pragma unroll
             for (int j = 0; j < 5; ++j) ob[j] += 2u * BK;
-        } else {
+        } else if constexpr (MODE != MODE_CONV2D) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) oa[i] += a_step;
 #pragma unroll
             for (int j = 0; j < 5; ++j) ob[j] += 2u * BK;
         }
-        if constexpr (MODE != MODE_DENSE) {
+        if constexpr (MODE == MODE_CONV2D) {                   // k-tile (c_chunk, c_tap), taps innermost; ob[] stay the row offsets
+            const int ty = c_tap / 3, tx = c_tap - 3 * ty;
+            tap_off = ((ty * p.Wi + tx) * p.Cin + c_chunk * BK) * 2;
+            tap_mask = (1u << ty) | (8u << tx);
+            kb = (unsigned)(c_tap * p.Cin + c_chunk * BK) * 2u;
+            if (++c_tap == 9) { c_tap = 0; ++c_chunk; }
+        } else if constexpr (MODE == MODE_TCONV) {
             if (c_left == 0) { conv_tap(c_tap); ++c_tap; c_left = cpb; }
             else {
 #pragma unroll
@@ -230,7 +265,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
         }
         return;
 #endif
-        if constexpr (idx < 4 && MODE != MODE_DENSE) {
+        if constexpr (idx < 4 && MODE == MODE_CONV2D) {
+            const unsigned mk = tap_mask << (6 * idx);
+            const bool ok = (cv_flags & mk) == mk;
+            const char* src = ok ? (const char*)p.A + (size_t)(cv_base[idx < 4 ? idx : 0] + (unsigned)tap_off) : (const char*)g_zero_page;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wv * 4 + idx) * 1024), 16, 0, 0);
+        } else if constexpr (idx < 4 && MODE != MODE_DENSE) {
             const unsigned o = cv_off[idx < NCV ? idx : 0];
             const char* src = o == kPad ? (const char*)g_zero_page : (const char*)p.A + (size_t)o;
             __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wv * 4 + idx) * 1024), 16, 0, 0);
@@ -239,7 +279,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase + (size_t)(oa[idx] + va)), (lds_void_t*)(st + (wv * 4 + idx) * 1024), 16, 0, 0);
         } else {
             constexpr int j = idx - 4;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.W + (size_t)(ob[j] + voff_b)), (lds_void_t*)(st + W_A_BYTES + (wv * 5 + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.W + (size_t)(ob[j] + (MODE == MODE_CONV2D ? kb : 0u) + voff_b)), (lds_void_t*)(st + W_A_BYTES + (wv * 5 + j) * 1024), 16, 0, 0);
         }
     };
 

@@ -246,9 +246,19 @@ def test_every_contraction_kernel_agrees(gpu, every_contraction_kernel):
     y = (x.float() @ wg.float().T + bg.float()).half().float()
     ref_g = y[:, :D] * Fn.gelu(y[:, D:])
 
+    # more than one 64-channel chunk per tap (k_gemm_z walks K chunk-major with the taps innermost, the others tap-major) and
+    # the stride-2 / (0,1,0,1)-padded downsampling form (downsampling.py:116-148)
+    xc2 = rnd(g, 2, 10, 12, 192, dev=gpu)
+    wc2, bc2 = rnd(g, 328, 3, 3, 192, scale=(9 * 192) ** -0.5, dev=gpu), rnd(g, 328, dev=gpu)
+    nchw = lambda t: t.float().permute(0, 3, 1, 2)
+    ref_conv2 = Fn.conv2d(nchw(xc2), nchw(wc2), bc2.float(), padding=1).permute(0, 2, 3, 1)
+    ref_conv2s = Fn.conv2d(Fn.pad(nchw(xc2), (0, 1, 0, 1)), nchw(wc2), bc2.float(), stride=2).permute(0, 2, 3, 1)
+
     def body(tile):
         close(ops.linear(x, w, b, rowvec=rv, rows_per_vec=rpv, residual=res, aux=aux, s_acc=0.3, s_res=1.0, s_aux=0.7), ref_lin)
         close(ops.conv3x3(xc, wc, bc), ref_conv)
+        close(ops.conv3x3(xc2, wc2, bc2), ref_conv2)
+        close(ops.conv3x3(xc2, wc2, bc2, stride=2, pad_lo=0), ref_conv2s)
         close(ops.tconv3(xt, wt, bt, B, F, HW), ref_t)
         close(ops.linear_geglu(x, wp, bp, D), ref_g, tol=4e-3)
     every_contraction_kernel(body)
