@@ -84,6 +84,7 @@ struct GemmParams {
     // (stride lda2) - the channel concatenation [A | A2] the up blocks' shortcut projection reads is never written.
     const __half* A2; long long lda2; int K1;     // A2 = null: one source
     // VGG-style activation options of the GENERAL epilogue (gemm_epilogue; the convolution kernels use it):
+    int band;                             // persistent 256 x 320 kernels: tile columns per band of the tile order (band_width())
     int relu;                             // result = max(result, 0)
     const __half* relu_mask;              // [M][ldc]: result zeroed where mask <= 0 (ReLU backward: grad * (activation > 0))
 };
@@ -661,7 +662,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm_widep(GemmParams p) {
     // for 2.4 MB of LDS fill, and the band's weight panel (4 x 320 rows x K) is what the XCD keeps re-reading round
     // after round.  Plain row-major order made that 2 x 16 (N = 5120: 704 KB) or 1 x 32 (N = 10240: 1.3 MB per
     // k-tile, ~6 TB/s chip-wide from beyond the L2) with a weight panel that no L2 holds.
-    const unsigned bw = tiles_n >= 4 ? 4u : (unsigned)tiles_n;
+    const unsigned bw0 = p.band > 0 ? (unsigned)p.band : 4u;
+    const unsigned bw = (unsigned)tiles_n >= bw0 ? bw0 : (unsigned)tiles_n;
     const unsigned band_sz = (unsigned)tiles_m * bw, full_bands = (unsigned)tiles_n / bw;
     auto setup_tile = [&](unsigned tile) {
         unsigned b = tile / band_sz, w = bw, t2 = tile - b * band_sz;
@@ -1520,6 +1522,20 @@ int persistent_blocks() {
     return n;
 }
 
+// Tile columns per band of the persistent 256 x 320 kernels' tile order (bands of `band` tile columns, row-major inside a band: the
+// 32 tiles an XCD holds at a time are ~32 / band rows x band columns).  A narrower band re-reads A more often from beyond the L2
+// (once per band) but keeps the band's weight panel (band x 320 x K x 2 B) well inside the 4 MB L2.  Measured
+// (tools/band_ab.sh and tools/gemm_ab.py, profiles/r04/band_width.txt): with more than four tile columns and K = 640, 3 beats 4 by
+// 4-7 % both isolated and inside the unit ([64512,5120,640]: 564 -> 541 us isolated, 7.35 -> 6.85 ms per unit over its 15
+// calls); at K = 1280 the isolated gain ([16128,10240,1280] 432 -> 392 us) does not survive inside the unit (+0.5 %, and +4 % on
+// [4032,10240,1280]), and with at most four tile columns one band (A read once) is best.  SYN3R_Z_BAND overrides (tuning).
+int band_width(const GemmParams& p) {
+    static int band_env = -2;
+    if (band_env == -2) { const char* e = getenv("SYN3R_Z_BAND"); band_env = e ? atoi(e) : 0; }
+    if (band_env > 0) return band_env;
+    return ((p.N + WBN - 1) / WBN > 4 && p.K <= 640) ? 3 : 4;
+}
+
 int launch_widep(const GemmParams& p, hipStream_t stream) {
     constexpr size_t lds = (size_t)2 * W_STAGE + 16384;   // 163,840 B: the ring + the tail the epilogue staging runs into
     static_assert(8 * WM * EPI_LD * sizeof(__half) <= lds - W_STAGE, "epilogue staging must fit behind ring slot 0");
@@ -1536,7 +1552,9 @@ int launch_widep(const GemmParams& p, hipStream_t stream) {
         if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_widep[M%d,N%d,K%d,e%d]", p.M, p.N, p.K, p.geglu_D > 0 ? 2 : (p.residual != nullptr));
         else snprintf(name, sizeof(name), "k_gemm_widep");
     }
-    SYN3R_LAUNCH_NAMED(name, k_gemm_widep, dim3(blocks), dim3(512), lds, stream, p);
+    GemmParams q = p;
+    q.band = band_width(p);
+    SYN3R_LAUNCH_NAMED(name, k_gemm_widep, dim3(blocks), dim3(512), lds, stream, q);
     SYN3R_LAUNCH_CHECK("gemm_widep launch");
     return SYN3R_OK;
 }
@@ -1552,15 +1570,18 @@ int launch_z(const GemmParams& p, hipStream_t stream) {
     }
     int tiles = ((p.M + WBM - 1) / WBM) * ((p.N + WBN - 1) / WBN);
     const int blocks = std::min(tiles, persistent_blocks());
+    GemmParams q = p;
+    q.band = band_width(p);
+    const GemmParams& p_ = q;
     char name[96];
     if (trace_on()) {
         if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_z<%d>[M%d,N%d,K%d,e%d]", MODE, p.M, p.N, p.K, p.geglu_D > 0 ? 2 : (p.residual != nullptr));
         else snprintf(name, sizeof(name), "k_gemm_z<%d>", MODE);
     }
     if constexpr (MODE == MODE_DENSE) {
-        if (p.A2) { SYN3R_LAUNCH_NAMED(name, (k_gemm_z<true, MODE_DENSE>), dim3(blocks), dim3(512), Z_LDS, stream, p); SYN3R_LAUNCH_CHECK("gemm_z launch"); return SYN3R_OK; }
+        if (p.A2) { SYN3R_LAUNCH_NAMED(name, (k_gemm_z<true, MODE_DENSE>), dim3(blocks), dim3(512), Z_LDS, stream, p_); SYN3R_LAUNCH_CHECK("gemm_z launch"); return SYN3R_OK; }
     }
-    SYN3R_LAUNCH_NAMED(name, (k_gemm_z<false, MODE>), dim3(blocks), dim3(512), Z_LDS, stream, p);
+    SYN3R_LAUNCH_NAMED(name, (k_gemm_z<false, MODE>), dim3(blocks), dim3(512), Z_LDS, stream, p_);
     SYN3R_LAUNCH_CHECK("gemm_z launch");
     return SYN3R_OK;
 }

@@ -82,7 +82,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
     const int nkt = p.K / BK;
     // tile order: bands of 4 tile columns, row-major inside a band (as k_gemm_widep: the 32 tiles an XCD holds at a time are
     // 8 rows x 4 columns and the band's weight panel is what that XCD's L2 keeps)
-    const unsigned bw = tiles_n >= 4 ? 4u : (unsigned)tiles_n;
+    const unsigned bw0 = p.band > 0 ? (unsigned)p.band : 4u;
+    const unsigned bw = (unsigned)tiles_n >= bw0 ? bw0 : (unsigned)tiles_n;
     const unsigned band_sz = (unsigned)tiles_m * bw, full_bands = (unsigned)tiles_n / bw;
     auto tile_origin = [&](unsigned tile, int& m0, int& n0, int& tn) {
         unsigned b = tile / band_sz, w = bw, t2 = tile - b * band_sz;

@@ -1,0 +1,1 @@
+for b in 1 2 3 4; do echo "SYN3R_Z_BAND=$b"; SYN3R_Z_BAND=$b SYN3R_GEMM_Z=1 python tools/gemm_iso3.py - 2>&1 | grep -v amdgpu.ids | cut -c26-420; done
