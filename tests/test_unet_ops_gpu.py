@@ -126,6 +126,29 @@ def test_attention_spatial_peaked_softmax(gpu):
     close(out, ref, tol=3e-3)
 
 
+@pytest.mark.parametrize("growth", [0.5, 3.0, 12.0])
+def test_attention_spatial_moving_reference(growth, gpu):
+    """The softmax reference the kernel subtracts is moved lazily (only past a threshold): keys whose logits grow along
+    the sequence, slowly (below the threshold per tile), faster and in jumps larger than fp16 could hold without the move;
+    and large negative logits in the first tile (the reference starts below zero)."""
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(11)
+    S, C = 1000, 64
+    qkv = rnd(g, S, 3 * C, dev=gpu)
+    q = qkv[:, :C].float()
+    # key j = a copy of the mean query direction scaled so that its logit grows ~linearly along the sequence
+    d = q.mean(0)
+    d = d / d.norm()
+    qkv[:, :C] = (q + 2.0 * d).half()                                    # every query has a positive component along d
+    ramp = torch.linspace(-growth * 8, growth * 8, S, device=gpu)[:, None]
+    qkv[:, C:2 * C] = (qkv[:, C:2 * C].float() + ramp * d).half()
+    out = ops.attention(qkv, 1, S, 1)
+    qq, k, v = [t.float().reshape(1, S, 1, 64).transpose(1, 2) for t in qkv.split(C, dim=1)]
+    ref = Fn.scaled_dot_product_attention(qq, k, v).transpose(1, 2).reshape(S, C)
+    assert torch.isfinite(out.float()).all()
+    close(out, ref, tol=3e-3)
+
+
 @pytest.mark.parametrize("B,F,HW,heads", [(2, 14, 50, 2), (1, 25, 33, 5), (2, 3, 7, 1), (1, 32, 9, 1)])
 def test_attention_temporal(B, F, HW, heads, gpu):
     from syn3r_amd.unet import ops
