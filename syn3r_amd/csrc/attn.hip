@@ -14,7 +14,7 @@
 // sum is a register reduction plus one lane^32 exchange (no 32-lane shuffles).  The probability
 // tile is then used directly from the accumulator as the B operand of O^T += V^T.P (the k order
 // of an accumulator-sourced fragment is permuted: element j of lane half h is key 16s + 8(j>>2) + 4h + (j&3)).
-// V stays row-major [key][d] in LDS (16-byte coalesced staging) and its transposed A fragments come from
+// V stays row-major [key][d] in LDS (16-byte pieces, LDS-DMA in k_attn_spatial) and its transposed A fragments come from
 // gfx950's ds_read_b64_tr_b16: each 16-lane group fetches a 4-key x 16-d block column-major, two reads
 // (keys r0..r0+3 and r0+8..r0+11) make exactly the permuted 8-key fragment.
 #include "common.h"
@@ -80,224 +80,21 @@ struct AttnParams {
 
 constexpr int BQ = 128, BKV = 64, ATHREADS = 256;
 
-__global__ void __launch_bounds__(ATHREADS, 2) k_attn_spatial_v1(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) __half Ks[2][BKV * 64];
-    __shared__ __attribute__((aligned(16))) __half Vs[2][BKV * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int lq = lane & 31, h = lane >> 5;
-    const int qblocks = (p.S + BQ - 1) / BQ;
-    // all query blocks of one (sequence, head) share its K/V (2.4 MB at S = 9216): keep them on one XCD's L2
-    int bid = (int)xcd_chunk_remap(blockIdx.x, gridDim.x);
-    const int qb = bid % qblocks; bid /= qblocks;
-    const int hd = bid % p.heads;
-    const int seq = bid / p.heads;
-    const long long row0 = (long long)seq * p.S;
-    const int q0 = qb * BQ + wv * 32;
-    const __half* qp = p.q + hd * 64;
-    const __half* kp = p.k + hd * 64;
-    const __half* vp = p.v + hd * 64;
-
-    // Q fragments (B operand), prescaled by 1/8 (exact in fp16)
-    half8 qf[4];
-    {
-        int qi = q0 + lq;
-        if (qi > p.S - 1) qi = p.S - 1;
-        const __half* src = qp + (row0 + qi) * p.ld;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            half8 t = *(const half8*)(src + ks * 16 + 8 * h);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = t[j] * (_Float16)0.125f;
-            qf[ks] = t;
-        }
-    }
-
-    // staging assignment: 64 keys x 8 chunks = 512 chunks, 2 per thread.  The two K and two V source pointers of a
-    // thread advance by one tile (64 rows) per call: no per-tile 64-bit address arithmetic, and the row-in-range test
-    // is wave-uniform (only a sequence's last, partial tile takes the checked path).
-    const int s_chunk = tid & 7;
-    const int s_key0 = tid >> 3;   // keys s_key0 and s_key0 + 32
-    uint4 rk[2], rv[2];
-    const __half* kptr = kp + (row0 + s_key0) * p.ld + s_chunk * 8;
-    const __half* vptr = vp + (row0 + s_key0) * p.ld + s_chunk * 8;
-    const long long half_tile = 32 * p.ld, tile_step = (long long)BKV * p.ld;
-    auto load_kv = [&](int kv0) {
-        if (kv0 + BKV <= p.S) {
-            rk[0] = *(const uint4*)kptr; rk[1] = *(const uint4*)(kptr + half_tile);
-            rv[0] = *(const uint4*)vptr; rv[1] = *(const uint4*)(vptr + half_tile);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (kv0 + s_key0 + 32 * i < p.S) {
-                    rk[i] = *(const uint4*)(kptr + i * half_tile);
-                    rv[i] = *(const uint4*)(vptr + i * half_tile);
-                } else {
-                    rk[i] = make_uint4(0, 0, 0, 0);
-                    rv[i] = make_uint4(0, 0, 0, 0);
-                }
-            }
-        }
-        kptr += tile_step;
-        vptr += tile_step;
-    };
-    auto store_kv = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int key = s_key0 + 32 * i;
-            *(uint4*)(&Ks[buf][k_off(key, s_chunk)]) = rk[i];
-            *(uint4*)(&Vs[buf][v_off(key, s_chunk * 8)]) = rv[i];
-        }
-    };
-
-    // Softmax bookkeeping is kept off the critical resources: the exponent argument and the row sums are
-    // packed fp32 operations (v_pk_fma_f32 / v_pk_add_f32), the lane^32 exchange of the row maximum is a
-    // v_permlane32_swap instead of an LDS-pipe shuffle, and both LDS images are bank-conflict free.
-    float16v ot[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; }
-    float m_run = kNegBig;
-    float l_run = 0.f;
-
-    const int ntiles = (p.S + BKV - 1) / BKV;
-    // one KV tile; CUR (the LDS buffer) is a compile-time constant so every fragment address is base + immediate
-    auto tile = [&](int t, auto CUR) {
-        constexpr int cur = decltype(CUR)::value;
-        if (t + 1 < ntiles) load_kv((t + 1) * BKV);
-        // S^T = K . Q^T : two 32-key groups
-        // Fragment reads are issued in batches AHEAD of the MFMAs that consume them (hipcc otherwise emits
-        // read / wait / MFMA triples, exposing one LDS round trip per MFMA: ~1300 cycles per phase against 256 of
-        // matrix work): all eight K fragments before QK^T, and all eight V fragments before the softmax, whose
-        // VALU work then covers their latency.
-        float16v st[2];
-        half8 kf[2][4];
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kf[g][ks] = *(const half8*)(&Ks[cur][k_off(g * 32 + lq, ks * 2 + h)]);
-        __builtin_amdgcn_sched_barrier(0);
-        // The QK^T MFMAs issue at raised priority: VALU arbitration between the waves of a SIMD is by priority, then
-        // age, and at equal priority the other waves' softmax VALU starves this wave's matrix issue (+5 %).
-        // The first MFMA of each chain takes the constant 0 as its C operand: no zeroing of 32 accumulator registers.
-        const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int g = 0; g < 2; ++g) st[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[g][0], qf[0], zero16, 0, 0, 0);
-#pragma unroll
-        for (int ks = 1; ks < 4; ++ks)
-#pragma unroll
-            for (int g = 0; g < 2; ++g) st[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[g][ks], qf[ks], st[g], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        half8 vf[2][2][2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) vf[g][s][dt] = v_frag_tr(Vs[cur], g * 32 + s * 16 + 4 * h, dt * 32, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        const int kv0 = t * BKV;
-        if (kv0 + BKV > p.S) {   // wave-uniform: mask keys beyond the sequence
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int key = kv0 + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (key >= p.S) st[g][r] = kNegBig;
-                }
-        }
-        // four independent max chains (then a 2-level combine) instead of one 32-long dependent chain: with three
-        // waves per SIMD the softmax phase is bound by VALU latency, not issue
-        float mq[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) mq[c] = st[c >> 1][(c & 1) * 8];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 1; r < 8; ++r) mq[c] = fmaxf(mq[c], st[c >> 1][(c & 1) * 8 + r]);
-        float mx = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
-        {
-            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(mx), __float_as_int(mx), false, false);
-            mx = fmaxf(__int_as_float(sw[0]), __int_as_float(sw[1]));
-        }
-        const float m_new = fmaxf(m_run, mx);
-        // rescale the running sums only when some query's maximum moved (wave-uniform test)
-        if (__ballot(m_new != m_run) != 0ull) {
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
-            l_run *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
-            m_run = m_new;
-        }
-        const float2v l2 = {kLog2e, kLog2e};
-        const float2v mn = {-m_new * kLog2e, -m_new * kLog2e};
-        float2v ls2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};      // independent partial sums
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                float2v x = {st[g][r], st[g][r + 1]};
-                x = x * l2 + mn;                                   // exp(s - m) = exp2(s log2e - m log2e): v_pk_fma_f32
-                float2v e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-                st[g][r] = e[0];
-                st[g][r + 1] = e[1];
-                ls2[(r >> 1) & 3] += e;
-            }
-        {
-            const float2v t = (ls2[0] + ls2[1]) + (ls2[2] + ls2[3]);
-            l_run += t[0] + t[1];
-        }
-        // O^T += V^T . P
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                half8 pf = pack8(st[g], s);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[g][s][dt], pf, ot[dt], 0, 0, 0);
-            }
-        __builtin_amdgcn_s_setprio(0);
-        if (t + 1 < ntiles) store_kv(cur ^ 1);
-        __syncthreads();
-    };
-    load_kv(0);
-    store_kv(0);
-    __syncthreads();
-    for (int t = 0; t < ntiles; t += 2) {
-        tile(t, std::integral_constant<int, 0>{});
-        if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
-    }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int qi = q0 + lq;
-    if (qi < p.S) {
-        __half* dst = p.o + (row0 + qi) * p.ldo + hd * 64;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                half4 o4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o4[e] = (_Float16)(ot[dt][4 * g + e] * inv);
-                *(half4*)(dst + dt * 32 + 8 * g + 4 * h) = o4;
-            }
-    }
-}
-
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-// Vector-issue budget of one 32-query x 64-key score tile (the kernel is bound by the SIMD's vector issue port, not by the
-// matrix pipe: MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'): 16 MFMAs, 32 v_exp_f32, 24 max, 16 cvt_pk, and the
-// LDS fragment reads are what the algorithm needs.  Everything else is kept off that port:
+// k_attn_spatial: what one 32-query x 64-key score tile costs a wavefront is 16 MFMAs (32 x 32 x 16), 32 v_exp_f32,
+// 24 max, 16 cvt_pk and 24 LDS fragment reads; under this kernel the chip runs at ~1.4 GHz (GRBM_GUI_ACTIVE), the SIMD has
+// an instruction active 97 % of the time and the vector port 66 % (profiles/r04/attention_v2.txt).  Everything the
+// algorithm does not need is kept off the vector port, partly by giving it to the matrix pipe:
 //   * Q is prescaled by log2(e)/8 (one fp32 multiply, one rounding to fp16), and the running maximum is subtracted BY THE
 //     MATRIX PIPE: one extra k-step per 32-key group, A = a constant fragment with ones in k-slots 0 and 1, B = a fragment
 //     holding (-m_hi, -m_lo) of the lane's query in those slots (m = m_hi + m_lo exactly, two fp16), so the accumulator
 //     leaves the pipe as s*log2e - m, ready for v_exp_f32.  The B fragment is rewritten only when a query's maximum moved
 //     (wave-uniform test; after the first tiles of a sequence it almost never does): the 16 v_pk_fma per tile are gone for
 //     two MFMAs (16 issue cycles).  (A 16-register C tuple holding -m does the same without the extra MFMAs, but hipcc
-//     alternates it between two tuples and copies per tile.)
+//     ties the second MFMA's C to its D and copies the tuple per tile: measured 3 % slower.)
 //   * the row sums come from the matrix pipe too: v_mfma_f32_4x4x4_16b_f16 with an all-ones A operand returns, in each
 //     lane, the fp32 sum of that lane's own four fp16 B values (tools/ubench/mfma4x4_rowsum.hip) — 8 two-pass MFMAs per
 //     tile replace 16 v_pk_add_f32 + their moves, and the normaliser sums exactly the fp16 probabilities the O^T MFMAs use.
@@ -305,6 +102,7 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 //     per-lane SOURCE address, both are XOR involutions of the 16-byte chunk index): no staging registers, no ds_write, and
 //     the copy is issued after the tile's last fragment read so that hipcc's conservative vmcnt(0) in front of LDS reads
 //     never waits on a copy in flight.
+// ATTN_X_* : timing experiments (wrong results), tools/build_variant.sh with SRC=attn; record in profiles/r04/attention_v2.txt
 #ifndef ATTN_WAVES
 #define ATTN_WAVES 3
 #endif
@@ -400,10 +198,17 @@ __global__ void __launch_bounds__(ATHREADS, ATTN_WAVES) k_attn_spatial(AttnParam
         // all eight V fragments before the softmax, whose VALU work then covers their latency.
         float16v st[2];
         half8 kf[2][2];
+#ifdef ATTN_X_NOLDS
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { kf[g][ks] = qf[ks]; asm volatile("" : "+v"(kf[g][ks])); }
+#else
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) kf[g][ks] = *(const half8*)(&Ks[cur][k_off(g * 32 + lq, ks * 2 + h)]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // The QK^T MFMAs issue at raised priority: VALU arbitration between the waves of a SIMD is by priority, then
         // age, and at equal priority the other waves' softmax VALU starves this wave's matrix issue (+5 %).
@@ -416,10 +221,17 @@ __global__ void __launch_bounds__(ATHREADS, ATTN_WAVES) k_attn_spatial(AttnParam
 #pragma unroll
             for (int g = 0; g < 2; ++g) st[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[g][ks], qf[ks], st[g], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef ATTN_X_NOLDS
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { kf[g][ks] = qf[ks + 2]; asm volatile("" : "+v"(kf[g][ks])); }
+#else
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) kf[g][ks] = *(const half8*)(&Ks[cur][k_off(g * 32 + lq, (ks + 2) * 2 + h)]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -433,7 +245,11 @@ __global__ void __launch_bounds__(ATHREADS, ATTN_WAVES) k_attn_spatial(AttnParam
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
+#ifdef ATTN_X_NOLDS
+                for (int dt = 0; dt < 2; ++dt) { vf[g][s][dt] = qf[dt + s]; asm volatile("" : "+v"(vf[g][s][dt])); }
+#else
                 for (int dt = 0; dt < 2; ++dt) vf[g][s][dt] = v_frag_tr(Vs[cur], g * 32 + s * 16 + 4 * h, dt * 32, lane);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #ifndef ATTN_X_NODMA
         if (t + 1 < ntiles) dma_tile((t + 1) * BKV, cur ^ 1);
@@ -521,7 +337,9 @@ __global__ void __launch_bounds__(ATHREADS, ATTN_WAVES) k_attn_spatial(AttnParam
 #endif
             }
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's K / V have landed
+#ifndef ATTN_X_NOBAR
         __syncthreads();
+#endif
     };
     dma_tile(0, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -647,13 +465,7 @@ extern "C" int syn3r_attention_f16(const void* q, const void* k, const void* v, 
     p.o = (__half*)out; p.ldo = ldo; p.S = S; p.nseq = nseq; p.heads = heads;
     long long blocks = (long long)nseq * heads * ((S + BQ - 1) / BQ);
     SYN3R_REQUIRE(blocks < (1ll << 31), "attention: grid too large");
-    static int v1 = -1;
-    if (v1 < 0) { const char* e = getenv("SYN3R_ATTN_V1"); v1 = e && atoi(e) ? 1 : 0; }
-    if (v1) {
-        SYN3R_LAUNCH(k_attn_spatial_v1, dim3((unsigned)blocks), dim3(ATHREADS), 0, (hipStream_t)stream, p);
-    } else {
-        SYN3R_LAUNCH(k_attn_spatial, dim3((unsigned)blocks), dim3(ATHREADS), 0, (hipStream_t)stream, p);
-    }
+    SYN3R_LAUNCH(k_attn_spatial, dim3((unsigned)blocks), dim3(ATHREADS), 0, (hipStream_t)stream, p);
     SYN3R_LAUNCH_CHECK("attention launch");
     return SYN3R_OK;
 }
