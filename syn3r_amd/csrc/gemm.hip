@@ -1565,6 +1565,7 @@ int launch_z(const GemmParams& p, hipStream_t stream) {
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gemm_z<false, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, Z_LDS);
         if (e == hipSuccess && MODE == MODE_DENSE) e = hipFuncSetAttribute((const void*)k_gemm_z<true, MODE_DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, Z_LDS);
+        if (e == hipSuccess && MODE == MODE_CONV2D) e = hipFuncSetAttribute((const void*)k_gemm_z<false, MODE_CONV2D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Z_LDS);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_z)");
         attr_set = true;
     }
@@ -1580,6 +1581,9 @@ int launch_z(const GemmParams& p, hipStream_t stream) {
     }
     if constexpr (MODE == MODE_DENSE) {
         if (p.A2) { SYN3R_LAUNCH_NAMED(name, (k_gemm_z<true, MODE_DENSE>), dim3(blocks), dim3(512), Z_LDS, stream, p_); SYN3R_LAUNCH_CHECK("gemm_z launch"); return SYN3R_OK; }
+    }
+    if constexpr (MODE == MODE_CONV2D) {
+        if (p.ups) { SYN3R_LAUNCH_NAMED(name, (k_gemm_z<false, MODE_CONV2D, true>), dim3(blocks), dim3(512), Z_LDS, stream, p_); SYN3R_LAUNCH_CHECK("gemm_z launch"); return SYN3R_OK; }
     }
     SYN3R_LAUNCH_NAMED(name, (k_gemm_z<false, MODE>), dim3(blocks), dim3(512), Z_LDS, stream, p_);
     SYN3R_LAUNCH_CHECK("gemm_z launch");
@@ -1700,7 +1704,7 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
         }
     }
     // Convolutions on the 256 x 320 tile (round 4, k_gemm_z<MODE>): lean epilogue (no ReLU options, aux only with a residual),
-    // whole 16-byte column chunks, 32-bit byte offsets into the input, no fused upsample, and a grid that fills the chip as the
+    // whole 16-byte column chunks, 32-bit byte offsets into the input, and a grid that fills the chip as the
     // dense rule above asks (M = 4 032 at level 3 gives 64 tiles: +110 % there - those stay on the 160-column tile, 128 blocks).
     // Measured inside the UNet unit, same box (tools/gemm_ab.py SYN3R_CONV_Z 0 1, profiles/r04/conv_z_ab.txt), with the filter
     // taps innermost in K: 3x3 convolutions -4..-12 % (isolated +8..+16 %, 1 165-1 352 TFLOP/s), the temporal convolutions +-2 %
@@ -1713,8 +1717,10 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
         const long long rounds = (tiles + 255) / 256;
         const bool fills = tiles * 10 >= rounds * 256 * 8;
         const long long in_bytes = MODE == MODE_CONV2D ? (long long)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2 : (long long)p.M * p.Cin * 2;
+        static int czu_env = -2;            // SYN3R_CONV_Z_UPS=0: the fused-upsample convolutions stay on the 160-column kernel (tuning)
+        if (czu_env == -2) { const char* e = getenv("SYN3R_CONV_Z_UPS"); czu_env = e ? atoi(e) : 1; }
         const bool lean = !p.relu && !p.relu_mask && (!p.aux || p.residual) && p.geglu_D <= 0 && !p.A2 && !p.a_tiled &&
-                          !(MODE == MODE_CONV2D && p.ups);      // (the fused nearest-2x upsample is not an affine gather: 160-column kernel)
+                          !(p.ups && (p.stride != 1 || p.pad != 1 || (czu_env == 0 && g_dma_bm != -322)));
         const bool ok = lean && p.M % 8 == 0 && p.N % 8 == 0 && p.M >= 8 && p.N >= 8 && in_bytes < (1ll << 32) - (1 << 20) &&
                         (long long)p.N * p.K < (1ll << 31) && p.Cin % BK == 0;
         const bool pays = MODE == MODE_CONV2D && p.N >= 320;

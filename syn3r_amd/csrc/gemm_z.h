@@ -66,8 +66,15 @@ __device__ __forceinline__ void z_wait(half8 (&af)[NAF][TM], half8 (&bf)[RB]) {
 // tools/ubench/lds_dma_rate.hip).  The A pieces then take a PER-LANE source: the im2col gather of resnet.py:274,290 /
 // downsampling.py:116-148 / upsampling.py:172-183 / the frame shift of resnet.py:571-597, one 32-bit byte offset per piece
 // (or the zero page for padding), re-derived when the filter tap changes and advanced by 128 bytes per k-tile inside a tap.
-template <bool TWOSRC, int MODE>
+// UPS (MODE_CONV2D only): the input is read through a nearest-2x upsample (upsampling.py:172-183: F.interpolate(scale 2) then the
+// 3 x 3 convolution; the upsampled image is never written).  Tap (ty, tx) of output pixel (y, x) reads input pixel
+// ((y + ty - 1) >> 1, (x + tx - 1) >> 1): from the pixel of tap (0, 0) that is (ty + 1 - (y & 1)) >> 1 rows and the same in x
+// further - taps 0 and 2 move by 0 / 1 for every pixel, the middle tap by 1 only for EVEN output rows / columns.  So the
+// k-tile offset stays wave-uniform except for two lane-dependent additions, steered by two parity bits per piece that share
+// the validity register (4 x 6 validity bits + 4 x 2 parity bits = 32).
+template <bool TWOSRC, int MODE, bool UPS = false>
 __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
+    static_assert(!UPS || MODE == MODE_CONV2D, "UPS is a conv2d option");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -131,6 +138,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
     unsigned kb = 0;                                           // conv2d: byte offset of the k-tile inside a weight row
     int tap_off = 0;                                           // conv2d: wave-uniform byte offset of k-tile (chunk, tap) from cv_base
     unsigned tap_mask = 0;                                     // conv2d: the two validity bits of the current tap (piece 0's position)
+    unsigned add_y = 0, add_x = 0;                             // UPS: what the middle tap adds for even output rows / columns (wave-uniform)
     const int cpb = MODE == MODE_DENSE ? 1 : p.Cin / BK;       // k-tiles per filter tap
     // m / d for m < 2^24 (launch_dma checks M) by one float multiply and a correction step
     auto udiv = [](unsigned m, unsigned d, float rcp, unsigned& rem) -> unsigned {
@@ -156,13 +164,25 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
                 m = m < (unsigned)p.M ? m : (unsigned)p.M - 1u;
                 unsigned r, x;
                 const unsigned n = udiv(m, d_hw, r_hw, r), y = udiv(r, d_w, r_w, x);
-                const int y0 = (int)y * p.stride - p.pad, x0 = (int)x * p.stride - p.pad;       // input pixel of tap (0, 0)
-                cv_base[i] = (unsigned)(((int)(n * (unsigned)p.Hi) + y0) * p.Wi + x0) * (unsigned)p.Cin * 2u + lanechunk;
                 unsigned f = 0;
+                if constexpr (UPS) {
+                    const int yu = (int)y - 1, xu = (int)x - 1;          // tap (0, 0) on the upsampled grid (stride 1, pad 1)
+                    const int y0 = yu >> 1, x0 = xu >> 1;                // its input pixel (-1 for the padding row / column)
+                    cv_base[i] = (unsigned)(((int)(n * (unsigned)p.Hi) + y0) * p.Wi + x0) * (unsigned)p.Cin * 2u + lanechunk;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    f |= (unsigned)(y0 + t >= 0 && y0 + t < p.Hi) << t;
-                    f |= (unsigned)(x0 + t >= 0 && x0 + t < p.Wi) << (3 + t);
+                    for (int t = 0; t < 3; ++t) {
+                        f |= (unsigned)(yu + t >= 0 && yu + t < 2 * p.Hi) << t;
+                        f |= (unsigned)(xu + t >= 0 && xu + t < 2 * p.Wi) << (3 + t);
+                    }
+                    cv_flags |= ((y & 1u) << (24 + 2 * i)) | ((x & 1u) << (25 + 2 * i));
+                } else {
+                    const int y0 = (int)y * p.stride - p.pad, x0 = (int)x * p.stride - p.pad;   // input pixel of tap (0, 0)
+                    cv_base[i] = (unsigned)(((int)(n * (unsigned)p.Hi) + y0) * p.Wi + x0) * (unsigned)p.Cin * 2u + lanechunk;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        f |= (unsigned)(y0 + t >= 0 && y0 + t < p.Hi) << t;
+                        f |= (unsigned)(x0 + t >= 0 && x0 + t < p.Wi) << (3 + t);
+                    }
                 }
                 cv_flags |= f << (6 * i);
             }
@@ -226,7 +246,13 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
         }
         if constexpr (MODE == MODE_CONV2D) {                   // k-tile (c_chunk, c_tap), taps innermost; ob[] stay the row offsets
             const int ty = c_tap / 3, tx = c_tap - 3 * ty;
-            tap_off = ((ty * p.Wi + tx) * p.Cin + c_chunk * BK) * 2;
+            if constexpr (UPS) {
+                tap_off = (((ty == 2 ? p.Wi : 0) + (tx == 2 ? 1 : 0)) * p.Cin + c_chunk * BK) * 2;
+                add_y = ty == 1 ? (unsigned)(p.Wi * p.Cin * 2) : 0u;
+                add_x = tx == 1 ? (unsigned)(p.Cin * 2) : 0u;
+            } else {
+                tap_off = ((ty * p.Wi + tx) * p.Cin + c_chunk * BK) * 2;
+            }
             tap_mask = (1u << ty) | (8u << tx);
             kb = (unsigned)(c_tap * p.Cin + c_chunk * BK) * 2u;
             if (++c_tap == 9) { c_tap = 0; ++c_chunk; }
@@ -269,7 +295,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
         if constexpr (idx < 4 && MODE == MODE_CONV2D) {
             const unsigned mk = tap_mask << (6 * idx);
             const bool ok = (cv_flags & mk) == mk;
-            const char* src = ok ? (const char*)p.A + (size_t)(cv_base[idx < 4 ? idx : 0] + (unsigned)tap_off) : (const char*)g_zero_page;
+            unsigned o = cv_base[idx < 4 ? idx : 0] + (unsigned)tap_off;
+            if constexpr (UPS) {
+                o += (cv_flags & (1u << (24 + 2 * (idx & 3)))) ? 0u : add_y;
+                o += (cv_flags & (2u << (24 + 2 * (idx & 3)))) ? 0u : add_x;
+            }
+            const char* src = ok ? (const char*)p.A + (size_t)o : (const char*)g_zero_page;
             __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wv * 4 + idx) * 1024), 16, 0, 0);
         } else if constexpr (idx < 4 && MODE != MODE_DENSE) {
             const unsigned o = cv_off[idx < NCV ? idx : 0];

@@ -70,6 +70,33 @@ def test_conv3x3(NB, Hi, Wi, Cin, Cout, stride, ups, gpu):
     close(out, ref)
 
 
+@pytest.mark.parametrize("NB,Hi,Wi,Cin,Cout", [(2, 5, 7, 64, 320), (3, 9, 16, 128, 328), (1, 18, 32, 192, 640)])
+def test_conv3x3_upsample_every_kernel(NB, Hi, Wi, Cin, Cout, gpu, every_contraction_kernel):
+    """upsampling.py:172-183 (nearest 2x, then the 3 x 3 convolution) fused into the gather, through every kernel family:
+    odd and even image sizes (both parities of the output rows / columns at the borders), several images, a residual."""
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(NB * Hi + Cout)
+    x = rnd(g, NB, Hi, Wi, Cin, dev=gpu)
+    w = rnd(g, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, dev=gpu)
+    b = rnd(g, Cout, dev=gpu)
+    res = rnd(g, NB * 4 * Hi * Wi, Cout, dev=gpu)
+    xin = Fn.interpolate(x.permute(0, 3, 1, 2).float(), scale_factor=2.0, mode="nearest")
+    ref = Fn.conv2d(xin, w.float(), b.float(), padding=1).permute(0, 2, 3, 1)
+    wk = w.permute(0, 2, 3, 1).contiguous()
+    outs = {}
+
+    def body(tile):
+        out = ops.conv3x3(x, wk, b, upsample=True)
+        assert out.shape == ref.shape
+        close(out, ref)
+        out_r = ops.conv3x3(x, wk, b, upsample=True, residual=res, s_acc=0.5, s_res=1.0)
+        close(out_r.reshape(-1, Cout), 0.5 * ref.reshape(-1, Cout) + res.float())
+        outs[tile] = out
+    every_contraction_kernel(body)
+    for tile, out in outs.items():                      # same products, same k order inside a 64-channel chunk: tight agreement
+        assert (out.float() - outs[0].float()).abs().max().item() <= 2e-3 * ref.abs().max().item(), tile
+
+
 def test_conv3x3_epilogue(gpu):
     from syn3r_amd.unet import ops
     g = torch.Generator().manual_seed(11)
