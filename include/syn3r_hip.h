@@ -350,6 +350,18 @@ int syn3r_feedforward_fused_f16(const void* x, long long ldx, const void* w1_chu
                                 int M, int C, void* stream);
 
 /*
+ * LayerNorm + FeedForward in that kernel: the `norm3(hidden_states)` -> `ff(...)` pair of BasicTransformerBlock.forward and
+ * TemporalBasicTransformerBlock.forward (attention.py:376-392, 519-530) for C = 320.  x is the UN-normalised activation; the
+ * kernel normalises its resident 128-row x tile with (ln_gamma, ln_beta [320], ln_eps) - fp32 statistics, the arithmetic and
+ * summation order of syn3r_layernorm_f16, so the result equals syn3r_layernorm_f16 followed by syn3r_feedforward_fused_f16
+ * bit for bit - and the normalised activation is never written to memory.  `residual` is typically x itself.
+ */
+int syn3r_feedforward_fused_ln_f16(const void* x, long long ldx, const void* ln_gamma, const void* ln_beta, float ln_eps,
+                                   const void* w1_chunked, const void* b1_chunked, int D, const void* w2, const void* b2,
+                                   void* out, long long ldc, const void* residual, long long ldr, const void* aux,
+                                   long long ldaux, float s_acc, float s_res, float s_aux, int M, int C, void* stream);
+
+/*
  * 3x3 Conv2d on NHWC fp16 (resnet.py:274,290; downsampling.py:116-148 with stride 2;
  * upsampling.py:172-183 with upsample != 0: nearest-2x of the input fused into the gather).
  * pad_lo = 1: padding 1 on every side.  pad_lo = 0: the VAE encoder's Downsample2D(padding=0), which pads

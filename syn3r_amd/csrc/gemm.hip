@@ -1262,6 +1262,9 @@ struct FfnParams {
     const __half* w1;        // [D/64][128][320] packed rows
     const __half* b1;        // [D/64][128] packed
     int D;                   // hidden width (multiple of 64)
+    const __half* ln_g;      // non-null: x is LayerNorm'ed (gamma, beta, eps over the 320 channels) inside the kernel first
+    const __half* ln_b;
+    float ln_eps;
 };
 
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
@@ -1325,6 +1328,58 @@ __global__ void __launch_bounds__(512, 2) k_ffn320(FfnParams q) {
                                              (lds_void_t*)(smem_raw + kt * 16384 + (wv * 2 + i) * 1024), 16, 0, 0);
         }
     issue_next();
+
+    // LayerNorm of the resident x tile (attention.py:430-453: norm3 in front of ff), so that the normalised activation is never
+    // written to / re-read from HBM.  Same arithmetic, same order of additions as k_layernorm<8> (norm.hip): 8 partial sums per
+    // row over the 16-byte chunks c, c + 8, ..., combined by the xor tree 4, 2, 1 - here four threads per row hold two of the
+    // eight each.  The tile is five [128 x 64] k-tile images with the chunk index XOR-swizzled by the row.
+    if (q.ln_g) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int r = tid >> 2, part = tid & 3;
+        half8 xv[5][2];
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                xv[kt][e] = *(const half8*)(smem_raw + kt * 16384 + r * 128 + (((part * 2 + e) ^ (r & 7)) << 4));
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sa += (float)xv[kt][0][i]; sb += (float)xv[kt][1][i]; }
+        sa += __shfl_xor(sa, 2, 64); sb += __shfl_xor(sb, 2, 64);
+        sa += __shfl_xor(sa, 1, 64); sb += __shfl_xor(sb, 1, 64);
+        const float cf = (float)p.N;               // = 320, as a run-time value: the same division k_layernorm compiles to
+        const float mean = (sa + sb) / cf;
+        float qa = 0.f, qb = 0.f;
+        {
+#pragma clang fp contract(off)      // k_layernorm's squares are a packed multiply followed by adds, not an fma: the same bits here
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float da = (float)xv[kt][0][i] - mean, db = (float)xv[kt][1][i] - mean;
+                    const float da2 = da * da, db2 = db * db;
+                    qa += da2; qb += db2;
+                }
+        }
+        qa += __shfl_xor(qa, 2, 64); qb += __shfl_xor(qb, 2, 64);
+        qa += __shfl_xor(qa, 1, 64); qb += __shfl_xor(qb, 1, 64);
+        const float rstd = rsqrtf((qa + qb) / cf + q.ln_eps);
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int cv = kt * 8 + part * 2 + e;
+                const half8 g = *(const half8*)(q.ln_g + cv * 8), b = *(const half8*)(q.ln_b + cv * 8);
+                half8 o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = (_Float16)(((float)xv[kt][e][i] - mean) * rstd * (float)g[i] + (float)b[i]);
+                *(half8*)(smem_raw + kt * 16384 + r * 128 + (((part * 2 + e) ^ (r & 7)) << 4)) = o;
+            }
+        __syncthreads();
+    }
 
     float4v acc[TM][TN];                  // out: 64 rows x 80 columns of this wavefront
 #pragma unroll
@@ -1917,10 +1972,32 @@ extern "C" int syn3r_feedforward_f16(const void* x, long long ldx, const void* w
     return launch<MODE_DENSE>(q, (hipStream_t)stream);
 }
 
+namespace {
+int feedforward_fused(const void* x, long long ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* w1_chunked,
+                      const void* b1_chunked, int D, const void* w2, const void* b2, void* out, long long ldc, const void* residual,
+                      long long ldr, const void* aux, long long ldaux, float s_acc, float s_res, float s_aux, int M, int C, void* stream);
+}
 extern "C" int syn3r_feedforward_fused_f16(const void* x, long long ldx, const void* w1_chunked, const void* b1_chunked,
                                            int D, const void* w2, const void* b2, void* out, long long ldc,
                                            const void* residual, long long ldr, const void* aux, long long ldaux,
                                            float s_acc, float s_res, float s_aux, int M, int C, void* stream) {
+    return feedforward_fused(x, ldx, nullptr, nullptr, 0.f, w1_chunked, b1_chunked, D, w2, b2, out, ldc, residual, ldr, aux, ldaux,
+                             s_acc, s_res, s_aux, M, C, stream);
+}
+extern "C" int syn3r_feedforward_fused_ln_f16(const void* x, long long ldx, const void* ln_gamma, const void* ln_beta, float ln_eps,
+                                              const void* w1_chunked, const void* b1_chunked, int D, const void* w2, const void* b2,
+                                              void* out, long long ldc, const void* residual, long long ldr, const void* aux,
+                                              long long ldaux, float s_acc, float s_res, float s_aux, int M, int C, void* stream) {
+    SYN3R_REQUIRE(ln_gamma && ln_beta, "feedforward_fused_ln_f16: null LayerNorm parameters");
+    SYN3R_REQUIRE(((uintptr_t)ln_gamma | (uintptr_t)ln_beta) % 16 == 0, "feedforward_fused_ln_f16: LayerNorm parameters must be 16-byte aligned");
+    SYN3R_REQUIRE(ln_eps > 0.f, "feedforward_fused_ln_f16: eps must be positive");
+    return feedforward_fused(x, ldx, ln_gamma, ln_beta, ln_eps, w1_chunked, b1_chunked, D, w2, b2, out, ldc, residual, ldr, aux, ldaux,
+                             s_acc, s_res, s_aux, M, C, stream);
+}
+namespace {
+int feedforward_fused(const void* x, long long ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* w1_chunked,
+                      const void* b1_chunked, int D, const void* w2, const void* b2, void* out, long long ldc, const void* residual,
+                      long long ldr, const void* aux, long long ldaux, float s_acc, float s_res, float s_aux, int M, int C, void* stream) {
     SYN3R_REQUIRE(x && w1_chunked && b1_chunked && w2 && out, "feedforward_fused_f16: null operand");
     SYN3R_REQUIRE(C == F_C, "feedforward_fused_f16: the fused kernel is built for C = %d channels (got %d): use syn3r_feedforward_f16", F_C, C);
     SYN3R_REQUIRE(M > 0 && D >= F_HC && D % F_HC == 0, "feedforward_fused_f16: bad sizes M=%d D=%d (D must be a multiple of %d)", M, D, F_HC);
@@ -1930,12 +2007,14 @@ extern "C" int syn3r_feedforward_fused_f16(const void* x, long long ldx, const v
     p.bias = (const __half*)b2; p.residual = (const __half*)residual; p.ldr = ldr; p.aux = (const __half*)aux; p.ldaux = ldaux;
     p.s_acc = s_acc; p.s_res = s_res; p.s_aux = s_aux; p.M = M; p.N = F_C; p.K = D;
     q.w1 = (const __half*)w1_chunked; q.b1 = (const __half*)b1_chunked; q.D = D;
+    q.ln_g = (const __half*)ln_gamma; q.ln_b = (const __half*)ln_beta; q.ln_eps = ln_eps;
     int rc = check_common(p, "feedforward_fused_f16");
     if (rc) return rc;
     SYN3R_REQUIRE(ldx % 8 == 0 && ldx >= C, "feedforward_fused_f16: ldx=%lld must be >= C and a multiple of 8", ldx);
     SYN3R_REQUIRE(((uintptr_t)w1_chunked | (uintptr_t)b1_chunked) % 16 == 0, "feedforward_fused_f16: weights must be 16-byte aligned");
     return launch_ffn320(q, (hipStream_t)stream);
 }
+}  // namespace
 
 extern "C" int syn3r_conv2d3x3_f16(const void* X, const void* W, void* out, long long ldc, const void* bias,
                                    const void* rowvec, long long ldrv, int rows_per_vec, const void* residual,

@@ -398,12 +398,19 @@ class UNetSpatioTemporalConditionModel:
             cache[pre] = out
         return out
 
-    def _ff(self, pre: str, x: torch.Tensor, **epilogue) -> torch.Tensor:
+    def _ff(self, pre: str, x: torch.Tensor, norm: Optional[str] = None, **epilogue) -> torch.Tensor:
+        """FeedForward of block `pre` on x; `norm` = the LayerNorm (parameter prefix) that precedes it in the reference
+        (attention.py:376-392, 519-530): applied inside the fused kernel at C = 320, as its own launch otherwise."""
         D = self.p.shapes[pre + ".net.0.proj.weight"][0] // 2
         cw = self.packed.get(pre + ".net.0.proj.geglu_cw")
-        if cw is not None:               # C = 320: one kernel, no intermediate in HBM
+        if cw is not None:               # C = 320: one kernel, neither the normalised nor the hidden activation in HBM
+            ln = (self.w(norm + ".weight"), self.w(norm + ".bias"), 1e-5) if norm and os.environ.get("SYN3R_FF_LN") != "0" else None
+            if norm and ln is None:
+                x = ops.layernorm(x, self.w(norm + ".weight"), self.w(norm + ".bias"))
             return ops.feedforward_fused(x, cw, self.packed[pre + ".net.0.proj.geglu_cb"], D, self.w(pre + ".net.2.weight"),
-                                         self.w(pre + ".net.2.bias"), **epilogue)
+                                         self.w(pre + ".net.2.bias"), ln=ln, **epilogue)
+        if norm:
+            x = ops.layernorm(x, self.w(norm + ".weight"), self.w(norm + ".bias"))
         wp = self.w(pre + ".net.0.proj.geglu_w")
         if os.environ.get("SYN3R_FF_TILED") == "0":      # tuning: row-major intermediate, two separate calls
             return ops.linear(ops.linear_geglu(x, wp, self.w(pre + ".net.0.proj.geglu_b"), D),
@@ -434,8 +441,7 @@ class UNetSpatioTemporalConditionModel:
         a1 = ops.attention(ops.linear(n1, W(b + ".attn1.qkv")), B * F, HW, heads)
         hs = ops.linear(a1, W(b + ".attn1.to_out.0.weight"), W(b + ".attn1.to_out.0.bias"), residual=hs,
                         rowvec=self._cross_vec(b + ".attn2", ehs, st["ctx_cache"]), rows_per_vec=(B if st["shared_ctx"] else 1) * F * HW)
-        n3 = ops.layernorm(hs, W(b + ".norm3.weight"), W(b + ".norm3.bias"))
-        hs = self._ff(b + ".ff", n3, residual=hs)
+        hs = self._ff(b + ".ff", hs, norm=b + ".norm3", residual=hs)
         # TemporalBasicTransformerBlock (attention.py:478-533) on hs + emb
         t = pre + ".temporal_transformer_blocks.0"
         nin, hmix = ops.layernorm(hs, W(t + ".norm_in.weight"), W(t + ".norm_in.bias"), addvec=emb, rows_per_vec=HW,
@@ -462,10 +468,9 @@ class UNetSpatioTemporalConditionModel:
             rpv, grp = -G, (G * F * HW if G != B else 0)
         tt = ops.linear(a1, W(t + ".attn1.to_out.0.weight"), W(t + ".attn1.to_out.0.bias"), residual=tt,
                         rowvec=self._cross_vec(t + ".attn2", ehs, st["ctx_cache"]), rows_per_vec=rpv, rv_group_rows=grp)
-        n3 = ops.layernorm(tt, W(t + ".norm3.weight"), W(t + ".norm3.bias"))
         a, om = self._blend_scales(pre + ".time_mixer.mix_factor")
-        # alpha*hs + (1-alpha)*(ff + tt)
-        mix = self._ff(t + ".ff", n3, residual=tt, aux=hs, s_acc=om, s_res=om, s_aux=a)
+        # alpha*hs + (1-alpha)*(ff(norm3(tt)) + tt)
+        mix = self._ff(t + ".ff", tt, norm=t + ".norm3", residual=tt, aux=hs, s_acc=om, s_res=om, s_aux=a)
         return ops.linear(mix, W(pre + ".proj_out.weight"), W(pre + ".proj_out.bias"), residual=x)
 
     # ------------------------------------------------------------------ forward

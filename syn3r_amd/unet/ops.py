@@ -143,9 +143,12 @@ FUSED_FF_CHANNELS = 320      # syn3r_feedforward_fused_f16 is built for this wid
 
 def feedforward_fused(x: torch.Tensor, w1_chunked: torch.Tensor, b1_chunked: torch.Tensor, D: int, w2: torch.Tensor,
                       b2: Optional[torch.Tensor] = None, *, residual: Optional[torch.Tensor] = None,
-                      aux: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0, s_aux: float = 1.0) -> torch.Tensor:
+                      aux: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0, s_aux: float = 1.0,
+                      ln: Optional[tuple] = None) -> torch.Tensor:
     """FeedForward.forward (attention.py:608-665) in ONE kernel for C = 320: geglu(x @ W1^T + b1) @ W2^T + b2 with the
-    `linear` epilogue; the hidden activation never leaves the CU (syn3r_feedforward_fused_f16)."""
+    `linear` epilogue; the hidden activation never leaves the CU (syn3r_feedforward_fused_f16).
+    ln = (gamma, beta, eps): x is LayerNorm'ed inside the kernel first (norm3 -> ff, attention.py:376-392; equal bit for bit
+    to `layernorm` followed by this call; syn3r_feedforward_fused_ln_f16)."""
     dev = _chk(w1_chunked, b1_chunked, w2, b2, residual, aux)
     L.require_gpu(x)
     M, K = x.shape
@@ -153,12 +156,20 @@ def feedforward_fused(x: torch.Tensor, w1_chunked: torch.Tensor, b1_chunked: tor
     if x.stride(1) != 1 or K != N or w2.shape[1] != D or tuple(w1_chunked.shape) != (2 * D, K):
         raise ValueError(f"feedforward_fused: x {tuple(x.shape)} / w1 {tuple(w1_chunked.shape)} / w2 {tuple(w2.shape)} / D={D} mismatch")
     out = torch.empty((M, N), dtype=H, device=dev)
-    rc = L.load().syn3r_feedforward_fused_f16(
-        x.data_ptr(), x.stride(0), L.ptr(w1_chunked), L.ptr(b1_chunked), D, L.ptr(w2), L.ptr(b2), L.ptr(out), N,
-        residual.data_ptr() if residual is not None else None, residual.stride(0) if residual is not None else 0,
-        aux.data_ptr() if aux is not None else None, aux.stride(0) if aux is not None else 0,
-        float(s_acc), float(s_res), float(s_aux), M, K, L.stream_ptr(dev))
-    L.check(rc, "syn3r_feedforward_fused_f16")
+    tail = (L.ptr(w1_chunked), L.ptr(b1_chunked), D, L.ptr(w2), L.ptr(b2), L.ptr(out), N,
+            residual.data_ptr() if residual is not None else None, residual.stride(0) if residual is not None else 0,
+            aux.data_ptr() if aux is not None else None, aux.stride(0) if aux is not None else 0,
+            float(s_acc), float(s_res), float(s_aux), M, K, L.stream_ptr(dev))
+    if ln is not None:
+        gamma, beta, eps = ln
+        _chk(gamma, beta)
+        if gamma.numel() != K or beta.numel() != K:
+            raise ValueError(f"feedforward_fused: LayerNorm parameters of {gamma.numel()} / {beta.numel()} channels for C = {K}")
+        rc = L.load().syn3r_feedforward_fused_ln_f16(x.data_ptr(), x.stride(0), L.ptr(gamma), L.ptr(beta), float(eps), *tail)
+        L.check(rc, "syn3r_feedforward_fused_ln_f16")
+    else:
+        rc = L.load().syn3r_feedforward_fused_f16(x.data_ptr(), x.stride(0), *tail)
+        L.check(rc, "syn3r_feedforward_fused_f16")
     _count("gemm", 2.0 * M * 2 * D * K + 2.0 * M * N * D)
     return out
 

@@ -377,6 +377,35 @@ def test_feedforward_tiled_intermediate(M, C, D, gpu):
 
 
 @pytest.mark.parametrize("M,D", [(128, 64), (700, 1280), (4097, 1280), (129, 192)])
+def test_feedforward_fused_layernorm_c320(M, D, gpu):
+    """norm3 -> ff in one kernel (syn3r_feedforward_fused_ln_f16): bit for bit the LayerNorm launch followed by the fused
+    feed-forward (same statistics, same order of additions), and the fp32 restatement of attention.py:376-392 within the
+    feed-forward's tolerance; ragged M, rows with a large offset (the two-pass variance), strided x, the full epilogue."""
+    from syn3r_amd.unet import ops
+    C = 320
+    g = torch.Generator().manual_seed(M * 3 + D)
+    wide = rnd(g, M, 2 * C, dev=gpu)
+    x = wide[:, C // 2:C // 2 + C]                                      # row stride 640: a column slice
+    x[::7] += 6.0                                                        # some rows far from zero mean
+    ga, be = (1.0 + 0.2 * rnd(g, C, dev=gpu).float()).half(), (0.1 * rnd(g, C, dev=gpu).float()).half()
+    w1, b1 = rnd(g, 2 * D, C, scale=C ** -0.5, dev=gpu), rnd(g, 2 * D, dev=gpu)
+    w2, b2 = rnd(g, C, D, scale=D ** -0.5, dev=gpu), rnd(g, C, dev=gpu)
+    aux = rnd(g, M, C, dev=gpu)
+    wc, bc, _ = ops.pack_geglu_chunked(w1, b1)
+    n = ops.layernorm(x.contiguous(), ga, be)
+    for kw in ({}, {"residual": x.contiguous(), "aux": aux, "s_acc": 0.4, "s_res": 0.6, "s_aux": 0.25}):
+        two = ops.feedforward_fused(n, wc, bc, D, w2, b2, **kw)
+        one = ops.feedforward_fused(x, wc, bc, D, w2, b2, ln=(ga, be, 1e-5), **kw)
+        assert torch.equal(one, two), (one.float() - two.float()).abs().max().item()
+    nf = Fn.layer_norm(x.float(), (C,), ga.float(), be.float(), 1e-5).half().float()
+    y = (nf @ w1.float().T + b1.float()).half().float()
+    h = (y[:, :D] * Fn.gelu(y[:, D:])).half().float()
+    close(ops.feedforward_fused(x, wc, bc, D, w2, b2, ln=(ga, be, 1e-5)), h @ w2.float().T + b2.float(), tol=6e-3)
+    with pytest.raises(ValueError):
+        ops.feedforward_fused(x, wc, bc, D, w2, b2, ln=(ga[:64], be[:64], 1e-5))
+
+
+@pytest.mark.parametrize("M,D", [(128, 64), (700, 1280), (4097, 1280), (129, 192)])
 def test_feedforward_fused_c320(M, D, gpu):
     """`feedforward_fused` (syn3r_feedforward_fused_f16: x -> net.0 -> GEGLU -> net.2 in one kernel, C = 320) against the
     two-kernel path (same arithmetic: fp32 accumulation in k order, projection and gate rounded to fp16) and the fp32
