@@ -527,6 +527,34 @@ int syn3r_pcd_statistical_outlier(const double* points, int n, int nb_neighbors,
 int syn3r_flow_cycle_mask(const float* flow_fw, const float* flow_bw, int n, int H, int W, float thresh, float* mask, float* dist,
                           void* stream);
 
+/*
+ * The whole UNet forward as ONE call: `self.unet(latent_model_input, t, encoder_hidden_states=image_embeddings,
+ * added_time_ids=added_time_ids, return_dict=False)[0]` (model/SVD_2pass_prob_uncertain_post.py:763,786;
+ * UNetSpatioTemporalConditionModel.forward, diffusers/models/unets/unet_spatio_temporal_condition.py:356-489) for hosts that
+ * are not Python.  The launch sequence is the one syn3r_amd/unet/model.py issues (same operators, same order, same results).
+ *
+ * syn3r_unet_create: reads `<weights_dir>/config.json` and `<weights_dir>/diffusion_pytorch_model[.<variant>].safetensors`
+ *   (the `unet/` directory of a diffusers checkpoint: what `from_pretrained(<local dir>, torch_dtype=float16, variant="fp16")`
+ *   reads at model/diffusionGS.py:1089; variant may be NULL; F16 / F32 / BF16 tensors, kept in fp16), repacks the weights for the
+ *   kernels and uploads them to the CURRENT device.  One handle per device; a handle is not re-entrant (one forward at a time).
+ * syn3r_unet_workspace_bytes: exact scratch need of one forward of that shape (0 on a bad shape).
+ * syn3r_unet_forward, all pointers device memory on the handle's device:
+ *   sample [B, F, in_channels, h, w] fp16; timestep (the scheduler's continuous timestep); encoder_hidden_states
+ *   [ehs_rows, cross_attention_dim] fp16 with ehs_rows = B, or 1 for one context shared by the batch; added_time_ids
+ *   [B, 3] fp32 (fps, motion bucket, noise augmentation); out [B, F, out_channels, h, w] fp16.  ctx_group: 0 = the batch is
+ *   one call of the reference; G > 0 = B / G independent calls of batch G stacked (the two passes of a denoising step: the
+ *   reference's batch-interleaved temporal context is applied per group).  h, w multiples of 8, F <= 32.
+ *   workspace: syn3r_unet_workspace_bytes(...) bytes, 256-byte aligned.  Every launch goes to `stream`; nothing synchronises
+ *   except the first forward of a new (F, B), which allocates the per-block frame-position embeddings (hipMalloc).
+ */
+typedef struct syn3r_unet syn3r_unet;
+int syn3r_unet_create(const char* weights_dir, const char* variant, syn3r_unet** out);
+int syn3r_unet_destroy(syn3r_unet* unet);
+size_t syn3r_unet_workspace_bytes(syn3r_unet* unet, int B, int F, int h, int w, int ehs_rows);
+int syn3r_unet_forward(syn3r_unet* unet, const void* sample, double timestep, const void* encoder_hidden_states, int ehs_rows,
+                       const float* added_time_ids, void* out, int B, int F, int h, int w, int ctx_group, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
