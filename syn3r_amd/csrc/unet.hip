@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
+#include <mutex>
 #include <vector>
 
 using namespace syn3r;
@@ -39,7 +41,9 @@ __global__ void k_timestep_embedding(const float* __restrict__ t_dev, double t_h
     if (i >= n * half) return;
     const int r = i / half, c = i - r * half;
     const float t = t_dev ? t_dev[r] : (float)t_host + t_step * (float)r;
-    const float e = expf(-9.210340371976184f * (float)c / (float)half);
+    // (`tensor / python_int` on the device is a multiplication by the fp32 reciprocal in torch: the same here, or the two hosts
+    // differ in the last bit of the exponent whenever `half` is not a power of two)
+    const float e = expf((-9.210340371976184f * (float)c) * (1.0f / (float)half));
     const float a = t * e;
     out[(size_t)r * dim + c] = __float2half(cosf(a));
     out[(size_t)r * dim + half + c] = __float2half(sinf(a));
@@ -251,6 +255,14 @@ struct syn3r_unet {
 };
 
 namespace {
+
+// Live handles: every entry point checks its handle against this set (a stale or fabricated pointer is an error, not a crash).
+std::mutex g_unet_mu;
+std::unordered_set<const syn3r_unet*>& unet_registry() { static auto* s = new std::unordered_set<const syn3r_unet*>; return *s; }
+bool unet_live(const syn3r_unet* m) {
+    std::lock_guard<std::mutex> lk(g_unet_mu);
+    return m && unet_registry().count(m);
+}
 
 struct HostPack { std::string name; long long rows, cols; std::vector<u16> d; };
 
@@ -491,11 +503,19 @@ extern "C" int syn3r_unet_create(const char* weights_dir, const char* variant, s
     const char* e = getenv("SYN3R_FF_LN");
     m->ff_ln = !(e && !strcmp(e, "0"));
     *out = m.release();
+    {
+        std::lock_guard<std::mutex> lk(g_unet_mu);
+        unet_registry().insert(*out);
+    }
     return SYN3R_OK;
 }
 
 extern "C" int syn3r_unet_destroy(syn3r_unet* m) {
     if (!m) return SYN3R_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_unet_mu);
+        if (!unet_registry().erase(m)) { set_error("unet_destroy: not a live handle"); return SYN3R_E_INVALID; }
+    }
     for (auto& kv : m->pos_cache) hipFree(kv.second);
     if (m->blob) hipFree(m->blob);
     delete m;
@@ -957,7 +977,7 @@ struct Run {
 };
 
 int check_shape(const syn3r_unet* m, int B, int F, int h, int w, int ehs_rows, int ctx_group) {
-    SYN3R_REQUIRE(m, "unet: null handle");
+    SYN3R_REQUIRE(unet_live(m), "unet: not a live handle (syn3r_unet_create)");
     SYN3R_REQUIRE(B > 0 && B <= 64 && F > 0 && F <= 32 && SYN3R_SIDE_OK(h) && SYN3R_SIDE_OK(w), "unet: bad sizes B=%d F=%d h=%d w=%d (F <= 32)", B, F, h, w);
     SYN3R_REQUIRE((long long)B * F * h * w <= SYN3R_DIM_MAX, "unet: B*F*h*w = %lld rows is beyond the operators' limit", (long long)B * F * h * w);
     const int down = 1 << (m->boc.size() - 1);

@@ -74,3 +74,56 @@ def test_unet_abi_rejects_bad_arguments(tiny, gpu, tmp_path):
     assert rc != 0 and b"workspace" in lib.syn3r_last_error()
     h2 = C.c_void_p()
     assert lib.syn3r_unet_create(str(tmp_path).encode(), None, C.byref(h2)) != 0 and b"config.json" in lib.syn3r_last_error()
+
+
+def test_unet_abi_full_size_equals_python_host(gpu, tmp_path):
+    """The SVD-XT configuration (1.52 B parameters, seeded weights written as a diffusers `unet/` directory) at the bench's
+    CFG shape [2, 14, 8, 72, 128]: the C-ABI forward equals the Python host graph bit for bit; the workspace query is what
+    the run needs (a smaller workspace is refused, not overrun)."""
+    import json
+    import time
+    from safetensors.torch import save_file
+    from syn3r_amd import _lib
+    from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel
+    model = UNetSpatioTemporalConditionModel().init_random(gpu, seed=3)
+    d = tmp_path / "unet"
+    d.mkdir()
+    cfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in model.config.items()}
+    (d / "config.json").write_text(json.dumps(dict(cfg, _class_name="UNetSpatioTemporalConditionModel")))
+    save_file({k: v.detach().to("cpu", torch.float16).contiguous() for k, v in model.p.t.items()}, str(d / "diffusion_pytorch_model.fp16.safetensors"))
+    lib = _lib.load()
+    handle = C.c_void_p()
+    t0 = time.time()
+    _lib.check(lib.syn3r_unet_create(str(d).encode(), b"fp16", C.byref(handle)), "syn3r_unet_create")
+    t_create = time.time() - t0
+    try:
+        B, F, h, w = 2, 14, 72, 128
+        g = torch.Generator().manual_seed(7)
+        sample = torch.randn(B, F, 8, h, w, generator=g).to(H).to(gpu)
+        ehs = torch.randn(B, 1, 1024, generator=g).to(H).to(gpu)
+        added = torch.tensor([[6.0, 127.0, 0.02]] * B).to(H).to(gpu)
+        ref = model(sample, 1.6377, ehs, added)[0]
+        out = _abi_forward(lib, handle, sample, 1.6377, ehs, added)
+        assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
+        need = lib.syn3r_unet_workspace_bytes(handle, B, F, h, w, B)
+        ws = torch.empty(need, dtype=torch.uint8, device=gpu)
+        o2 = torch.empty_like(out)
+        ids = added.float().contiguous()
+        e2 = ehs.reshape(B, -1).contiguous()
+        args = (handle, sample.data_ptr(), 1.6377, e2.data_ptr(), B, ids.data_ptr(), o2.data_ptr(), B, F, h, w, 0)
+        rc = lib.syn3r_unet_forward(*args, ws.data_ptr(), need // 2, _lib.stream_ptr(gpu))
+        assert rc != 0 and b"workspace" in lib.syn3r_last_error()
+        # timing: the C-ABI call against the Python host (eager), same kernels
+        def timed(f, n=3):
+            f(); torch.cuda.synchronize()
+            t = time.time()
+            for _ in range(n):
+                f()
+            torch.cuda.synchronize()
+            return (time.time() - t) / n * 1e3
+        ms_abi = timed(lambda: _lib.check(lib.syn3r_unet_forward(*args, ws.data_ptr(), need, _lib.stream_ptr(gpu)), "forward"))
+        ms_py = timed(lambda: model(sample, 1.6377, ehs, added))
+        print(f"\n[unet abi] create {t_create:.1f} s, workspace {need / 2**30:.2f} GiB, forward {ms_abi:.1f} ms (C-ABI) vs {ms_py:.1f} ms (Python host, eager)")
+        assert torch.equal(o2, ref)
+    finally:
+        lib.syn3r_unet_destroy(handle)
