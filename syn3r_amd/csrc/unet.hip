@@ -473,14 +473,20 @@ extern "C" int syn3r_unet_create(const char* weights_dir, const char* variant, s
     if (rc) return rc;
     std::unique_ptr<StFile> fp;
     std::string err;
+    auto absent = [](const std::string& e) { return e.compare(0, 11, "cannot open") == 0; };
     if (variant && *variant) {
         fp.reset(new StFile);
-        if (!fp->open_(dir + "/diffusion_pytorch_model." + variant + ".safetensors", err)) fp.reset();
+        if (!fp->open_(dir + "/diffusion_pytorch_model." + variant + ".safetensors", err)) {
+            if (!absent(err)) return fail("unet_create: %s", err);               // the file is there and is not a checkpoint
+            fp.reset();
+        }
     }
     if (!fp) {
         fp.reset(new StFile);
-        if (!fp->open_(dir + "/diffusion_pytorch_model.safetensors", err))
+        if (!fp->open_(dir + "/diffusion_pytorch_model.safetensors", err)) {
+            if (!absent(err)) return fail("unet_create: %s", err);
             return fail("unet_create: no safetensors weights under %s (diffusion_pytorch_model[.variant].safetensors)", dir);
+        }
     }
     const StFile& f = *fp;
     std::vector<HostPack> packs;
