@@ -9,6 +9,8 @@
 //   mode 4: stores only
 //   mode 5: as 3 with a COUNTED wait (vmcnt(2): the k-tile's two stores, issued behind its loads, may stay in flight)
 //   mode 6: as 1, and the burst is drained (vmcnt(0)) before the next tile's first request
+//   mode 7: as 1, and during the tile's last PF k-tiles every wavefront touches one line per lane of the NEXT tile's A rows
+//           (k-tiles 0 .. PFK-1: plain loads into a dummy register) so that the requests behind the store burst are served by the L2
 // A operands: rows of a [M, K] fp16 matrix read once per tile column band (4 tiles share a row block); W: a small resident panel.
 // build: hipcc --offload-arch=gfx950 -O3 tools/ubench/store_load_mix.hip -o tools/ubench/store_load_mix
 #include <hip/hip_runtime.h>
@@ -24,6 +26,9 @@ __device__ __forceinline__ void spin10ns(int n) {
     while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(1);
 }
 
+#ifndef PFK
+#define PFK 4
+#endif
 template <int MODE>
 __global__ void __launch_bounds__(512, 2) k(const char* A, const char* W, char* out, long long lda, long long ldo, int tiles_n, int ntiles, int nk, int spin,
                                             unsigned long long* cyc) {
@@ -35,6 +40,7 @@ __global__ void __launch_bounds__(512, 2) k(const char* A, const char* W, char* 
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     int pending = 0;                                  // mode 3: stores of the previous tile still to issue
     char* pbase = out;
+    unsigned sink_acc = 0;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int tm = t / tiles_n, tn = t % tiles_n;
         const char* arow = A + (size_t)tm * 256 * lda;
@@ -56,6 +62,20 @@ __global__ void __launch_bounds__(512, 2) k(const char* A, const char* W, char* 
                     const int q = lane + it * 64, row = q / 20, ch = q % 20;
                     *(u32x4*)(pbase + (size_t)((wv >> 1) * 64 + row) * ldo + (wv & 1) * 320 + ch * 16) = v;
                     --pending;
+                }
+            }
+            if (MODE == 7 && kt >= nk - 2 && t + (int)gridDim.x < ntiles) {
+                // next tile's A rows: 256 rows x PFK k-tiles x 128 B = 256 * PFK lines; 16 wave-loads of 64 lines per k-tile here -> 2 k-tiles cover PFK = 8
+                const int tn2 = t + (int)gridDim.x;
+                const char* arow2 = A + (size_t)(tn2 / tiles_n) * 256 * lda;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int line = ((kt - (nk - 2)) * 16 + wv * 2 + i) * 64 + lane;         // 0 .. 2047
+                    if (line < 256 * PFK) {
+                        unsigned x;
+                        asm volatile("global_load_dword %0, %1, off" : "=v"(x) : "v"(arow2 + (size_t)(line % 256) * lda + (size_t)(line / 256) * 128));
+                        sink_acc += 0;      // (the value is never consumed: the request only has to reach the L2)
+                    }
                 }
             }
             spin10ns(spin);
@@ -115,6 +135,7 @@ int main() {
             run<3>("stores 2 per k-tile inside the next tile's k-loop", A, W, out, lda, ldo, tiles_m, tiles_n, nk, spin, cyc);
             run<5>("  ... with a counted wait (the 2 stores stay in flight)", A, W, out, lda, ldo, tiles_m, tiles_n, nk, spin, cyc);
             run<6>("stores burst drained before the next tile's loads", A, W, out, lda, ldo, tiles_m, tiles_n, nk, spin, cyc);
+            run<7>("today + next tile's first A k-tiles touched into the L2 ahead", A, W, out, lda, ldo, tiles_m, tiles_n, nk, spin, cyc);
         }
     }
     return 0;
