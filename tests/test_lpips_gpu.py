@@ -92,3 +92,33 @@ def test_trainer_uses_lpips_when_switched_on(gpu, tmp_path):
     assert np.isfinite(ev["lpips"]) and ev["lpips"] > 0
     tr.lpips = None
     assert np.isnan(tr.evaluate([cam])["lpips"])
+
+
+@pytest.mark.gpu
+def test_lpips_layer_backward_saturates_instead_of_overflowing(gpu):
+    """the layer backward multiplies by 1 / |a| and by the loss scale (~2.6e5 at relu5_3): a pixel whose feature norm
+    is tiny but positive used to overflow the fp16 gradient to inf, which the backward convolutions then spread into the image
+    gradient and Adam.  The kernel clamps to the fp16 range: every gradient is finite, the ordinary pixels are untouched."""
+    from syn3r_amd import _lib as L
+    lib = L.load()
+    P, C = 256, 512
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(P, C, generator=g).to(torch.float16).to(gpu)
+    b = torch.rand(P, C, generator=g).to(torch.float16).to(gpu)
+    a[::16] = 0.0
+    a[::16, 3] = 6e-5                                   # tiny but positive norm: 1 / |a| ~ 1.7e4
+    a[8::16] = 0.0                                      # an all-zero pixel (norm 0 + 1e-10)
+    w = torch.rand(C, generator=g).to(gpu)
+    grad = torch.empty(P, C, dtype=torch.float16, device=gpu)
+    L.check(lib.syn3r_lpips_layer_bwd_f16(L.ptr(a), L.ptr(b), L.ptr(w), P, C, 2.6e5, 0, L.ptr(grad), L.stream_ptr(gpu)), "lpips_layer_bwd")
+    torch.cuda.synchronize()
+    gf = grad.float()
+    assert bool(torch.isfinite(gf).all())
+    assert float(gf.abs().max()) <= 65504.0
+    ordinary = gf[1::16].clone()
+    assert float(ordinary.abs().max()) > 0.0
+    # the same call at a scale no fp16 gradient survives: saturated at the largest finite fp16, never inf / NaN
+    L.check(lib.syn3r_lpips_layer_bwd_f16(L.ptr(a), L.ptr(b), L.ptr(w), P, C, 1.0e12, 0, L.ptr(grad), L.stream_ptr(gpu)), "lpips_layer_bwd")
+    torch.cuda.synchronize()
+    gf = grad.float()
+    assert bool(torch.isfinite(gf).all()) and float(gf.abs().max()) == 65504.0
