@@ -94,6 +94,10 @@ class StableVideoDiffusionPipeline:
         self._guidance_scale = None
         import os
         self.use_graphs = os.environ.get("SYN3R_UNET_GRAPH", "0") == "1"     # replay captured UNet launch sequences (hipGraph)
+        # the two passes of a Replace step on TWO HIP streams (see _streamed_replace): SYN3R_TWO_STREAMS=0 turns it off
+        self.two_streams = os.environ.get("SYN3R_TWO_STREAMS", "1") != "0" and self.device.type == "cuda"
+        self._side = None               # the two side streams, created on first use
+        self._streams_warm = set()      # shapes whose shared caches (frame-position embeddings, scratch buffers) exist
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype: torch.dtype = torch.float16, variant: Optional[str] = "fp16",
@@ -255,6 +259,50 @@ class StableVideoDiffusionPipeline:
             out.append(sch.step_interp_prob_uncertain(pred, t, lat[k], cond, mask, lam, step_i=i).prev_sample)
         return out
 
+    # ---- the two passes of a Replace step on two HIP streams ---------------------------------------------------------
+    # A contraction launch of T tiles takes ceil(T / 256) rounds of the persistent kernels: at F = 25 the stacked step loses
+    # 7.9 % of its contraction time to the last, partly empty round (1 800 tiles = 7.03 rounds take 8).
+    # Two launch sequences that do not depend on each other fill those rounds with each other's blocks when they run on two
+    # streams.  Measured at F = 25, same box, ms per (step, pass) unit (tools/two_stream_units.py): Replace, the two passes
+    # (B = 2 each) on two streams 172.8 against 177.4 stacked into one B = 4 sequence and 179.2 pass after pass; Post gains
+    # nothing from it (guidance tiles beside the CFG forward 296.0 against 294.7 stacked; the passes on two streams 299.2): it
+    # keeps the stacked order.  Same kernels on the same operands as the pass-after-pass order: bit-identical to it.  The
+    # first call of a shape runs stacked on one stream (it creates what both sequences read: frame-position embeddings,
+    # folded contexts, scratch buffers).
+    def _fork(self, key):
+        """(side stream 1, side stream 2), both waiting for the current stream - or None for the first call of `key`."""
+        if not self.two_streams:
+            return None
+        if key not in self._streams_warm:
+            self._streams_warm.add(key)
+            return None
+        if self._side is None:
+            self._side = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+        cur = torch.cuda.current_stream(self.device)
+        for s_ in self._side:
+            s_.wait_stream(cur)
+        return self._side
+
+    def _join(self, streams):
+        cur = torch.cuda.current_stream(self.device)
+        for s_ in streams:
+            cur.wait_stream(s_)
+
+    def _streamed_replace(self, i, t, lat, img4, ehs4, added4, ops2, do_cfg):
+        """The two passes of a Replace step (SVD_2pass_prob_uncertain.py:661-742), each on its own stream."""
+        g = 2 if do_cfg else 1
+        streams = self._fork(("replace", tuple(lat[0].shape)))
+        if streams is None:
+            return self._merged_replace(i, t, lat, img4, ehs4, added4, ops2, do_cfg)
+        out = []
+        for k in range(2):
+            cond, mask, lam, _ = ops2[k]
+            with torch.cuda.stream(streams[k]):
+                out.append(self._pass_replace(i, t, lat[k], img4[k * g:(k + 1) * g], ehs4[k * g:(k + 1) * g], added4[k * g:(k + 1) * g],
+                                              cond, mask, lam, do_cfg))
+        self._join(streams)
+        return out
+
     def _merged_post(self, i, t, lat, img4, ehs4, added4, ops2, do_cfg, tile_ctx):
         sch = self.scheduler
         g = 2 if do_cfg else 1
@@ -325,7 +373,7 @@ class StableVideoDiffusionPipeline:
             if merged:
                 lat = (latents, latents.flip(dims=[1]))
                 fw, bw = (self._merged_post(i, t, lat, img4, ehs4, added4, ops2, do_cfg, tile_ctx) if post else
-                          self._merged_replace(i, t, lat, img4, ehs4, added4, ops2, do_cfg))
+                          self._streamed_replace(i, t, lat, img4, ehs4, added4, ops2, do_cfg))
                 latents = weight_fw * fw + (1 - weight_fw) * bw.flip(dims=[1])      # :828 / :736
             else:
                 fw = step(i, t, latents, image_latent_start, emb_start, added_time_ids, temp_cond_latents, mask, lambda_ts,

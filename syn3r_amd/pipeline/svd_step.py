@@ -105,7 +105,7 @@ class SvdStepBench:
         if variant == "post":
             fw, bw = p._merged_post(i, t, lat, st["img4"], st["ehs4"], st["added4"], st["ops2"], True, st["tile_ctx"])
         else:
-            fw, bw = p._merged_replace(i, t, lat, st["img4"], st["ehs4"], st["added4"], st["ops2"], True)
+            fw, bw = p._streamed_replace(i, t, lat, st["img4"], st["ehs4"], st["added4"], st["ops2"], True)
         return st["weight_fw"] * fw + (1 - st["weight_fw"]) * bw.flip(dims=[1])
 
     def count_flops(self) -> dict:

@@ -229,3 +229,36 @@ def test_full_size_post_pipeline_matches_reference(gpu, golden_dir):
     assert err.mean() < 1e-3 * scale, (err.mean(), scale)
     assert (err > 1e-2 * scale).mean() < 1e-4, ((err > 1e-2 * scale).mean(), err.max(), scale)
     assert abs(float(np.abs(a).mean()) - float(g["mean_abs"])) < 2e-3 * scale
+
+
+def test_replace_passes_on_two_streams_equal_the_pass_after_pass_order(gpu):
+    """`_streamed_replace`: from the second step of a shape on, the two passes of a Replace step run on two HIP streams (their
+    kernels fill each other's partly empty last rounds).  Same kernels on the same operands as the pass-after-pass order:
+    bit-identical to it; the first call of a shape runs stacked on one stream."""
+    from oracle import unet_weights as UW
+    from syn3r_amd.pipeline.svd_step import SvdStepBench
+    from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel
+    unet = UNetSpatioTemporalConditionModel(**UW.PIPELINE_CONFIG)
+    unet.load_state_dict(UW.make_state_dict(unet.parameter_shapes(), seed=3), gpu)
+    b = SvdStepBench(25, gpu, h=16, w=24, unet=unet)
+    b.step_both("replace")                                   # first call of the shape: stacked, creates the shared caches
+    st = b._both_replace
+    pipe = st["pipe"]
+    assert pipe.two_streams and ("replace", (1, 25, 4, 16, 24)) in pipe._streams_warm
+    i, t = 7, b.sch.timesteps[7]
+    lat = (b.latents, b.latents.flip(dims=[1]))
+    streamed = pipe._streamed_replace(i, t, lat, st["img4"], st["ehs4"], st["added4"], st["ops2"], True)
+    torch.cuda.synchronize()
+    assert pipe._side is not None                            # the side streams were used
+    seq = []
+    for k in range(2):
+        cond, mask, lam, _ = st["ops2"][k]
+        seq.append(pipe._pass_replace(i, t, lat[k], st["img4"][2 * k:2 * k + 2], st["ehs4"][2 * k:2 * k + 2], st["added4"][2 * k:2 * k + 2],
+                                      cond, mask, lam, True))
+    for a, c in zip(streamed, seq):
+        assert torch.equal(a, c)
+    pipe.two_streams = False
+    stacked = pipe._streamed_replace(i, t, lat, st["img4"], st["ehs4"], st["added4"], st["ops2"], True)
+    for a, c in zip(streamed, stacked):                      # the stacked order: the same latents up to fp16 rounding of regrouped tiles
+        scale = float(c.float().abs().max())
+        assert float((a.float() - c.float()).abs().mean()) < 5e-4 * scale
