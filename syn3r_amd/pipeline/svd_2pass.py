@@ -35,6 +35,9 @@ class StableVideoDiffusionPipelineOutput:
     frames: object
 
 
+_SIDE_STREAMS = {}        # device index -> the two side streams of the per-pass UNet calls (see StableVideoDiffusionPipeline._fork)
+
+
 def _append_dims(x, target_dims):
     return x[(...,) + (None,) * (target_dims - x.ndim)]
 
@@ -259,25 +262,35 @@ class StableVideoDiffusionPipeline:
             out.append(sch.step_interp_prob_uncertain(pred, t, lat[k], cond, mask, lam, step_i=i).prev_sample)
         return out
 
-    # ---- the two passes of a Replace step on two HIP streams ---------------------------------------------------------
+    # ---- independent launch sequences of a step on their own HIP streams ----------------------------------------------
     # A contraction launch of T tiles takes ceil(T / 256) rounds of the persistent kernels: at F = 25 the stacked step loses
     # 7.9 % of its contraction time to the last, partly empty round (1 800 tiles = 7.03 rounds take 8).
-    # Two launch sequences that do not depend on each other fill those rounds with each other's blocks when they run on two
-    # streams.  Measured at F = 25, same box, ms per (step, pass) unit (tools/two_stream_units.py): Replace, the two passes
-    # (B = 2 each) on two streams 172.8 against 177.4 stacked into one B = 4 sequence and 179.2 pass after pass; Post gains
-    # nothing from it (guidance tiles beside the CFG forward 296.0 against 294.7 stacked; the passes on two streams 299.2): it
-    # keeps the stacked order.  Same kernels on the same operands as the pass-after-pass order: bit-identical to it.  The
-    # first call of a shape runs stacked on one stream (it creates what both sequences read: frame-position embeddings,
-    # folded contexts, scratch buffers).
+    # Launch sequences that do not depend on each other fill those rounds with each other's blocks when they run on
+    # different streams.  Replace: the two passes (B = 2 each).  Post: each pass's CFG forward on its own stream beside the
+    # stacked guidance-tile forwards on the current one (the CFG input is built from the ORIGINAL latents, …post.py:786-792).
+    # Measured at F = 25, same box, ms per (step, pass) unit (tools/two_stream_units.py, profiles/r04/two_stream_units.txt):
+    # Replace 179.5 -> 174.8, Post 300.2 -> 288.9.  ONE pair of side streams per device and process (HIP multiplexes streams
+    # onto ~4 hardware queues: a second pair lands on occupied queues and serialises).  Results: the per-pass arithmetic of the
+    # pass-after-pass order (Replace: bit-identical to it), the same on every call.
     def _fork(self, key):
-        """(side stream 1, side stream 2), both waiting for the current stream - or None for the first call of `key`."""
+        """(side stream 1, side stream 2), both waiting for the current stream - or the current stream twice for the FIRST call of
+        `key`: that call creates what the sequences share (the UNet's frame-position embeddings of this batch size, folded
+        contexts, the scheduler's kernel-side operands), and a cache entry written on one side stream must not be read on the
+        other before it exists.  None: SYN3R_TWO_STREAMS=0."""
         if not self.two_streams:
             return None
         if key not in self._streams_warm:
             self._streams_warm.add(key)
-            return None
+            cur = torch.cuda.current_stream(self.device)
+            return (cur, cur)
         if self._side is None:
-            self._side = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+            # ONE pair of side streams per device for the whole process: HIP multiplexes streams onto a few hardware queues
+            # (4 by default), and two streams that land on one queue run one after the other - a second pipeline object with
+            # its own pair measured 369 ms where this pair gives 351 (tools/post_parts.py)
+            key = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            if key not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key] = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+            self._side = _SIDE_STREAMS[key]
         cur = torch.cuda.current_stream(self.device)
         for s_ in self._side:
             s_.wait_stream(cur)
@@ -286,13 +299,14 @@ class StableVideoDiffusionPipeline:
     def _join(self, streams):
         cur = torch.cuda.current_stream(self.device)
         for s_ in streams:
-            cur.wait_stream(s_)
+            if s_ is not cur:
+                cur.wait_stream(s_)
 
     def _streamed_replace(self, i, t, lat, img4, ehs4, added4, ops2, do_cfg):
         """The two passes of a Replace step (SVD_2pass_prob_uncertain.py:661-742), each on its own stream."""
         g = 2 if do_cfg else 1
         streams = self._fork(("replace", tuple(lat[0].shape)))
-        if streams is None:
+        if streams is None:                                  # SYN3R_TWO_STREAMS=0: both passes stacked into one launch sequence
             return self._merged_replace(i, t, lat, img4, ehs4, added4, ops2, do_cfg)
         out = []
         for k in range(2):
@@ -310,6 +324,17 @@ class StableVideoDiffusionPipeline:
         tiles, ov_y, ov_x, _ = ops2[0][3]
         grads = [[None] * 4, [None] * 4]
         ehs_t, added_t, grp = tile_ctx
+        # The CFG forwards do not depend on the guidance tiles (their input is built from the ORIGINAL latents, …post.py:786-792):
+        # each pass's CFG forward goes to its own stream FIRST, the tile forwards follow on the current one - three launch
+        # sequences whose kernels fill each other's partly empty last rounds (see above).  SYN3R_TWO_STREAMS=0: one stacked
+        # B = 4 CFG call behind the tiles.
+        streams = self._fork(("post", tuple(lat[0].shape)))
+        noises = None
+        if streams is not None:
+            noises = []
+            for k in range(2):
+                with torch.cuda.stream(streams[k]):
+                    noises.append(self._unet(x[k * g:(k + 1) * g], t, ehs4[k * g:(k + 1) * g], added4[k * g:(k + 1) * g]))
         for pair in ((0, 2), (1, 3)):                              # the four tile forwards of BOTH passes: two B = 4 calls
             xb = torch.cat([x[k * g:k * g + 1, :, :, tiles[q][0], tiles[q][1]] for k in range(2) for q in pair], dim=0).contiguous()
             noise = self._unet(xb, t, ehs_t, added_t, ctx_group=grp)
@@ -319,12 +344,16 @@ class StableVideoDiffusionPipeline:
                     o = sch.step_interp(noise[2 * k + n:2 * k + n + 1], t, lat[k][0:1, :, :, tiles[q][0], tiles[q][1]].contiguous(),
                                         tops[q][0], tops[q][1], ops2[k][2], step_i=i, lr=0.02, compute_grad=True)
                     grads[k][q] = o.grad
-        noise = self._unet(x, t, ehs4, added4, ctx_group=g)         # the CFG forwards of both passes: one B = 4 call
+        if streams is None:
+            noise = self._unet(x, t, ehs4, added4, ctx_group=g)    # the CFG forwards of both passes: one B = 4 call
+            noises = [noise[k * g:(k + 1) * g] for k in range(2)]
+        else:
+            self._join(streams)
         out = []
         for k in range(2):
             cond, mask, lam, _ = ops2[k]
             nxt = lat[k] - self._stitch(grads[k], ov_y, ov_x).half()
-            pred = self._cfg(noise[k * g:(k + 1) * g], do_cfg)
+            pred = self._cfg(noises[k], do_cfg)
             out.append(sch.step_interp(pred, t, nxt, cond, mask, lam, step_i=i, compute_grad=False).prev_sample)
         return out
 

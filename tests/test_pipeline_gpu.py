@@ -234,19 +234,20 @@ def test_full_size_post_pipeline_matches_reference(gpu, golden_dir):
 def test_replace_passes_on_two_streams_equal_the_pass_after_pass_order(gpu):
     """`_streamed_replace`: from the second step of a shape on, the two passes of a Replace step run on two HIP streams (their
     kernels fill each other's partly empty last rounds).  Same kernels on the same operands as the pass-after-pass order:
-    bit-identical to it; the first call of a shape runs stacked on one stream."""
+    bit-identical to it; the first call of a shape issues the same two sequences on one stream."""
     from oracle import unet_weights as UW
     from syn3r_amd.pipeline.svd_step import SvdStepBench
     from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel
     unet = UNetSpatioTemporalConditionModel(**UW.PIPELINE_CONFIG)
     unet.load_state_dict(UW.make_state_dict(unet.parameter_shapes(), seed=3), gpu)
     b = SvdStepBench(25, gpu, h=16, w=24, unet=unet)
-    b.step_both("replace")                                   # first call of the shape: stacked, creates the shared caches
+    b.step_both("replace")                                   # first call of the shape: the same sequences on ONE stream (creates the shared caches)
     st = b._both_replace
     pipe = st["pipe"]
     assert pipe.two_streams and ("replace", (1, 25, 4, 16, 24)) in pipe._streams_warm
     i, t = 7, b.sch.timesteps[7]
     lat = (b.latents, b.latents.flip(dims=[1]))
+    assert pipe._side is None                                # ... and did not touch the side streams
     streamed = pipe._streamed_replace(i, t, lat, st["img4"], st["ehs4"], st["added4"], st["ops2"], True)
     torch.cuda.synchronize()
     assert pipe._side is not None                            # the side streams were used
@@ -262,3 +263,41 @@ def test_replace_passes_on_two_streams_equal_the_pass_after_pass_order(gpu):
     for a, c in zip(streamed, stacked):                      # the stacked order: the same latents up to fp16 rounding of regrouped tiles
         scale = float(c.float().abs().max())
         assert float((a.float() - c.float()).abs().mean()) < 5e-4 * scale
+
+
+def test_post_step_on_three_streams_equals_the_one_stream_orders(gpu):
+    """`_merged_post` from the second step of a shape on: each pass's CFG forward on its own stream, the stacked guidance-tile
+    forwards beside them on the current one.  The CFG halves are the pass-after-pass arithmetic, the tiles the stacked one: the
+    latents equal BOTH one-stream orders within the tolerance those two have against each other, and a second streamed call
+    reproduces the first bit for bit (no race between the sequences)."""
+    from oracle import unet_weights as UW
+    from syn3r_amd.pipeline.svd_step import SvdStepBench
+    from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel
+    unet = UNetSpatioTemporalConditionModel(**UW.PIPELINE_CONFIG)
+    unet.load_state_dict(UW.make_state_dict(unet.parameter_shapes(), seed=3), gpu)
+    b = SvdStepBench(25, gpu, h=72, w=128, unet=unet)          # (the guidance tiles need a 9 x 16-divisible grid with 8-divisible tiles)
+    b.step_both("post")                                      # first call of the shape: the same sequences on one stream (creates the shared caches)
+    st = b._both_post
+    pipe = st["pipe"]
+    i, t = 7, b.sch.timesteps[7]
+    lat = (b.latents, b.latents.flip(dims=[1]))
+    args = (i, t, lat, st["img4"], st["ehs4"], st["added4"], st["ops2"], True, st["tile_ctx"])
+    assert pipe.two_streams
+    s1 = pipe._merged_post(*args)
+    s2 = pipe._merged_post(*args)
+    torch.cuda.synchronize()
+    assert pipe._side is not None
+    for a, c in zip(s1, s2):
+        assert torch.equal(a, c)
+    pipe.two_streams = False
+    stacked = pipe._merged_post(*args)
+    seq = []
+    for k in range(2):
+        cond, mask, lam, tops = st["ops2"][k]
+        seq.append(pipe._pass_post(i, t, lat[k], st["img4"][2 * k:2 * k + 2], st["ehs4"][2 * k:2 * k + 2], st["added4"][2 * k:2 * k + 2],
+                                   cond, mask, lam, True, tops))
+    for ref in (stacked, seq):
+        for a, c in zip(s1, ref):
+            scale = float(c.float().abs().max())
+            err = (a.float() - c.float()).abs()
+            assert float(err.mean()) < 5e-4 * scale and float((err > 1e-2 * scale).float().mean()) < 1e-4, (float(err.mean()), float(err.max()), scale)
