@@ -109,6 +109,7 @@ SIGNATURES = {
     "syn3r_pcd_outlier_workspace_bytes": (c_sz, [c_i]),
     "syn3r_pcd_statistical_outlier": (c_i, [c_p, c_i, c_i, c_d, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "syn3r_flow_cycle_mask": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
+    "syn3r_gemm_set_splitk_workspace": (c_i, [c_p, c_sz]),
     "syn3r_unet_create": (c_i, [C.c_char_p, C.c_char_p, C.POINTER(c_p)]),
     "syn3r_unet_destroy": (c_i, [c_p]),
     "syn3r_unet_workspace_bytes": (c_sz, [c_p, c_i, c_i, c_i, c_i, c_i]),

@@ -85,6 +85,10 @@ struct GemmParams {
     const __half* A2; long long lda2; int K1;     // A2 = null: one source
     // VGG-style activation options of the GENERAL epilogue (gemm_epilogue; the convolution kernels use it):
     int band;                             // persistent 256 x 320 kernels: tile columns per band of the tile order (band_width())
+    // split-K (k_gemm_dma<MODE, 256>, implicit-GEMM convolutions whose tile grid leaves most CUs idle): the K range is cut into
+    // `ksplit` equal parts, one block per (tile, part) writes its fp32 partial tile to split_ws
+    // [ksplit][M][N]; k_splitk_finish sums the parts in order and applies the epilogue (launch_dma)
+    int ksplit; float* split_ws;
     int relu;                             // result = max(result, 0)
     const __half* relu_mask;              // [M][ldc]: result zeroed where mask <= 0 (ReLU backward: grad * (activation > 0))
 };
@@ -306,7 +310,9 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
     const int wm = wv >> 1, wn = wv & 1;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const unsigned bid = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
+    const unsigned ntile = (unsigned)(tiles_m * tiles_n);
+    const int sp = p.ksplit > 1 ? (int)(blockIdx.x / ntile) : 0;             // split-K: which part of the K range
+    const unsigned bid = xcd_remap(blockIdx.x - (unsigned)sp * ntile, ntile);
     const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -416,7 +422,24 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = p.K / BK;
+    const int nkt = p.ksplit > 1 ? p.K / BK / p.ksplit : p.K / BK;
+    if (p.ksplit > 1) {                  // this block's part starts at k-tile sp * nkt, possibly inside a filter tap
+        const int kt0 = sp * nkt;
+#pragma unroll
+        for (int j = 0; j < NB_MAX; ++j) b_cur[j] += (long long)kt0 * b_inc[j];
+        if constexpr (MODE == MODE_DENSE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a_cur[i] += (long long)kt0 * a_inc[i];
+        } else {
+            const int rem = kt0 % cpb;   // k-tiles of the tap already behind this part
+            tap_next = kt0 / cpb;
+            setup_tap(tap_next);
+            ++tap_next;
+            c_left = cpb - rem;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a_cur[i] += (long long)rem * a_inc[i];
+        }
+    }
     issue_stage(0, 0);
     if (nkt > 1) issue_stage(1, 1);
 
@@ -485,8 +508,70 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
         if (++buf == DMA_STAGES) buf = 0;
     }
     if (defer) mma1();
+    if (p.ksplit > 1) {                  // fp32 partial tile of this K part: acc[i][j] = rows i*16 + fr, four columns j*16 + fq*4 ..
+        float* ws = p.split_ws + (size_t)sp * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + fq * 4;
+                if (m < p.M && n < p.N) *(float4v*)(ws + (size_t)m * p.N + n) = acc[i][j];      // (N % 8 == 0: whole quads)
+            }
+        }
+        return;
+    }
     __syncthreads();   // every wavefront is done reading the ring before the epilogue reuses it
     gemm_epilogue(p, acc, smem_raw, lane, wv, wm, wn, m0, n0, tile_n);
+}
+
+// The second half of a split-K contraction: out = epilogue(sum over the K parts, in order) with gemm_epilogue's arithmetic
+// (bias and row vector added in fp32, scaled, rounded to fp16; then the residual / aux blend on the rounded value).
+// One thread per 8 output columns.
+__global__ void __launch_bounds__(256) k_splitk_finish(GemmParams p) {
+    const int nch = p.N / 8;
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (long long)p.M * nch) return;
+    const int m = (int)(q / nch), n = (int)(q - (long long)m * nch) * 8;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    for (int s = 0; s < p.ksplit; ++s) {
+        const float4v* src = (const float4v*)(p.split_ws + ((size_t)s * p.M + m) * p.N + n);
+        const float4v a = src[0], b = src[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[e] += a[e]; f[4 + e] += b[e]; }
+    }
+    if (p.bias) {
+        const half8 b = *(const half8*)(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += (float)b[e];
+    }
+    if (p.rowvec) {
+        const half8 t = *(const half8*)(p.rowvec + (long long)rowvec_index(m, p.rows_per_vec, p.rv_group) * p.ldrv + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += (float)t[e];
+    }
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (_Float16)(f[e] * p.s_acc);
+    if (p.residual || p.aux) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+        if (p.residual) {
+            const half8 r = *(const half8*)(p.residual + (long long)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += p.s_res * (float)r[e];
+        }
+        if (p.aux) {
+            const half8 a = *(const half8*)(p.aux + (long long)m * p.ldaux + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += p.s_aux * (float)a[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)f[e];
+    }
+    *(half8*)(p.out + (long long)m * p.ldc + n) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1647,6 +1732,9 @@ int launch_z(const GemmParams& p, hipStream_t stream) {
 
 // Kernel family forced by the CALLING THREAD (syn3r_gemm_set_tile, see launch_dma); thread_local: no state shared between host threads
 thread_local int g_dma_bm = 0;
+// Split-K scratch of the CALLING THREAD (syn3r_gemm_set_splitk_workspace): null = no split-K
+thread_local void* g_splitk_ws = nullptr;
+thread_local size_t g_splitk_bytes = 0;
 
 // Which of the two persistent 256 x 320 kernels: measured inside the UNet unit on one box (tools/gemm_ab.py SYN3R_GEMM_Z 0 1,
 // profiles/r04/gemm_z_ab.txt) the software-pipelined k_gemm_z is 1.6..3.5 % faster on the gated projections and 1..5 %
@@ -1788,6 +1876,37 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
     // sum), the residual-add projections -5..-6 %; only grids that leave CUs without a 256-row block (dense, M = 4032)
     // stay with the 128-row blocks.  (Before the stagger the 128-row pairs won everywhere but N >= 5120.)
     const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+    // Split-K for the convolutions whose grid leaves most of the chip idle (level 3 of the UNet at F = 14: M = 4 032 rows = 128
+    // tiles of 256 x 160 on 256 CUs, and doubling the rows costs such a launch only +16 % time): S = 2 or 4 equal K parts so that
+    // tiles x S fills one round of the chip, fp32 partial tiles in the caller's workspace (syn3r_gemm_set_splitk_workspace, per
+    // calling thread), summed in order by k_splitk_finish.  Without a workspace, or when it is too small: one pass.
+    if constexpr (MODE != MODE_DENSE) {
+        const int nkt_all = p.K / BK;
+        const int S = (tiles256 * 4 <= 256 && nkt_all % 4 == 0 && nkt_all >= 16) ? 4 : ((tiles256 * 2 <= 256 && nkt_all % 2 == 0 && nkt_all >= 8) ? 2 : 1);
+        const size_t need = (size_t)S * p.M * p.N * sizeof(float);
+        if (S > 1 && g_dma_bm == 0 && g_splitk_ws && need <= g_splitk_bytes && p.N % 8 == 0 && p.M >= 8 && !p.relu && !p.relu_mask &&
+            p.geglu_D <= 0 && !p.out_tiled) {
+            constexpr size_t lds = (size_t)3 * (256 * BK * 2 + DMA_B_BYTES);
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute((const void*)k_gemm_dma<MODE, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_dma)");
+                attr_set = true;
+            }
+            GemmParams q = p;
+            q.ksplit = S; q.split_ws = (float*)g_splitk_ws;
+            char name[96];
+            if (trace_on()) {
+                if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_dma<%d,256>/%d[M%d,N%d,K%d,e%d]", MODE, S, p.M, p.N, p.K, p.residual != nullptr);
+                else snprintf(name, sizeof(name), "k_gemm_dma<%d,256>/k", MODE);
+            }
+            SYN3R_LAUNCH_NAMED(name, (k_gemm_dma<MODE, 256>), dim3((unsigned)(tiles256 * S)), dim3(512), lds, stream, q);
+            const long long chunks = (long long)p.M * (p.N / 8);
+            SYN3R_LAUNCH(k_splitk_finish, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, q);
+            SYN3R_LAUNCH_CHECK("gemm split-K launch");
+            return SYN3R_OK;
+        }
+    }
     int bm = g_dma_bm > 0 ? g_dma_bm : ((MODE != MODE_DENSE || tiles256 >= 256) ? 256 : 128);
     return bm == 128 ? launch_dma_bm<MODE, 128>(p, stream) : launch_dma_bm<MODE, 256>(p, stream);
 }
@@ -1810,6 +1929,14 @@ int check_common(const GemmParams& p, const char* who) {
 }
 
 }  // namespace
+
+extern "C" int syn3r_gemm_set_splitk_workspace(void* workspace, size_t bytes) {
+    SYN3R_REQUIRE((workspace == nullptr) == (bytes == 0), "gemm_set_splitk_workspace: pointer and size must both be given or both be zero");
+    SYN3R_REQUIRE(((uintptr_t)workspace % 16) == 0, "gemm_set_splitk_workspace: the workspace must be 16-byte aligned");
+    g_splitk_ws = workspace;
+    g_splitk_bytes = bytes;
+    return SYN3R_OK;
+}
 
 extern "C" int syn3r_gemm_set_tile(int bm) {
     SYN3R_REQUIRE(bm == 0 || bm == -128 || bm == -256 || bm == -320 || bm == -321 || bm == -322,

@@ -888,6 +888,27 @@ struct Run {
     // unet_spatio_temporal_condition.py:356-489
     void forward(const __half* sample, double timestep, const __half* ehs_in, int ehs_rows, const float* added_ids, __half* out) {
         const int c0 = m.boc[0];
+        // split-K scratch for the lowest level's convolutions (model.py:forward, the same rule): set for this forward, on this thread
+        void* splitk = nullptr;
+        {
+            const int down = 1 << (m.boc.size() - 1);
+            const long long m_low = (long long)B * F * (h / down) * (w / down);
+            const char* e = getenv("SYN3R_SPLITK");
+            if (!(e && !strcmp(e, "0")) && ((m_low + 255) / 256) * ((m.boc.back() + 159) / 160) * 2 <= 256) {
+                const size_t bytes = (size_t)4 * m_low * m.boc.back() * 4;
+                splitk = ok() ? ar.alloc(bytes) : nullptr;
+                if (ok() && !splitk) { set_error("unet_forward: workspace too small (needs syn3r_unet_workspace_bytes)"); rc = SYN3R_E_WORKSPACE; }
+                if (go()) chk(syn3r_gemm_set_splitk_workspace(splitk, bytes));
+            }
+        }
+        forward_body(sample, timestep, ehs_in, ehs_rows, added_ids, out);
+        if (splitk) {
+            if (!dry) syn3r_gemm_set_splitk_workspace(nullptr, 0);
+            ar.release(splitk);
+        }
+    }
+    void forward_body(const __half* sample, double timestep, const __half* ehs_in, int ehs_rows, const float* added_ids, __half* out) {
+        const int c0 = m.boc[0];
         // 1. time (:385-418)
         T te = make(B, c0);
         if (go()) hipLaunchKernelGGL(k_timestep_embedding, dim3((unsigned)((B * (c0 / 2) + 255) / 256)), dim3(256), 0, stream, (const float*)nullptr, timestep, 0.0f, B, c0, te.p);

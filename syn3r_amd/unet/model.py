@@ -494,6 +494,28 @@ class UNetSpatioTemporalConditionModel:
             raise NotImplementedError("temporal attention kernel supports up to 32 frames")
         W = self.w
         boc = c["block_out_channels"]
+        # split-K scratch for the lowest level's convolutions when their tile grid would leave most CUs idle (F = 14: 4 032 rows =
+        # 128 tiles on 256 CUs; include/syn3r_hip.h syn3r_gemm_set_splitk_workspace): set for this forward, on this thread
+        down = 2 ** (len(boc) - 1)
+        m_low = B * F * (h // down) * (w_ // down)
+        splitk = None
+        if os.environ.get("SYN3R_SPLITK") != "0" and ((m_low + 255) // 256) * ((boc[-1] + 159) // 160) * 2 <= 256:
+            nbytes = 4 * m_low * boc[-1] * 4                 # up to four fp32 partial tiles of the lowest level's widest output
+            splitk = L.workspace(dev, nbytes, "splitk")
+            # (the REQUESTED size, not the cached buffer's: which launches split must not depend on what ran before)
+            L.check(L.load().syn3r_gemm_set_splitk_workspace(L.ptr(splitk), nbytes), "syn3r_gemm_set_splitk_workspace")
+        try:
+            return self._forward(sample, timestep, encoder_hidden_states, added_time_ids, return_dict, ctx_group)
+        finally:
+            if splitk is not None:
+                L.load().syn3r_gemm_set_splitk_workspace(None, 0)
+
+    def _forward(self, sample, timestep, encoder_hidden_states, added_time_ids, return_dict, ctx_group):
+        dev = L.require_gpu(sample, encoder_hidden_states, added_time_ids)
+        c = self.config
+        B, F, Cin, h, w_ = sample.shape
+        W = self.w
+        boc = c["block_out_channels"]
         # 1. time (:385-418)
         ts = timestep if torch.is_tensor(timestep) else torch.tensor([timestep], dtype=torch.float64)
         ts = ts.reshape(-1).to(dev).expand(B)

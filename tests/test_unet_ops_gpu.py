@@ -531,3 +531,70 @@ def test_persistent_lds_dma_kernel_many_tiles(gpu):
         close(o3, 0.5 * ref_t + 1.5 * xt.float().repeat(1, 5))
     finally:
         lib.syn3r_gemm_set_tile(0)
+
+
+@pytest.mark.parametrize("NB,Hi,Wi,Cin,Cout", [(4, 8, 8, 128, 160), (28, 9, 16, 1280, 1280), (3, 6, 10, 128, 328), (2, 8, 8, 256, 160)])
+def test_conv3x3_split_k(NB, Hi, Wi, Cin, Cout, gpu):
+    """syn3r_gemm_set_splitk_workspace: the small-grid convolutions as two or four K parts (cut inside a filter tap too) + the finishing
+    launch (bias, per-sample row vector, residual: the one-pass epilogue's arithmetic on the fp32 sum of the parts): equal to the
+    one-pass launch up to the association of the fp32 sum, and to the fp32 reference within the usual tolerance; the split path
+    is really taken (kernel trace), and a workspace that is too small falls back to one pass."""
+    from syn3r_amd import _lib
+    from syn3r_amd.unet import ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(NB * Hi + Cout)
+    x = rnd(g, NB, Hi, Wi, Cin, dev=gpu)
+    w = rnd(g, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, dev=gpu)
+    b = rnd(g, Cout, dev=gpu)
+    temb = rnd(g, NB, Cout, dev=gpu)
+    res = rnd(g, NB * Hi * Wi, Cout, dev=gpu)
+    wk = w.permute(0, 2, 3, 1).contiguous()
+    kw = dict(rowvec=temb, rows_per_vec=Hi * Wi, residual=res, s_acc=0.7, s_res=1.0)
+    ref = 0.7 * (Fn.conv2d(x.permute(0, 3, 1, 2).float(), w.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+                 + temb.float().repeat_interleave(Hi * Wi, 0)) + res.float()
+    one = ops.conv3x3(x, wk, b, **kw).reshape(-1, Cout)
+    M = NB * Hi * Wi
+    ws = torch.empty(4 * M * Cout * 4, dtype=torch.uint8, device=gpu)
+    try:
+        _lib.check(lib.syn3r_gemm_set_splitk_workspace(ws.data_ptr(), ws.numel()), "set_splitk")
+        with _lib.kernel_trace() as tr:
+            split = ops.conv3x3(x, wk, b, **kw).reshape(-1, Cout)
+            torch.cuda.synchronize()
+        assert any("k_splitk_finish" in k for k in tr.result), list(tr.result)
+        _lib.check(lib.syn3r_gemm_set_splitk_workspace(ws.data_ptr(), 1024), "set_splitk")          # too small: one pass
+        with _lib.kernel_trace() as tr2:
+            small = ops.conv3x3(x, wk, b, **kw).reshape(-1, Cout)
+            torch.cuda.synchronize()
+        assert not any("k_splitk_finish" in k for k in tr2.result)
+        assert torch.equal(small, one)
+    finally:
+        lib.syn3r_gemm_set_splitk_workspace(None, 0)
+    close(split, ref)
+    assert (split.float() - one.float()).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    assert lib.syn3r_gemm_set_splitk_workspace(ws.data_ptr(), 0) != 0            # pointer without a size
+
+
+def test_tconv3_split_k(gpu):
+    from syn3r_amd import _lib
+    from syn3r_amd.unet import ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    B, F, HW, Cin, Cout = 2, 6, 20, 256, 192
+    x = rnd(g, B * F * HW, Cin, dev=gpu)
+    w = rnd(g, Cout, Cin, 3, scale=(3 * Cin) ** -0.5, dev=gpu)
+    b, res = rnd(g, Cout, dev=gpu), rnd(g, B * F * HW, Cout, dev=gpu)
+    x5 = x.float().reshape(B, F, HW, Cin).permute(0, 3, 1, 2)[..., None]
+    ref = Fn.conv3d(x5, w.float()[..., None, None], b.float(), padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(B * F * HW, Cout)
+    wk = w.permute(0, 2, 1).contiguous()
+    one = ops.tconv3(x, wk, b, B, F, HW, residual=res, s_acc=0.6, s_res=1.0)
+    ws = torch.empty(4 * B * F * HW * Cout * 4, dtype=torch.uint8, device=gpu)
+    try:
+        _lib.check(lib.syn3r_gemm_set_splitk_workspace(ws.data_ptr(), ws.numel()), "set_splitk")
+        with _lib.kernel_trace() as tr:
+            split = ops.tconv3(x, wk, b, B, F, HW, residual=res, s_acc=0.6, s_res=1.0)
+            torch.cuda.synchronize()
+        assert any("k_splitk_finish" in k for k in tr.result), list(tr.result)
+    finally:
+        lib.syn3r_gemm_set_splitk_workspace(None, 0)
+    close(split, 0.6 * ref + res.float())
+    assert (split.float() - one.float()).abs().max().item() <= 2e-3 * ref.abs().max().item()
