@@ -311,8 +311,8 @@ int syn3r_gemm_2src_f16(const void* A1, long long lda1, int K1, const void* A2, 
  * persistent 256 x 320 kernel (round 4: dense, two-source and implicit-GEMM convolution modes) wherever it admits the shape. */
 int syn3r_gemm_set_tile(int bm);
 
-/* Split-K scratch, PER CALLING THREAD (round 4).  With a workspace set, the implicit-GEMM convolutions (syn3r_conv2d3x3_f16,
- * syn3r_tconv3_f16) whose tile grid would leave more than half of the CUs idle (level 3 of the SVD UNet at F = 14: 4 032 rows) run
+/* Split-K scratch, PER CALLING THREAD (round 4).  With a workspace set, the contractions (syn3r_gemm_f16, syn3r_gemm_2src_f16
+ * when no part would straddle K1, net.2 of syn3r_feedforward_f16, syn3r_conv2d3x3_f16, syn3r_tconv3_f16) whose tile grid would leave more than half of the CUs idle (level 3 of the SVD UNet at F = 14: 4 032 rows) run
  * as two or four equal K parts - one block per (tile, part), fp32 partial tiles in the workspace - followed by a small
  * launch that sums the parts IN ORDER and applies the epilogue (same arithmetic as the one-pass epilogue; the fp32 sum is
  * associated differently, so results differ from the one-pass launch in the last bits).  Up to 4 * M * N * 4 bytes are used per launch

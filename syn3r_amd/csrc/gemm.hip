@@ -332,6 +332,8 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
             const int last_rb = (p.M + 127) >> 7, rb = (m >> 7) < last_rb ? (m >> 7) : last_rb - 1;
             a_base[i] = p.a_tiled ? p.A + (long long)rb * (p.K >> 6) * 8192 + (m & 127) * 64 + csrc * 8
                                   : p.A + (long long)mc * p.lda + csrc * 8;
+            // two sources (split-K launches only, parts never straddle K1): the parts from k-tile K1 / BK on read A2
+            if (p.A2 && p.ksplit > 1 && sp * (p.K / BK / p.ksplit) >= p.K1 / BK) a_base[i] = p.A2 + (long long)mc * p.lda2 + csrc * 8;
             a_n[i] = a_y[i] = a_x[i] = 0;
         } else if constexpr (MODE == MODE_CONV2D) {
             int hw = p.Ho * p.Wo;
@@ -429,7 +431,7 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
         for (int j = 0; j < NB_MAX; ++j) b_cur[j] += (long long)kt0 * b_inc[j];
         if constexpr (MODE == MODE_DENSE) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a_cur[i] += (long long)kt0 * a_inc[i];
+            for (int i = 0; i < 4; ++i) a_cur[i] += (long long)(kt0 - ((p.A2 && kt0 >= p.K1 / BK) ? p.K1 / BK : 0)) * a_inc[i];
         } else {
             const int rem = kt0 % cpb;   // k-tiles of the tap already behind this part
             tap_next = kt0 / cpb;
@@ -1814,6 +1816,42 @@ int launch_dma_bm(const GemmParams& p, hipStream_t stream) {
     return SYN3R_OK;
 }
 
+// Split-K for the contractions whose grid leaves most of the chip idle (level 3 of the UNet at F = 14: M = 4 032 rows = 128
+// tiles of 256 x 160 on 256 CUs, and doubling the rows costs such a launch only +16 % time): S = 2 or 4 equal K parts so that
+// tiles x S fills one round of the chip, fp32 partial tiles in the caller's workspace (syn3r_gemm_set_splitk_workspace, per
+// calling thread), summed in order by k_splitk_finish.  Without a workspace, or when it is too small: *done stays false and the
+// caller launches one pass.  Two-source A: only when no part straddles the boundary between the sources.
+template <int MODE>
+int launch_splitk(const GemmParams& p, hipStream_t stream, bool* done) {
+    const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+    const int nkt_all = p.K / BK;
+    const int S = (tiles256 * 4 <= 256 && nkt_all % 4 == 0 && nkt_all >= 16) ? 4 : ((tiles256 * 2 <= 256 && nkt_all % 2 == 0 && nkt_all >= 8) ? 2 : 1);
+    const size_t need = (size_t)S * p.M * p.N * sizeof(float);
+    if (S == 1 || g_dma_bm != 0 || !g_splitk_ws || need > g_splitk_bytes || p.N % 8 != 0 || p.M < 8 || p.relu || p.relu_mask ||
+        p.geglu_D > 0 || p.out_tiled || (p.A2 && (MODE != MODE_DENSE || p.a_tiled || (p.K1 / BK) % (nkt_all / S) != 0)))
+        return SYN3R_OK;
+    constexpr size_t lds = (size_t)3 * (256 * BK * 2 + DMA_B_BYTES);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_dma<MODE, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_dma)");
+        attr_set = true;
+    }
+    GemmParams q = p;
+    q.ksplit = S; q.split_ws = (float*)g_splitk_ws;
+    char name[96];
+    if (trace_on()) {
+        if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_dma<%d,256>/%d[M%d,N%d,K%d,e%d]", MODE, S, p.M, p.N, p.K, p.residual != nullptr);
+        else snprintf(name, sizeof(name), "k_gemm_dma<%d,256>/k", MODE);
+    }
+    SYN3R_LAUNCH_NAMED(name, (k_gemm_dma<MODE, 256>), dim3((unsigned)(tiles256 * S)), dim3(512), lds, stream, q);
+    const long long chunks = (long long)p.M * (p.N / 8);
+    SYN3R_LAUNCH(k_splitk_finish, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, q);
+    SYN3R_LAUNCH_CHECK("gemm split-K launch");
+    *done = true;
+    return SYN3R_OK;
+}
+
 template <int MODE>
 int launch_dma(const GemmParams& p, hipStream_t stream) {
     static int wide_env = -2;       // SYN3R_GEMM_WIDE: unset = by shape, 0 = never, 1 = always (tuning)
@@ -1876,37 +1914,9 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
     // sum), the residual-add projections -5..-6 %; only grids that leave CUs without a 256-row block (dense, M = 4032)
     // stay with the 128-row blocks.  (Before the stagger the 128-row pairs won everywhere but N >= 5120.)
     const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
-    // Split-K for the convolutions whose grid leaves most of the chip idle (level 3 of the UNet at F = 14: M = 4 032 rows = 128
-    // tiles of 256 x 160 on 256 CUs, and doubling the rows costs such a launch only +16 % time): S = 2 or 4 equal K parts so that
-    // tiles x S fills one round of the chip, fp32 partial tiles in the caller's workspace (syn3r_gemm_set_splitk_workspace, per
-    // calling thread), summed in order by k_splitk_finish.  Without a workspace, or when it is too small: one pass.
-    if constexpr (MODE != MODE_DENSE) {
-        const int nkt_all = p.K / BK;
-        const int S = (tiles256 * 4 <= 256 && nkt_all % 4 == 0 && nkt_all >= 16) ? 4 : ((tiles256 * 2 <= 256 && nkt_all % 2 == 0 && nkt_all >= 8) ? 2 : 1);
-        const size_t need = (size_t)S * p.M * p.N * sizeof(float);
-        if (S > 1 && g_dma_bm == 0 && g_splitk_ws && need <= g_splitk_bytes && p.N % 8 == 0 && p.M >= 8 && !p.relu && !p.relu_mask &&
-            p.geglu_D <= 0 && !p.out_tiled) {
-            constexpr size_t lds = (size_t)3 * (256 * BK * 2 + DMA_B_BYTES);
-            static bool attr_set = false;
-            if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute((const void*)k_gemm_dma<MODE, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_dma)");
-                attr_set = true;
-            }
-            GemmParams q = p;
-            q.ksplit = S; q.split_ws = (float*)g_splitk_ws;
-            char name[96];
-            if (trace_on()) {
-                if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_dma<%d,256>/%d[M%d,N%d,K%d,e%d]", MODE, S, p.M, p.N, p.K, p.residual != nullptr);
-                else snprintf(name, sizeof(name), "k_gemm_dma<%d,256>/k", MODE);
-            }
-            SYN3R_LAUNCH_NAMED(name, (k_gemm_dma<MODE, 256>), dim3((unsigned)(tiles256 * S)), dim3(512), lds, stream, q);
-            const long long chunks = (long long)p.M * (p.N / 8);
-            SYN3R_LAUNCH(k_splitk_finish, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, q);
-            SYN3R_LAUNCH_CHECK("gemm split-K launch");
-            return SYN3R_OK;
-        }
-    }
+    bool split = false;
+    int rc = launch_splitk<MODE>(p, stream, &split);
+    if (split || rc) return rc;
     int bm = g_dma_bm > 0 ? g_dma_bm : ((MODE != MODE_DENSE || tiles256 >= 256) ? 256 : 128);
     return bm == 128 ? launch_dma_bm<MODE, 128>(p, stream) : launch_dma_bm<MODE, 256>(p, stream);
 }
@@ -2039,6 +2049,9 @@ extern "C" int syn3r_gemm_2src_f16(const void* A1, long long lda1, int K1, const
     // only the persistent 256 x 320 kernel reads two sources; syn3r_gemm_2src_supported() is its admission test
     SYN3R_REQUIRE(syn3r_gemm_2src_supported(M, N, K1, K2, lda1, lda2) != 0,
                   "gemm_2src: shape M=%d N=%d not served by the two-source kernel (concatenate and call syn3r_gemm_f16)", M, N);
+    bool split = false;
+    rc = launch_splitk<MODE_DENSE>(p, (hipStream_t)stream, &split);     // a grid of a quarter of the chip: the two sources as K parts
+    if (split || rc) return rc;
     return wide_launch(p, (hipStream_t)stream);
 }
 

@@ -598,3 +598,82 @@ def test_tconv3_split_k(gpu):
         lib.syn3r_gemm_set_splitk_workspace(None, 0)
     close(split, 0.6 * ref + res.float())
     assert (split.float() - one.float()).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+def test_linear_split_k(gpu):
+    """The dense contraction on the split-K path (a small grid, long K) with the full epilogue."""
+    from syn3r_amd import _lib
+    from syn3r_amd.unet import ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(21)
+    M, N, K, rpv = 600, 320, 2560, 100
+    x, w, b = rnd(g, M, K, dev=gpu), rnd(g, N, K, scale=K ** -0.5, dev=gpu), rnd(g, N, dev=gpu)
+    rv, res, aux = rnd(g, M // rpv, N, dev=gpu), rnd(g, M, N, dev=gpu), rnd(g, M, N, dev=gpu)
+    kw = dict(rowvec=rv, rows_per_vec=rpv, residual=res, aux=aux, s_acc=0.3, s_res=1.0, s_aux=0.7)
+    ref = 0.3 * (x.float() @ w.float().T + b.float() + rv.float().repeat_interleave(rpv, 0)) + res.float() + 0.7 * aux.float()
+    one = ops.linear(x, w, b, **kw)
+    ws = torch.empty(4 * M * N * 4, dtype=torch.uint8, device=gpu)
+    try:
+        _lib.check(lib.syn3r_gemm_set_splitk_workspace(ws.data_ptr(), ws.numel()), "set_splitk")
+        with _lib.kernel_trace() as tr:
+            split = ops.linear(x, w, b, **kw)
+            torch.cuda.synchronize()
+        assert any("k_splitk_finish" in k for k in tr.result), list(tr.result)
+    finally:
+        lib.syn3r_gemm_set_splitk_workspace(None, 0)
+    close(split, ref)
+    assert (split.float() - one.float()).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+def test_feedforward_split_k(gpu):
+    """net.2 of the two-launch FeedForward reads its A operand from the tiled workspace; at level 3 of the UNet (4 032 rows,
+    K = 5 120) its grid is small enough for the split-K path: same result as the unsplit launch within fp16 rounding."""
+    from syn3r_amd import _lib
+    from syn3r_amd.unet import ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(22)
+    M, C, D = 4032, 1280, 5120
+    x = rnd(g, M, C, dev=gpu)
+    w1, b1 = rnd(g, 2 * D, C, scale=C ** -0.5, dev=gpu), rnd(g, 2 * D, dev=gpu)
+    w2, b2, res = rnd(g, C, D, scale=D ** -0.5, dev=gpu), rnd(g, C, dev=gpu), rnd(g, M, C, dev=gpu)
+    wp, bp, _ = ops.pack_geglu(w1, b1)
+    one = ops.feedforward(x, wp, bp, D, w2, b2, residual=res)
+    ws = torch.empty(4 * M * C * 4, dtype=torch.uint8, device=gpu)
+    try:
+        _lib.check(lib.syn3r_gemm_set_splitk_workspace(ws.data_ptr(), ws.numel()), "set_splitk")
+        with _lib.kernel_trace() as tr:
+            split = ops.feedforward(x, wp, bp, D, w2, b2, residual=res)
+            torch.cuda.synchronize()
+        assert any("k_splitk_finish" in k for k in tr.result), list(tr.result)
+    finally:
+        lib.syn3r_gemm_set_splitk_workspace(None, 0)
+    y = (x.float() @ w1.float().T + b1.float()).half().float()
+    h = (y[:, :D] * Fn.gelu(y[:, D:])).half().float()
+    close(split, h @ w2.float().T + b2.float() + res.float(), tol=4e-3)
+    assert (split.float() - one.float()).abs().max().item() <= 2e-3 * one.float().abs().max().item()
+
+
+@pytest.mark.parametrize("M,K1,K2,N", [(4032, 1280, 1280, 1280), (1000, 256, 256, 320), (520, 1280, 640, 320)])
+def test_linear_cat_split_k(M, K1, K2, N, gpu):
+    """The two-source shortcut projection on the split-K path: the K parts of the second source read A2 (no part may
+    straddle the boundary: K1 = 1280, K2 = 640 cannot be split in 2 or 4 equal parts that respect it and stays unsplit)."""
+    from syn3r_amd import _lib
+    from syn3r_amd.unet import ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + K2)
+    big1, big2 = rnd(g, M, K1 + 64, dev=gpu), rnd(g, M, K2 + 8, dev=gpu)
+    x1, x2 = big1[:, 32:32 + K1], big2[:, 8:]                    # strided sources
+    w, b = rnd(g, N, K1 + K2, scale=(K1 + K2) ** -0.5, dev=gpu), rnd(g, N, dev=gpu)
+    one = ops.linear_cat(x1, x2, w, b)
+    ws = torch.empty(4 * M * N * 4, dtype=torch.uint8, device=gpu)
+    try:
+        _lib.check(lib.syn3r_gemm_set_splitk_workspace(ws.data_ptr(), ws.numel()), "set_splitk")
+        with _lib.kernel_trace() as tr:
+            split = ops.linear_cat(x1, x2, w, b)
+            torch.cuda.synchronize()
+        assert any("k_splitk_finish" in k for k in tr.result) == (K1 == K2), list(tr.result)
+    finally:
+        lib.syn3r_gemm_set_splitk_workspace(None, 0)
+    ref = torch.cat([x1, x2], 1).float() @ w.float().T + b.float()
+    close(split, ref)
+    assert (split.float() - one.float()).abs().max().item() <= 2e-3 * ref.abs().max().item()
