@@ -371,6 +371,20 @@ int syn3r_feedforward_fused_ln_f16(const void* x, long long ldx, const void* ln_
                                    long long ldaux, float s_acc, float s_res, float s_aux, int M, int C, void* stream);
 
 /*
+ * (hidden + add vector) -> LayerNorm -> FeedForward -> + (hidden + add vector) in that kernel: the head of
+ * TemporalBasicTransformerBlock.forward for C = 320 (attention.py:500-517: `residual = hidden_states` after the frame-position
+ * embedding was added by the caller, transformer_temporal.py:339; `norm_in`; `ff_in`; `+ residual`).  x is the activation BEFORE
+ * the embedding is added, addvec [rows, 320] holds one embedding row per rows_per_vec consecutive rows of x.  The kernel adds the
+ * vector to its resident x tile (an fp16 tensor add, rounded as the reference's), normalises it, and its epilogue adds the
+ * same fp16 sum as the residual: bit for bit syn3r_layernorm_f16(x, addvec, want the sum) followed by syn3r_feedforward_fused_f16 with
+ * that sum as the residual, without the two [M, 320] round trips.  aux / scales as syn3r_feedforward_fused_f16.
+ */
+int syn3r_feedforward_fused_addln_f16(const void* x, long long ldx, const void* addvec, int rows_per_vec, const void* ln_gamma,
+                                      const void* ln_beta, float ln_eps, const void* w1_chunked, const void* b1_chunked, int D,
+                                      const void* w2, const void* b2, void* out, long long ldc, const void* aux, long long ldaux,
+                                      float s_acc, float s_res, float s_aux, int M, int C, void* stream);
+
+/*
  * 3x3 Conv2d on NHWC fp16 (resnet.py:274,290; downsampling.py:116-148 with stride 2;
  * upsampling.py:172-183 with upsample != 0: nearest-2x of the input fused into the gather).
  * pad_lo = 1: padding 1 on every side.  pad_lo = 0: the VAE encoder's Downsample2D(padding=0), which pads

@@ -83,6 +83,8 @@ struct GemmParams {
     // Two-source A (k_gemm_widep only): columns [0, K1) of a row come from A (stride lda), columns [K1, K) from A2
     // (stride lda2) - the channel concatenation [A | A2] the up blocks' shortcut projection reads is never written.
     const __half* A2; long long lda2; int K1;     // A2 = null: one source
+    // k_ffn320 only: the residual operand is residual + res_add[row / res_add_rpv] (an fp16 tensor add, rounded as such)
+    const __half* res_add; int res_add_rpv;
     // VGG-style activation options of the GENERAL epilogue (gemm_epilogue; the convolution kernels use it):
     int band;                             // persistent 256 x 320 kernels: tile columns per band of the tile order (band_width())
     // split-K (k_gemm_dma<MODE, 256>, implicit-GEMM convolutions whose tile grid leaves most CUs idle): the K range is cut into
@@ -115,7 +117,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chu
 // reads back at once (qkv, proj_in) non-temporal stores cost the PRODUCER 8..25 %, so it is opt-in per call.
 #define OUT_STORE(ptr, val) do { if (p.out_nt) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
 
-template <int PREFETCH_RES = 1>
+template <int PREFETCH_RES = 1, bool RES_ADD = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc)[TM][TN], char* smem_raw, int lane,
                                               int wv, int wm, int wn, int m0, int n0, int tile_n) {
     const int fr = lane & 15, fq = lane >> 4;
@@ -129,14 +131,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
     // behind the accumulator -> LDS staging and the block barrier (10 x 16 B per lane; the MFMA fragments
     // are dead here, so the registers are free).
     half8 res[WM * (WN / 8) / 64];
+    half8 radd[RES_ADD ? WM * (WN / 8) / 64 : 1];      // RES_ADD: the vector the residual gets added first (requested with it, added where it is used)
     auto prefetch_residual = [&]() {
 #pragma unroll
         for (int it = 0; it < WM * (WN / 8) / 64; ++it) {
             const int q = lane + it * 64;
             int row = q / (WN / 8), ch = q - row * (WN / 8);
             int m = gm0 + row, n = gn0 + ch * 8;
-            if (m < p.M && n + 8 <= p.N) res[it] = *(const half8*)(p.residual + (long long)m * p.ldr + n);
-            else {
+            if (m < p.M && n + 8 <= p.N) {
+                res[it] = *(const half8*)(p.residual + (long long)m * p.ldr + n);
+                if constexpr (RES_ADD) { if (p.res_add) radd[it] = *(const half8*)(p.res_add + (long long)(m / p.res_add_rpv) * p.N + n); }
+            } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) res[it][e] = (m < p.M && n + e < p.N) ? ((const _Float16*)p.residual)[(long long)m * p.ldr + n + e] : (_Float16)0.f;
             }
@@ -243,6 +248,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
                 half8 rr;
                 if constexpr (PREFETCH_RES != 0) rr = res[it];
                 else rr = *(const half8*)(p.residual + (long long)m * p.ldr + n);
+                if constexpr (RES_ADD) { if (p.res_add) rr = rr + radd[it]; }          // fp16 tensor add
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] += p.s_res * (float)rr[e];
             }
@@ -1352,6 +1358,8 @@ struct FfnParams {
     const __half* ln_g;      // non-null: x is LayerNorm'ed (gamma, beta, eps over the 320 channels) inside the kernel first
     const __half* ln_b;
     float ln_eps;
+    const __half* ln_add;    // non-null: x + ln_add[row / ln_add_rpv] (fp16 tensor add) is what gets normalised ([rows, 320], 16-byte aligned)
+    int ln_add_rpv;
 };
 
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
@@ -1421,16 +1429,31 @@ __global__ void __launch_bounds__(512, 2) k_ffn320(FfnParams q) {
     // row over the 16-byte chunks c, c + 8, ..., combined by the xor tree 4, 2, 1 - here four threads per row hold two of the
     // eight each.  The tile is five [128 x 64] k-tile images with the chunk index XOR-swizzled by the row.
     if (q.ln_g) {
+        const int r = tid >> 2, part = tid & 3;
+        half8 xv[5][2], addv[5][2];
+        if (q.ln_add) {       // requested before the wait for the x tile: one latency, not two
+            int m = m0 + r;
+            m = m < p.M ? m : p.M - 1;
+            const __half* av = q.ln_add + (long long)(m / q.ln_add_rpv) * F_C;
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) addv[kt][e] = *(const half8*)(av + (kt * 8 + part * 2 + e) * 8);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int r = tid >> 2, part = tid & 3;
-        half8 xv[5][2];
         float sa = 0.f, sb = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
             for (int e = 0; e < 2; ++e)
                 xv[kt][e] = *(const half8*)(smem_raw + kt * 16384 + r * 128 + (((part * 2 + e) ^ (r & 7)) << 4));
+        if (q.ln_add) {       // norm_in of the temporal block normalises hidden + frame-position embedding (attention.py:500-507)
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) xv[kt][e] = xv[kt][e] + addv[kt][e];   // fp16 add, as k_layernorm
+        }
 #pragma unroll
         for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
@@ -1607,7 +1630,7 @@ __global__ void __launch_bounds__(512, 2) k_ffn320(FfnParams q) {
 #undef FSTAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // every wavefront is done with the tiles before the epilogue reuses the LDS
-    gemm_epilogue<1>(p, acc, smem_raw, lane, wv, wm, wn, m0, 0, 0);
+    gemm_epilogue<1, true>(p, acc, smem_raw, lane, wv, wm, wn, m0, 0, 0);
 }
 
 int launch_ffn320(const FfnParams& q, hipStream_t stream) {
@@ -2115,7 +2138,8 @@ extern "C" int syn3r_feedforward_f16(const void* x, long long ldx, const void* w
 namespace {
 int feedforward_fused(const void* x, long long ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* w1_chunked,
                       const void* b1_chunked, int D, const void* w2, const void* b2, void* out, long long ldc, const void* residual,
-                      long long ldr, const void* aux, long long ldaux, float s_acc, float s_res, float s_aux, int M, int C, void* stream);
+                      long long ldr, const void* aux, long long ldaux, float s_acc, float s_res, float s_aux, int M, int C, void* stream,
+                      const void* addvec = nullptr, int rows_per_vec = 0);
 }
 extern "C" int syn3r_feedforward_fused_f16(const void* x, long long ldx, const void* w1_chunked, const void* b1_chunked,
                                            int D, const void* w2, const void* b2, void* out, long long ldc,
@@ -2134,10 +2158,23 @@ extern "C" int syn3r_feedforward_fused_ln_f16(const void* x, long long ldx, cons
     return feedforward_fused(x, ldx, ln_gamma, ln_beta, ln_eps, w1_chunked, b1_chunked, D, w2, b2, out, ldc, residual, ldr, aux, ldaux,
                              s_acc, s_res, s_aux, M, C, stream);
 }
+extern "C" int syn3r_feedforward_fused_addln_f16(const void* x, long long ldx, const void* addvec, int rows_per_vec, const void* ln_gamma,
+                                                 const void* ln_beta, float ln_eps, const void* w1_chunked, const void* b1_chunked, int D,
+                                                 const void* w2, const void* b2, void* out, long long ldc, const void* aux, long long ldaux,
+                                                 float s_acc, float s_res, float s_aux, int M, int C, void* stream) {
+    SYN3R_REQUIRE(ln_gamma && ln_beta && addvec, "feedforward_fused_addln_f16: null LayerNorm parameters / add vector");
+    SYN3R_REQUIRE(((uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)addvec) % 16 == 0, "feedforward_fused_addln_f16: LayerNorm parameters and the add vector must be 16-byte aligned");
+    SYN3R_REQUIRE(ln_eps > 0.f, "feedforward_fused_addln_f16: eps must be positive");
+    SYN3R_REQUIRE(rows_per_vec > 0, "feedforward_fused_addln_f16: rows_per_vec=%d must be positive", rows_per_vec);
+    // the residual of this entry IS x + addvec (the tensor the reference keeps as `residual` before norm_in)
+    return feedforward_fused(x, ldx, ln_gamma, ln_beta, ln_eps, w1_chunked, b1_chunked, D, w2, b2, out, ldc, x, ldx, aux, ldaux,
+                             s_acc, s_res, s_aux, M, C, stream, addvec, rows_per_vec);
+}
 namespace {
 int feedforward_fused(const void* x, long long ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* w1_chunked,
                       const void* b1_chunked, int D, const void* w2, const void* b2, void* out, long long ldc, const void* residual,
-                      long long ldr, const void* aux, long long ldaux, float s_acc, float s_res, float s_aux, int M, int C, void* stream) {
+                      long long ldr, const void* aux, long long ldaux, float s_acc, float s_res, float s_aux, int M, int C, void* stream,
+                      const void* addvec, int rows_per_vec) {
     SYN3R_REQUIRE(x && w1_chunked && b1_chunked && w2 && out, "feedforward_fused_f16: null operand");
     SYN3R_REQUIRE(C == F_C, "feedforward_fused_f16: the fused kernel is built for C = %d channels (got %d): use syn3r_feedforward_f16", F_C, C);
     SYN3R_REQUIRE(M > 0 && D >= F_HC && D % F_HC == 0, "feedforward_fused_f16: bad sizes M=%d D=%d (D must be a multiple of %d)", M, D, F_HC);
@@ -2148,6 +2185,7 @@ int feedforward_fused(const void* x, long long ldx, const void* ln_gamma, const 
     p.s_acc = s_acc; p.s_res = s_res; p.s_aux = s_aux; p.M = M; p.N = F_C; p.K = D;
     q.w1 = (const __half*)w1_chunked; q.b1 = (const __half*)b1_chunked; q.D = D;
     q.ln_g = (const __half*)ln_gamma; q.ln_b = (const __half*)ln_beta; q.ln_eps = ln_eps;
+    q.ln_add = (const __half*)addvec; q.ln_add_rpv = rows_per_vec; p.res_add = (const __half*)addvec; p.res_add_rpv = rows_per_vec;
     int rc = check_common(p, "feedforward_fused_f16");
     if (rc) return rc;
     SYN3R_REQUIRE(ldx % 8 == 0 && ldx >= C, "feedforward_fused_f16: ldx=%lld must be >= C and a multiple of 8", ldx);

@@ -845,12 +845,23 @@ struct Run {
             hs = f2;
         }
         // TemporalBasicTransformerBlock on hs + emb
-        T hmix;
-        T nin = layernorm(hs, t + ".norm_in", emb, HW, &hmix);
-        Epi e0; e0.residual = &hmix;
-        T tt = ff(t + ".ff_in", nin, "", e0);
-        drop(nin);
-        drop(hmix);
+        T tt;
+        if (m.ff_ln && m.w.count(t + ".ff_in.net.0.proj.geglu_cw")) {          // C = 320: add, norm_in, ff_in and + residual in one kernel
+            tt = make(hs.rows, hs.cols);
+            const Wt* w0 = W(t + ".ff_in.net.0.proj.weight");
+            if (go())
+                chk(syn3r_feedforward_fused_addln_f16(hs.p, hs.cols, emb, HW, Wp(t + ".norm_in.weight"), Wp(t + ".norm_in.bias"), 1e-5f,
+                                                      Wp(t + ".ff_in.net.0.proj.geglu_cw"), Wp(t + ".ff_in.net.0.proj.geglu_cb"), w0 ? (int)(w0->rows / 2) : 0,
+                                                      Wp(t + ".ff_in.net.2.weight"), Wp(t + ".ff_in.net.2.bias"), tt.p, tt.cols, nullptr, 0, 1.f, 1.f, 0.f,
+                                                      (int)hs.rows, hs.cols, stream));
+        } else {
+            T hmix;
+            T nin = layernorm(hs, t + ".norm_in", emb, HW, &hmix);
+            Epi e0; e0.residual = &hmix;
+            tt = ff(t + ".ff_in", nin, "", e0);
+            drop(nin);
+            drop(hmix);
+        }
         {
             T n1 = layernorm(tt, t + ".norm1");
             T qkv = linear(n1, t + ".attn1.qkv", "");

@@ -398,17 +398,24 @@ class UNetSpatioTemporalConditionModel:
             cache[pre] = out
         return out
 
-    def _ff(self, pre: str, x: torch.Tensor, norm: Optional[str] = None, **epilogue) -> torch.Tensor:
+    def _ff(self, pre: str, x: torch.Tensor, norm: Optional[str] = None, addvec: Optional[tuple] = None, **epilogue) -> torch.Tensor:
         """FeedForward of block `pre` on x; `norm` = the LayerNorm (parameter prefix) that precedes it in the reference
-        (attention.py:376-392, 519-530): applied inside the fused kernel at C = 320, as its own launch otherwise."""
+        (attention.py:376-392, 519-530): applied inside the fused kernel at C = 320, as its own launch otherwise.
+        addvec = (vec, rows_per_vec): x + vec[row // rows_per_vec] is what `norm` normalises and what is added back as the
+        residual (norm_in / ff_in, attention.py:500-517): also inside the fused kernel at C = 320."""
         D = self.p.shapes[pre + ".net.0.proj.weight"][0] // 2
         cw = self.packed.get(pre + ".net.0.proj.geglu_cw")
+        fuse = os.environ.get("SYN3R_FF_LN") != "0"
+        if addvec is not None and not (cw is not None and fuse):         # the sum as a tensor, then the plain path
+            x, hmix = ops.layernorm(x, self.w(norm + ".weight"), self.w(norm + ".bias"), addvec=addvec[0], rows_per_vec=addvec[1],
+                                    want_sum=True)
+            norm, addvec, epilogue = None, None, dict(epilogue, residual=hmix)
         if cw is not None:               # C = 320: one kernel, neither the normalised nor the hidden activation in HBM
-            ln = (self.w(norm + ".weight"), self.w(norm + ".bias"), 1e-5) if norm and os.environ.get("SYN3R_FF_LN") != "0" else None
+            ln = (self.w(norm + ".weight"), self.w(norm + ".bias"), 1e-5) if norm and fuse else None
             if norm and ln is None:
                 x = ops.layernorm(x, self.w(norm + ".weight"), self.w(norm + ".bias"))
             return ops.feedforward_fused(x, cw, self.packed[pre + ".net.0.proj.geglu_cb"], D, self.w(pre + ".net.2.weight"),
-                                         self.w(pre + ".net.2.bias"), ln=ln, **epilogue)
+                                         self.w(pre + ".net.2.bias"), ln=ln, addvec=addvec, **epilogue)
         if norm:
             x = ops.layernorm(x, self.w(norm + ".weight"), self.w(norm + ".bias"))
         wp = self.w(pre + ".net.0.proj.geglu_w")
@@ -444,9 +451,7 @@ class UNetSpatioTemporalConditionModel:
         hs = self._ff(b + ".ff", hs, norm=b + ".norm3", residual=hs)
         # TemporalBasicTransformerBlock (attention.py:478-533) on hs + emb
         t = pre + ".temporal_transformer_blocks.0"
-        nin, hmix = ops.layernorm(hs, W(t + ".norm_in.weight"), W(t + ".norm_in.bias"), addvec=emb, rows_per_vec=HW,
-                                  want_sum=True)
-        tt = self._ff(t + ".ff_in", nin, residual=hmix)
+        tt = self._ff(t + ".ff_in", hs, norm=t + ".norm_in", addvec=(emb, HW))       # ff_in(norm_in(hs + emb)) + (hs + emb)
         n1 = ops.layernorm(tt, W(t + ".norm1.weight"), W(t + ".norm1.bias"))
         a1 = ops.attention_temporal(ops.linear(n1, W(t + ".attn1.qkv")), B, F, HW, heads)
         # The reference lays the first-frame context out pixel-major / batch-minor

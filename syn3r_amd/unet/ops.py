@@ -144,11 +144,14 @@ FUSED_FF_CHANNELS = 320      # syn3r_feedforward_fused_f16 is built for this wid
 def feedforward_fused(x: torch.Tensor, w1_chunked: torch.Tensor, b1_chunked: torch.Tensor, D: int, w2: torch.Tensor,
                       b2: Optional[torch.Tensor] = None, *, residual: Optional[torch.Tensor] = None,
                       aux: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0, s_aux: float = 1.0,
-                      ln: Optional[tuple] = None) -> torch.Tensor:
+                      ln: Optional[tuple] = None, addvec: Optional[tuple] = None) -> torch.Tensor:
     """FeedForward.forward (attention.py:608-665) in ONE kernel for C = 320: geglu(x @ W1^T + b1) @ W2^T + b2 with the
     `linear` epilogue; the hidden activation never leaves the CU (syn3r_feedforward_fused_f16).
     ln = (gamma, beta, eps): x is LayerNorm'ed inside the kernel first (norm3 -> ff, attention.py:376-392; equal bit for bit
-    to `layernorm` followed by this call; syn3r_feedforward_fused_ln_f16)."""
+    to `layernorm` followed by this call; syn3r_feedforward_fused_ln_f16).
+    addvec = (vec [rows, C], rows_per_vec), with ln: x + vec[row // rows_per_vec] (fp16 tensor add) is what gets normalised AND the
+    residual (norm_in / ff_in of the temporal block, attention.py:500-517; `residual` must be left None;
+    syn3r_feedforward_fused_addln_f16)."""
     dev = _chk(w1_chunked, b1_chunked, w2, b2, residual, aux)
     L.require_gpu(x)
     M, K = x.shape
@@ -160,11 +163,22 @@ def feedforward_fused(x: torch.Tensor, w1_chunked: torch.Tensor, b1_chunked: tor
             residual.data_ptr() if residual is not None else None, residual.stride(0) if residual is not None else 0,
             aux.data_ptr() if aux is not None else None, aux.stride(0) if aux is not None else 0,
             float(s_acc), float(s_res), float(s_aux), M, K, L.stream_ptr(dev))
+    if addvec is not None and (ln is None or residual is not None):
+        raise ValueError("feedforward_fused: addvec needs ln and takes the place of the residual")
     if ln is not None:
         gamma, beta, eps = ln
         _chk(gamma, beta)
         if gamma.numel() != K or beta.numel() != K:
             raise ValueError(f"feedforward_fused: LayerNorm parameters of {gamma.numel()} / {beta.numel()} channels for C = {K}")
+    if addvec is not None:
+        vec, rpv = addvec
+        _chk(vec)
+        if vec.dim() != 2 or vec.shape[1] != K or not vec.is_contiguous() or rpv <= 0 or (M + rpv - 1) // rpv > vec.shape[0]:
+            raise ValueError(f"feedforward_fused: add vector {tuple(vec.shape)} / rows_per_vec={rpv} for x {tuple(x.shape)}")
+        rc = L.load().syn3r_feedforward_fused_addln_f16(x.data_ptr(), x.stride(0), L.ptr(vec), int(rpv), L.ptr(gamma), L.ptr(beta), float(eps),
+                                                        *tail[:7], *tail[9:])
+        L.check(rc, "syn3r_feedforward_fused_addln_f16")
+    elif ln is not None:
         rc = L.load().syn3r_feedforward_fused_ln_f16(x.data_ptr(), x.stride(0), L.ptr(gamma), L.ptr(beta), float(eps), *tail)
         L.check(rc, "syn3r_feedforward_fused_ln_f16")
     else:

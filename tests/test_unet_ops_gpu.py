@@ -677,3 +677,33 @@ def test_linear_cat_split_k(M, K1, K2, N, gpu):
     ref = torch.cat([x1, x2], 1).float() @ w.float().T + b.float()
     close(split, ref)
     assert (split.float() - one.float()).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M,D,rpv", [(128, 64, 32), (700, 1280, 144), (4097, 1280, 1000), (9216 * 2 + 5, 1280, 9216)])
+def test_feedforward_fused_add_layernorm_c320(M, D, rpv, gpu):
+    """(hidden + frame embedding) -> norm_in -> ff_in -> + (hidden + embedding) in one kernel
+    (syn3r_feedforward_fused_addln_f16; attention.py:500-517): bit for bit the LayerNorm launch with the add vector (which
+    also writes the sum) followed by the fused feed-forward with that sum as its residual; ragged M, strided x, aux + scales."""
+    from syn3r_amd.unet import ops
+    C = 320
+    g = torch.Generator().manual_seed(M + D + rpv)
+    wide = rnd(g, M, 2 * C, dev=gpu)
+    x = wide[:, C // 2:C // 2 + C]
+    vec = rnd(g, (M + rpv - 1) // rpv, C, dev=gpu)
+    ga, be = (1.0 + 0.2 * rnd(g, C, dev=gpu).float()).half(), (0.1 * rnd(g, C, dev=gpu).float()).half()
+    w1, b1 = rnd(g, 2 * D, C, scale=C ** -0.5, dev=gpu), rnd(g, 2 * D, dev=gpu)
+    w2, b2 = rnd(g, C, D, scale=D ** -0.5, dev=gpu), rnd(g, C, dev=gpu)
+    aux = rnd(g, M, C, dev=gpu)
+    wc, bc, _ = ops.pack_geglu_chunked(w1, b1)
+    n, xs = ops.layernorm(x.contiguous(), ga, be, addvec=vec, rows_per_vec=rpv, want_sum=True)
+    assert torch.equal(xs, x + vec.repeat_interleave(rpv, 0)[:M])
+    for kw in ({}, {"aux": aux, "s_acc": 0.4, "s_res": 0.6, "s_aux": 0.25}):
+        two = ops.feedforward_fused(n, wc, bc, D, w2, b2, residual=xs, **kw)
+        one = ops.feedforward_fused(x, wc, bc, D, w2, b2, ln=(ga, be, 1e-5), addvec=(vec, rpv), **kw)
+        assert torch.equal(one, two), (one.float() - two.float()).abs().max().item()
+    with pytest.raises(ValueError):
+        ops.feedforward_fused(x, wc, bc, D, w2, b2, addvec=(vec, rpv))                                  # no LayerNorm
+    with pytest.raises(ValueError):
+        ops.feedforward_fused(x, wc, bc, D, w2, b2, ln=(ga, be, 1e-5), addvec=(vec, rpv), residual=aux)   # the sum IS the residual
+    with pytest.raises(ValueError):
+        ops.feedforward_fused(x, wc, bc, D, w2, b2, ln=(ga, be, 1e-5), addvec=(vec[:-1], rpv))          # too few vectors
