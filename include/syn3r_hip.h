@@ -385,6 +385,17 @@ int syn3r_feedforward_fused_addln_f16(const void* x, long long ldx, const void* 
                                       float s_acc, float s_res, float s_aux, int M, int C, void* stream);
 
 /*
+ * LayerNorm + bias-free projection in ONE kernel for C = 320: `norm1(hidden_states)` followed by `attn1.to_q / to_k / to_v`
+ * (attention.py:340-352 and 509-512; attention_processor.py to_q / to_k / to_v, stored here as one [960, 320] matrix) of the
+ * level-0 transformer blocks.  out [M, N] = LayerNorm(x [M, 320]; ln_gamma, ln_beta, ln_eps) . W[N, 320]^T, N a multiple of 320.
+ * The x tile of a block stays on chip (normalised there with the arithmetic of syn3r_layernorm_f16, so the normalised values
+ * are the ones that launch would have written), the normalised activation is never written to memory.  Same fp32 accumulation
+ * order along K as syn3r_gemm_f16.  Other channel counts are rejected (SYN3R_E_INVALID): syn3r_layernorm_f16 + syn3r_gemm_f16.
+ */
+int syn3r_layernorm_linear320_f16(const void* x, long long ldx, const void* ln_gamma, const void* ln_beta, float ln_eps,
+                                  const void* W, void* out, long long ldc, int M, int N, int C, void* stream);
+
+/*
  * 3x3 Conv2d on NHWC fp16 (resnet.py:274,290; downsampling.py:116-148 with stride 2;
  * upsampling.py:172-183 with upsample != 0: nearest-2x of the input fused into the gather).
  * pad_lo = 1: padding 1 on every side.  pad_lo = 0: the VAE encoder's Downsample2D(padding=0), which pads

@@ -75,6 +75,7 @@ SIGNATURES = {
                                              c_f, c_f, c_f, c_i, c_i, c_p]),
     "syn3r_feedforward_fused_addln_f16": (c_i, [c_p, c_ll, c_p, c_i, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_p, c_ll, c_p, c_ll,
                                                 c_f, c_f, c_f, c_i, c_i, c_p]),
+    "syn3r_layernorm_linear320_f16": (c_i, [c_p, c_ll, c_p, c_p, c_f, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
     "syn3r_conv2d3x3_f16": (c_i, [c_p, c_p, c_p, c_ll, c_p, c_p, c_ll, c_i, c_p, c_ll, c_f, c_f,
                                   c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "syn3r_tconv3_f16": (c_i, [c_p, c_p, c_p, c_ll, c_p, c_p, c_ll, c_i, c_p, c_ll, c_f, c_f,

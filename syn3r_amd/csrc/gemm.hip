@@ -1366,6 +1366,79 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 #define DS_READ64(dst, addr, OFF) asm volatile("ds_read_b64 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
 #define DS_WRITE64(addr, val) asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(val) : "memory")
 
+// LayerNorm of a resident [128 x 320] x tile (five [128 x 64] k-tile images, 16-byte chunk index XOR-swizzled by the row) in
+// place, by all 512 threads of the block; waits for the tile's DMA first.  Shared by k_ffn320 and k_lnlin320.
+__device__ __forceinline__ void ln_tile320(char* smem_raw, int tid, int m0, int M, float cf, const __half* ln_g, const __half* ln_b,
+                                           float ln_eps, const __half* add, int add_rpv) {
+    // LayerNorm of the resident x tile (attention.py:430-453: norm3 in front of ff), so that the normalised activation is never
+    // written to / re-read from HBM.  Same arithmetic, same order of additions as k_layernorm<8> (norm.hip): 8 partial sums per
+    // row over the 16-byte chunks c, c + 8, ..., combined by the xor tree 4, 2, 1 - here four threads per row hold two of the
+    // eight each.  The tile is five [128 x 64] k-tile images with the chunk index XOR-swizzled by the row.
+    {
+        const int r = tid >> 2, part = tid & 3;
+        half8 xv[5][2], addv[5][2];
+        if (add) {       // requested before the wait for the x tile: one latency, not two
+            int m = m0 + r;
+            m = m < M ? m : M - 1;
+            const __half* av = add + (long long)(m / add_rpv) * F_C;
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) addv[kt][e] = *(const half8*)(av + (kt * 8 + part * 2 + e) * 8);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                xv[kt][e] = *(const half8*)(smem_raw + kt * 16384 + r * 128 + (((part * 2 + e) ^ (r & 7)) << 4));
+        if (add) {       // norm_in of the temporal block normalises hidden + frame-position embedding (attention.py:500-507)
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) xv[kt][e] = xv[kt][e] + addv[kt][e];   // fp16 add, as k_layernorm
+        }
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sa += (float)xv[kt][0][i]; sb += (float)xv[kt][1][i]; }
+        sa += __shfl_xor(sa, 2, 64); sb += __shfl_xor(sb, 2, 64);
+        sa += __shfl_xor(sa, 1, 64); sb += __shfl_xor(sb, 1, 64);
+        // cf = 320 as a run-time value: the same division k_layernorm compiles to
+        const float mean = (sa + sb) / cf;
+        float qa = 0.f, qb = 0.f;
+        {
+#pragma clang fp contract(off)      // k_layernorm's squares are a packed multiply followed by adds, not an fma: the same bits here
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float da = (float)xv[kt][0][i] - mean, db = (float)xv[kt][1][i] - mean;
+                    const float da2 = da * da, db2 = db * db;
+                    qa += da2; qb += db2;
+                }
+        }
+        qa += __shfl_xor(qa, 2, 64); qb += __shfl_xor(qb, 2, 64);
+        qa += __shfl_xor(qa, 1, 64); qb += __shfl_xor(qb, 1, 64);
+        const float rstd = rsqrtf((qa + qb) / cf + ln_eps);
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int cv = kt * 8 + part * 2 + e;
+                const half8 g = *(const half8*)(ln_g + cv * 8), b = *(const half8*)(ln_b + cv * 8);
+                half8 o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = (_Float16)(((float)xv[kt][e][i] - mean) * rstd * (float)g[i] + (float)b[i]);
+                *(half8*)(smem_raw + kt * 16384 + r * 128 + (((part * 2 + e) ^ (r & 7)) << 4)) = o;
+            }
+        __syncthreads();
+    }
+
+}
+
 __global__ void __launch_bounds__(512, 2) k_ffn320(FfnParams q) {
     const GemmParams& p = q.e;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1425,71 +1498,8 @@ __global__ void __launch_bounds__(512, 2) k_ffn320(FfnParams q) {
     issue_next();
 
     // LayerNorm of the resident x tile (attention.py:430-453: norm3 in front of ff), so that the normalised activation is never
-    // written to / re-read from HBM.  Same arithmetic, same order of additions as k_layernorm<8> (norm.hip): 8 partial sums per
-    // row over the 16-byte chunks c, c + 8, ..., combined by the xor tree 4, 2, 1 - here four threads per row hold two of the
-    // eight each.  The tile is five [128 x 64] k-tile images with the chunk index XOR-swizzled by the row.
-    if (q.ln_g) {
-        const int r = tid >> 2, part = tid & 3;
-        half8 xv[5][2], addv[5][2];
-        if (q.ln_add) {       // requested before the wait for the x tile: one latency, not two
-            int m = m0 + r;
-            m = m < p.M ? m : p.M - 1;
-            const __half* av = q.ln_add + (long long)(m / q.ln_add_rpv) * F_C;
-#pragma unroll
-            for (int kt = 0; kt < 5; ++kt)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) addv[kt][e] = *(const half8*)(av + (kt * 8 + part * 2 + e) * 8);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        float sa = 0.f, sb = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 5; ++kt)
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-                xv[kt][e] = *(const half8*)(smem_raw + kt * 16384 + r * 128 + (((part * 2 + e) ^ (r & 7)) << 4));
-        if (q.ln_add) {       // norm_in of the temporal block normalises hidden + frame-position embedding (attention.py:500-507)
-#pragma unroll
-            for (int kt = 0; kt < 5; ++kt)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) xv[kt][e] = xv[kt][e] + addv[kt][e];   // fp16 add, as k_layernorm
-        }
-#pragma unroll
-        for (int kt = 0; kt < 5; ++kt)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { sa += (float)xv[kt][0][i]; sb += (float)xv[kt][1][i]; }
-        sa += __shfl_xor(sa, 2, 64); sb += __shfl_xor(sb, 2, 64);
-        sa += __shfl_xor(sa, 1, 64); sb += __shfl_xor(sb, 1, 64);
-        const float cf = (float)p.N;               // = 320, as a run-time value: the same division k_layernorm compiles to
-        const float mean = (sa + sb) / cf;
-        float qa = 0.f, qb = 0.f;
-        {
-#pragma clang fp contract(off)      // k_layernorm's squares are a packed multiply followed by adds, not an fma: the same bits here
-#pragma unroll
-            for (int kt = 0; kt < 5; ++kt)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float da = (float)xv[kt][0][i] - mean, db = (float)xv[kt][1][i] - mean;
-                    const float da2 = da * da, db2 = db * db;
-                    qa += da2; qb += db2;
-                }
-        }
-        qa += __shfl_xor(qa, 2, 64); qb += __shfl_xor(qb, 2, 64);
-        qa += __shfl_xor(qa, 1, 64); qb += __shfl_xor(qb, 1, 64);
-        const float rstd = rsqrtf((qa + qb) / cf + q.ln_eps);
-#pragma unroll
-        for (int kt = 0; kt < 5; ++kt)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int cv = kt * 8 + part * 2 + e;
-                const half8 g = *(const half8*)(q.ln_g + cv * 8), b = *(const half8*)(q.ln_b + cv * 8);
-                half8 o;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = (_Float16)(((float)xv[kt][e][i] - mean) * rstd * (float)g[i] + (float)b[i]);
-                *(half8*)(smem_raw + kt * 16384 + r * 128 + (((part * 2 + e) ^ (r & 7)) << 4)) = o;
-            }
-        __syncthreads();
-    }
+    // written to / re-read from HBM
+    if (q.ln_g) ln_tile320(smem_raw, tid, m0, p.M, (float)p.N, q.ln_g, q.ln_b, q.ln_eps, q.ln_add, q.ln_add_rpv);
 
     float4v acc[TM][TN];                  // out: 64 rows x 80 columns of this wavefront
 #pragma unroll
@@ -1648,6 +1658,197 @@ int launch_ffn320(const FfnParams& q, hipStream_t stream) {
     }
     SYN3R_LAUNCH_NAMED(name, k_ffn320, dim3(tiles), dim3(512), F_LDS, stream, q);
     SYN3R_LAUNCH_CHECK("ffn320 launch");
+    return SYN3R_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm + bias-free projection for C = 320 in ONE kernel: `norm1(hidden_states)` -> `attn1.to_q / to_k / to_v` of the level-0
+// transformer blocks (attention.py:340-352, 509-512; the three projections are stored as one [960, 320] matrix).  The two-launch
+// path writes the normalised activation ([M, 320] fp16) and reads it back, and its contraction (K = 320: five k-tiles per tile,
+// k_gemm_w128) runs at a quarter of the matrix peak.  Here, as in k_ffn320, a block owns 128 rows: the x tile (80 KB) is DMA'd
+// into LDS once, normalised in place (ln_tile320: the arithmetic of k_layernorm<8>), and the output columns are walked in chunks
+// of 320 - the weight chunk streams through a FOUR-slot ring in [320 x 32] stages (20 KB; 20 MFMAs per wavefront and barrier),
+// eight wavefronts (2 x 4) of 64 rows x 80 columns each.  The fragments are double-buffered in registers: a stage's LDS reads are
+// issued one stage ahead (right behind the barrier that certifies its DMA), so they run under the previous stage's MFMAs - with
+// one barrier per stage the two wavefronts of a SIMD are in lockstep and would otherwise read together, then multiply together
+// (measured: 1 200-1 450 cycles per stage for 640 of matrix work).  The epilogue needs no LDS: two v_permlane16_swap per pair of
+// accumulator tiles give every lane eight consecutive columns, i.e. one 16-byte store per pair (64-byte row segments).
+// LDS: x 80 KB | ring 4 x 20 KB = 163,840 B.
+constexpr int Q_SLOT = F_C * 32 * 2;                  // 20,480: [320 rows x 32 k] of the weight chunk, 64-byte rows
+constexpr int Q_RING = F_X_BYTES;
+constexpr int Q_SLOTS = 4;
+constexpr int Q_LDS = Q_RING + Q_SLOTS * Q_SLOT;      // 163,840
+
+struct LnLinParams {
+    const __half* x; long long ldx;      // [M, 320]
+    const __half* W;                     // [N, 320], N a multiple of 320
+    __half* out; long long ldc;          // [M, N]
+    int M, N, C;                         // C = 320 (run-time copy: the LayerNorm's divisor)
+    const __half* ln_g; const __half* ln_b; float ln_eps;
+};
+
+__global__ void __launch_bounds__(512, 2) k_lnlin320(LnLinParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 2, wn = wv & 3;
+    const int tiles_m = (p.M + F_BM - 1) / F_BM;
+    const int m0 = (int)xcd_remap(blockIdx.x, (unsigned)tiles_m) * F_BM;
+    const int nstage = (p.N / F_C) * 10;
+    const bool full = m0 + F_BM <= p.M;               // every output store of the block is issued: exact vmcnt bookkeeping
+
+    // weight stage DMA: a wave-instruction moves 16 rows x 64 B; lane -> (row, 16-byte slot), source chunk swizzled (h_swz)
+    const int wprow = lane >> 2;
+    const int wcsrc = (lane & 3) ^ h_swz(wprow);
+    const int nbw = wv < 4 ? 3 : 2;
+    const int b_first = wv < 4 ? wv * 3 : 12 + (wv - 4) * 2;
+    const __half* w_lane = p.W + (long long)(b_first * 16 + wprow) * F_C + wcsrc * 8;
+    char* const ring = smem_raw + Q_RING;
+    int ig = 0, islot = 0;
+    auto issue_next = [&]() {
+        if (ig >= nstage) return;
+        const int c = ig / 10, ks = ig - c * 10;
+#ifdef SYN3R_Q_NODMA       // timing experiment (wrong results): the weight stream stops after the first stages
+        if (ig >= Q_SLOTS) { ++ig; if (++islot == Q_SLOTS) islot = 0; return; }
+#endif
+        const __half* src = w_lane + (long long)c * (F_C * F_C) + ks * 32;
+        char* slot = ring + islot * Q_SLOT;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < nbw)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + i * 16 * F_C), (lds_void_t*)(slot + (b_first + i) * 1024), 16, 0, 0);
+        ++ig;
+        if (++islot == Q_SLOTS) islot = 0;
+    };
+
+    // ---- prologue: the x tile (as k_ffn320) and the first three weight stages, then the LayerNorm in place
+    {
+        const int prow = lane >> 3;
+        const int csrc = (lane & 7) ^ prow;
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int m = m0 + (wv * 2 + i) * 8 + prow;
+                m = m < p.M ? m : p.M - 1;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(p.x + (long long)m * p.ldx + kt * BK + csrc * 8),
+                                                 (lds_void_t*)(smem_raw + kt * 16384 + (wv * 2 + i) * 1024), 16, 0, 0);
+            }
+    }
+    issue_next();
+    issue_next();
+    issue_next();
+#ifdef SYN3R_Q_NOLN
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#else
+    ln_tile320(smem_raw, tid, m0, p.M, (float)p.C, p.ln_g, p.ln_b, p.ln_eps, nullptr, 1);   // waits for every DMA above, ends on a barrier
+#endif
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const unsigned sw0 = (unsigned)(((0 + fq) ^ (fr & 7)) << 4), sw1 = (unsigned)(((4 + fq) ^ (fr & 7)) << 4);
+    const unsigned x_row = lds0 + (unsigned)((wm * 64 + fr) * 128);                       // + kt * 16384 + i * 2048 + sw
+    const unsigned w_row = lds0 + Q_RING + (unsigned)((wn * 80 + fr) * 64) + (unsigned)((fq ^ h_swz(fr)) << 4);   // + slot * Q_SLOT + j * 1024
+    typedef _Float16 half4e __attribute__((ext_vector_type(4)));
+
+    half8 a[2][TM], b[2][TN];
+#define Q_READS(BUF, KS, SLOT)                                                                                           \
+    {                                                                                                                    \
+        const unsigned xa_ = x_row + (unsigned)(((KS) >> 1) * 16384) + (((KS) & 1) ? sw1 : sw0);                         \
+        const unsigned wa_ = w_row + (unsigned)((SLOT) * Q_SLOT);                                                        \
+        DS_READ128(a[BUF][0], xa_, 0); DS_READ128(a[BUF][1], xa_, 2048); DS_READ128(a[BUF][2], xa_, 4096); DS_READ128(a[BUF][3], xa_, 6144); \
+        DS_READ128(b[BUF][0], wa_, 0); DS_READ128(b[BUF][1], wa_, 1024); DS_READ128(b[BUF][2], wa_, 2048); DS_READ128(b[BUF][3], wa_, 3072); \
+        DS_READ128(b[BUF][4], wa_, 4096);                                                                                \
+    }
+#define Q_MFMA(BUF, J)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[BUF][J], a[BUF][i], acc[i][J], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);
+
+    int rslot = 1, g = 0;                 // rslot: ring slot of stage g + 1
+    Q_READS(0, 0, 0);                     // stage 0 (landed: the LayerNorm waited for it)
+    const int nchunks = p.N / F_C;
+    for (int c = 0; c < nchunks; ++c) {
+        float4v acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks, ++g) {
+            const bool more = g + 1 < nstage;
+            if (more) {
+                // Stage g + 1 has landed once only what was issued AFTER its DMA is still in flight (vmcnt retires in order): DMA
+                // g + 2 (3 or 2 instructions per wavefront) and, in the first two stages after a chunk's stores (10 per wavefront;
+                // a block with rows past M may skip store instructions and counts none: it then waits for the stores too), those.
+                const bool after = g + 2 < nstage;
+                if (ks < 2 && c > 0 && full) {
+                    if (wv < 4) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                } else if (after) {
+                    if (wv < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();     // ... for every wavefront's pieces; and every wavefront is past the MFMAs of stage g - 1
+                if (ks & 1) { Q_READS(0, (ks + 1) % 10, rslot); } else { Q_READS(1, (ks + 1) % 10, rslot); }
+                if (++rslot == Q_SLOTS) rslot = 0;
+                issue_next();                     // stage g + 3 into the slot of stage g - 1
+                if (ks & 1) asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]), "+v"(b[1][4]));
+                else asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[0][4]));
+            } else {
+                if (ks & 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]), "+v"(b[1][4]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[0][4]));
+            }
+            if (ks & 1) { Q_MFMA(1, 0) Q_MFMA(1, 1) Q_MFMA(1, 2) Q_MFMA(1, 3) Q_MFMA(1, 4) }
+            else { Q_MFMA(0, 0) Q_MFMA(0, 1) Q_MFMA(0, 2) Q_MFMA(0, 3) Q_MFMA(0, 4) }
+        }
+        // ---- the chunk's 64 x 80 block of this wavefront, straight from the accumulators (acc[i][j][r] = C[row i*16 + (lane & 15)]
+        // [col j*16 + (lane >> 4)*4 + r]): for a pair of tiles (X, Y), v_permlane16_swap leaves the even 16-lane rows with columns
+        // fq*4 .. fq*4 + 7 of X and the odd rows with columns (fq-1)*4 .. + 7 of Y - one 16-byte store per lane and pair
+        __half* const obase = p.out + (long long)c * F_C + wn * WN;
+        auto store_pair = [&](const float4v& X, const float4v& Y, int rowX, int colX, int rowY, int colY) {
+            union { half4e h; unsigned u[2]; } x, y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x.h[r] = (_Float16)X[r]; y.h[r] = (_Float16)Y[r]; }
+            const auto r0 = __builtin_amdgcn_permlane16_swap(x.u[0], y.u[0], false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(x.u[1], y.u[1], false, false);
+            union { half8 h; unsigned u[4]; } o;
+            o.u[0] = r0[0]; o.u[1] = r1[0]; o.u[2] = r0[1]; o.u[3] = r1[1];
+            const int row = (fq & 1) ? rowY : rowX, col = ((fq & 1) ? colY : colX) + (fq >> 1) * 8;
+            const int m = m0 + wm * WM + row + fr;
+#ifndef SYN3R_Q_NOSTORE
+            if (m < p.M) *(half8*)(obase + (long long)m * p.ldc + col) = o.h;
+#else
+            if (m < -1) *(half8*)(obase + (long long)m * p.ldc + col) = o.h;
+#endif
+        };
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            store_pair(acc[i][0], acc[i][1], i * 16, 0, i * 16, 16);
+            store_pair(acc[i][2], acc[i][3], i * 16, 32, i * 16, 48);
+        }
+        store_pair(acc[0][4], acc[1][4], 0, 64, 16, 64);
+        store_pair(acc[2][4], acc[3][4], 32, 64, 48, 64);
+    }
+#undef Q_READS
+#undef Q_MFMA
+}
+
+int launch_lnlin320(const LnLinParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_lnlin320, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(lnlin320)");
+        attr_set = true;
+    }
+    const int tiles = (p.M + F_BM - 1) / F_BM;
+    char name[96];
+    if (trace_on()) {
+        if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_lnlin320[M%d,N%d]", p.M, p.N);
+        else snprintf(name, sizeof(name), "k_gemm_lnlin320");
+    }
+    SYN3R_LAUNCH_NAMED(name, k_lnlin320, dim3(tiles), dim3(512), Q_LDS, stream, p);
+    SYN3R_LAUNCH_CHECK("lnlin320 launch");
     return SYN3R_OK;
 }
 
@@ -2193,6 +2394,21 @@ int feedforward_fused(const void* x, long long ldx, const void* ln_gamma, const 
     return launch_ffn320(q, (hipStream_t)stream);
 }
 }  // namespace
+
+extern "C" int syn3r_layernorm_linear320_f16(const void* x, long long ldx, const void* ln_gamma, const void* ln_beta, float ln_eps,
+                                             const void* W, void* out, long long ldc, int M, int N, int C, void* stream) {
+    SYN3R_REQUIRE(x && ln_gamma && ln_beta && W && out, "layernorm_linear320_f16: null operand");
+    SYN3R_REQUIRE(C == F_C, "layernorm_linear320_f16: the kernel is built for C = %d channels (got %d): use syn3r_layernorm_f16 + syn3r_gemm_f16", F_C, C);
+    SYN3R_REQUIRE(SYN3R_DIM_OK(M) && SYN3R_DIM_OK(N) && N % F_C == 0, "layernorm_linear320_f16: bad sizes M=%d N=%d (N must be a multiple of %d)", M, N, F_C);
+    SYN3R_REQUIRE(ldx % 8 == 0 && ldx >= C && ldc % 8 == 0 && ldc >= N, "layernorm_linear320_f16: bad strides ldx=%lld ldc=%lld", ldx, ldc);
+    SYN3R_REQUIRE(((uintptr_t)x | (uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)W | (uintptr_t)out) % 16 == 0, "layernorm_linear320_f16: operands must be 16-byte aligned");
+    SYN3R_REQUIRE(ln_eps > 0.f, "layernorm_linear320_f16: eps must be positive");
+    SYN3R_REQUIRE((long long)M * ldx < (1ll << 40) && (long long)M * ldc < (1ll << 40), "layernorm_linear320_f16: operand too large");
+    LnLinParams p{};
+    p.x = (const __half*)x; p.ldx = ldx; p.W = (const __half*)W; p.out = (__half*)out; p.ldc = ldc; p.M = M; p.N = N; p.C = C;
+    p.ln_g = (const __half*)ln_gamma; p.ln_b = (const __half*)ln_beta; p.ln_eps = ln_eps;
+    return launch_lnlin320(p, (hipStream_t)stream);
+}
 
 extern "C" int syn3r_conv2d3x3_f16(const void* X, const void* W, void* out, long long ldc, const void* bias,
                                    const void* rowvec, long long ldrv, int rows_per_vec, const void* residual,

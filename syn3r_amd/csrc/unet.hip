@@ -251,7 +251,7 @@ struct syn3r_unet {
     std::unordered_map<std::string, std::pair<int, int>> temb_slice;
     std::vector<std::string> temb_names;
     std::map<std::string, __half*> pos_cache;                           // frame-position embeddings per (block, F, B): functions of the weights only
-    bool ff_ln = true;
+    bool ff_ln = true, ln_qkv = true;
 };
 
 namespace {
@@ -508,6 +508,8 @@ extern "C" int syn3r_unet_create(const char* weights_dir, const char* variant, s
     }
     const char* e = getenv("SYN3R_FF_LN");
     m->ff_ln = !(e && !strcmp(e, "0"));
+    e = getenv("SYN3R_LN_QKV");
+    m->ln_qkv = !(e && !strcmp(e, "0"));
     *out = m.release();
     {
         std::lock_guard<std::mutex> lk(g_unet_mu);
@@ -685,6 +687,21 @@ struct Run {
             chk(syn3r_layernorm_f16(x.p, out.p, xsum ? xsum->p : nullptr, addvec, rows_per_vec, x.rows, x.cols, Wp(pre + ".weight"), Wp(pre + ".bias"), 1e-5f, stream));
         return out;
     }
+    // model.py:_norm_qkv - attn1's stacked q / k / v projection of norm1(x): one kernel at C = 320
+    T norm_qkv(const std::string& blk, const T& x) {
+        const Wt* wq = W(blk + ".attn1.qkv");
+        if (m.ln_qkv && x.cols == 320 && wq && wq->rows % 320 == 0) {
+            T out = make(x.rows, (int)wq->rows);
+            if (go())
+                chk(syn3r_layernorm_linear320_f16(x.p, x.cols, Wp(blk + ".norm1.weight"), Wp(blk + ".norm1.bias"), 1e-5f, wq->p, out.p, out.cols,
+                                                  (int)x.rows, (int)wq->rows, x.cols, stream));
+            return out;
+        }
+        T n1 = layernorm(x, blk + ".norm1");
+        T qkv = linear(n1, blk + ".attn1.qkv", "");
+        drop(n1);
+        return qkv;
+    }
     T attention(const T& qkv, int nseq, int S, int heads) {
         const int C = heads * 64;
         T out = make(qkv.rows, C);
@@ -828,9 +845,7 @@ struct Run {
         const __half* emb = pos_embedding(pre, ch);
         const std::string b = pre + ".transformer_blocks.0", t = pre + ".temporal_transformer_blocks.0";
         {   // BasicTransformerBlock
-            T n1 = layernorm(hs, b + ".norm1");
-            T qkv = linear(n1, b + ".attn1.qkv", "");
-            drop(n1);
+            T qkv = norm_qkv(b, hs);
             T a1 = attention(qkv, B * F, HW, heads);
             drop(qkv);
             const T& cv = cross_vec(b + ".attn2");
@@ -863,9 +878,7 @@ struct Run {
             drop(hmix);
         }
         {
-            T n1 = layernorm(tt, t + ".norm1");
-            T qkv = linear(n1, t + ".attn1.qkv", "");
-            drop(n1);
+            T qkv = norm_qkv(t, tt);
             T a1 = attention_temporal(qkv, HW, heads);
             drop(qkv);
             // the reference's batch-interleaved temporal context (transformer_temporal.py:310-317 vs attention.py:487-489): see model.py

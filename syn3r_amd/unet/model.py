@@ -425,6 +425,14 @@ class UNetSpatioTemporalConditionModel:
         return ops.feedforward(x, wp, self.w(pre + ".net.0.proj.geglu_b"), D, self.w(pre + ".net.2.weight"),
                                self.w(pre + ".net.2.bias"), **epilogue)
 
+    def _norm_qkv(self, blk: str, x: torch.Tensor) -> torch.Tensor:
+        """attn1's stacked q / k / v projection of norm1(x) (attention.py:340-352, 509-512): one kernel at C = 320
+        (SYN3R_LN_QKV=0: the two launches, tuning)."""
+        W = self.w
+        if os.environ.get("SYN3R_LN_QKV") == "0":
+            return ops.linear(ops.layernorm(x, W(blk + ".norm1.weight"), W(blk + ".norm1.bias")), W(blk + ".attn1.qkv"))
+        return ops.layernorm_linear(x, W(blk + ".norm1.weight"), W(blk + ".norm1.bias"), W(blk + ".attn1.qkv"))
+
     def _transformer(self, pre: str, x: torch.Tensor, st: dict, ch: int, heads: int) -> torch.Tensor:
         B, F, h, w_ = st["B"], st["F"], st["h"], st["w"]
         HW = h * w_
@@ -444,16 +452,14 @@ class UNetSpatioTemporalConditionModel:
             emb = self._pos_cache[ck] = e.repeat(B, 1).contiguous()        # [B*F, C]
         # BasicTransformerBlock (attention.py:283-403)
         b = pre + ".transformer_blocks.0"
-        n1 = ops.layernorm(hs, W(b + ".norm1.weight"), W(b + ".norm1.bias"))
-        a1 = ops.attention(ops.linear(n1, W(b + ".attn1.qkv")), B * F, HW, heads)
+        a1 = ops.attention(self._norm_qkv(b, hs), B * F, HW, heads)
         hs = ops.linear(a1, W(b + ".attn1.to_out.0.weight"), W(b + ".attn1.to_out.0.bias"), residual=hs,
                         rowvec=self._cross_vec(b + ".attn2", ehs, st["ctx_cache"]), rows_per_vec=(B if st["shared_ctx"] else 1) * F * HW)
         hs = self._ff(b + ".ff", hs, norm=b + ".norm3", residual=hs)
         # TemporalBasicTransformerBlock (attention.py:478-533) on hs + emb
         t = pre + ".temporal_transformer_blocks.0"
         tt = self._ff(t + ".ff_in", hs, norm=t + ".norm_in", addvec=(emb, HW))       # ff_in(norm_in(hs + emb)) + (hs + emb)
-        n1 = ops.layernorm(tt, W(t + ".norm1.weight"), W(t + ".norm1.bias"))
-        a1 = ops.attention_temporal(ops.linear(n1, W(t + ".attn1.qkv")), B, F, HW, heads)
+        a1 = ops.attention_temporal(self._norm_qkv(t, tt), B, F, HW, heads)
         # The reference lays the first-frame context out pixel-major / batch-minor
         # (transformer_temporal.py:310-317) while the temporal tokens are batch-major (attention.py:487-489):
         # token (b, pixel) reads the context of batch item (b*HW + pixel) mod B.  Reproduced, not fixed.

@@ -311,6 +311,26 @@ def linear_cat(x1: torch.Tensor, x2: torch.Tensor, weight: torch.Tensor, bias: O
     return out
 
 
+def layernorm_linear(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, weight: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """LayerNorm(x) @ weight^T (no bias) - norm1 followed by the stacked to_q / to_k / to_v projection (attention.py:340-352,
+    509-512).  At C = 320 with an output width that is a multiple of 320: ONE kernel, the normalised activation stays on chip
+    (syn3r_layernorm_linear320_f16); otherwise `layernorm` followed by `linear`."""
+    dev = _chk(gamma, beta, weight)
+    L.require_gpu(x)
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K or gamma.numel() != K or beta.numel() != K or x.stride(1) != 1:
+        raise ValueError(f"layernorm_linear: x {tuple(x.shape)} / weight {tuple(weight.shape)} / norm {gamma.numel()} mismatch")
+    if K != FUSED_FF_CHANNELS or N % FUSED_FF_CHANNELS or x.stride(0) % 8 or x.data_ptr() % 16:
+        return linear(layernorm(x.contiguous(), gamma, beta, eps), weight)
+    out = torch.empty((M, N), dtype=H, device=dev)
+    rc = L.load().syn3r_layernorm_linear320_f16(x.data_ptr(), x.stride(0), L.ptr(gamma), L.ptr(beta), float(eps), L.ptr(weight),
+                                                out.data_ptr(), out.stride(0), M, N, K, L.stream_ptr(dev))
+    L.check(rc, "syn3r_layernorm_linear320_f16")
+    _count("gemm", 2.0 * M * N * K)
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, *,
               addvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0, want_sum: bool = False):
     dev = _chk(x, gamma, beta, addvec)

@@ -707,3 +707,44 @@ def test_feedforward_fused_add_layernorm_c320(M, D, rpv, gpu):
         ops.feedforward_fused(x, wc, bc, D, w2, b2, ln=(ga, be, 1e-5), addvec=(vec, rpv), residual=aux)   # the sum IS the residual
     with pytest.raises(ValueError):
         ops.feedforward_fused(x, wc, bc, D, w2, b2, ln=(ga, be, 1e-5), addvec=(vec[:-1], rpv))          # too few vectors
+
+
+@pytest.mark.parametrize("M,N", [(128, 320), (700, 960), (4097, 960), (129, 640), (9216 * 3, 960)])
+def test_layernorm_linear_c320(M, N, gpu):
+    """norm1 -> stacked q / k / v projection in one kernel (syn3r_layernorm_linear320_f16; attention.py:340-352): against the
+    LayerNorm launch followed by `linear` (same normalised fp16 values, same fp32 accumulation order along K: equal up to the
+    order the 16-wide k groups reach the accumulator, i.e. within a few fp32 ulps before the fp16 rounding), and against the fp32
+    restatement; ragged M (partial last block), strided x, rows far from zero mean."""
+    from syn3r_amd.unet import ops
+    C = 320
+    g = torch.Generator().manual_seed(M + N)
+    wide = rnd(g, M, 2 * C, dev=gpu)
+    x = wide[:, C // 2:C // 2 + C]
+    x[::5] += 4.0
+    ga, be = (1.0 + 0.2 * rnd(g, C, dev=gpu).float()).half(), (0.1 * rnd(g, C, dev=gpu).float()).half()
+    w = rnd(g, N, C, scale=C ** -0.5, dev=gpu)
+    one = ops.layernorm_linear(x, ga, be, w)
+    n = ops.layernorm(x.contiguous(), ga, be)
+    two = ops.linear(n, w)
+    assert one.shape == (M, N)
+    ref = n.float() @ w.float().T                                        # on the SAME normalised fp16 values
+    assert (one.float() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    assert (one.float() - two.float()).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    assert (one != two).float().mean().item() < 0.02                     # fp16 outputs: all but a few last-bit roundings equal
+    nf = Fn.layer_norm(x.float(), (C,), ga.float(), be.float(), 1e-5).half().float()
+    close(one, nf @ w.float().T, tol=6e-3)
+
+
+def test_layernorm_linear_other_widths(gpu):
+    """Widths the fused kernel is not built for take the two launches (Python host) / are rejected at the C-ABI."""
+    from syn3r_amd import _lib
+    from syn3r_amd.unet import ops
+    g = torch.Generator().manual_seed(3)
+    for C, N in ((640, 1920), (320, 328)):
+        x, ga, be, w = rnd(g, 200, C, dev=gpu), rnd(g, C, dev=gpu), rnd(g, C, dev=gpu), rnd(g, N, C, scale=C ** -0.5, dev=gpu)
+        assert torch.equal(ops.layernorm_linear(x, ga, be, w), ops.linear(ops.layernorm(x, ga, be), w))
+    lib = _lib.load()
+    x, ga, be, w = rnd(g, 200, 640, dev=gpu), rnd(g, 640, dev=gpu), rnd(g, 640, dev=gpu), rnd(g, 640, 640, dev=gpu)
+    out = torch.empty(200, 640, dtype=torch.float16, device=gpu)
+    rc = lib.syn3r_layernorm_linear320_f16(x.data_ptr(), 640, ga.data_ptr(), be.data_ptr(), 1e-5, w.data_ptr(), out.data_ptr(), 640, 200, 640, 640, None)
+    assert rc != 0 and b"320" in lib.syn3r_last_error()
