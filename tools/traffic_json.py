@@ -30,6 +30,8 @@ def ktype(name):
     n = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].replace(" ", "")
     if "k_ffn320" in n:
         return "k_gemm_ffn320"
+    if "k_lnlin320" in n:
+        return "k_gemm_lnlin320"
     m = re.search(r"k_gemm\w*(<[^>]*>)?", n)
     if m:
         t = m.group(0)
@@ -69,6 +71,9 @@ def algorithmic_bytes(shapes_txt):
         if kt == "k_gemm_ffn320":
             D = int(f["D"])
             b = 2 * (M * 320 * 2 + 3 * D * 320 + (M * 320 if e else 0))
+        elif kt == "k_gemm_lnlin320":                      # LayerNorm + projection at K = 320: x once, W once, out once
+            N = int(f["N"])
+            b = 2 * (M * 320 + N * 320 + M * N)
         else:
             N, K = int(f["N"]), int(f["K"])
             taps = 9 if "<1" in kt else (3 if "<2" in kt else 1)            # implicit GEMM (MODE 1 / 2): every input element counted once
@@ -120,7 +125,7 @@ if shapes and fam:
 famjson = next((a for a in sys.argv[4:] if a.endswith(".json")), None)
 if famjson:
     pf = json.load(open(famjson))
-    gemm = [v for k, v in pf.items() if (k.startswith("k_gemm") and k != "k_gemm_skinny") or k == "k_ffn320"]
+    gemm = [v for k, v in pf.items() if (k.startswith("k_gemm") and k != "k_gemm_skinny") or k in ("k_ffn320", "k_lnlin320")]
     # MFMA busy of the whole contraction family: launch-weighted by the chip-active cycles of each member
     num = sum(v["per_launch"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * v["launches"] for v in gemm)
     den = sum(v["per_launch"].get("GRBM_GUI_ACTIVE", 0.0) * v["launches"] for v in gemm) / 8.0 * 1024.0
