@@ -1667,17 +1667,19 @@ int launch_ffn320(const FfnParams& q, hipStream_t stream) {
 // path writes the normalised activation ([M, 320] fp16) and reads it back, and its contraction (K = 320: five k-tiles per tile,
 // k_gemm_w128) runs at a quarter of the matrix peak.  Here, as in k_ffn320, a block owns 128 rows: the x tile (80 KB) is DMA'd
 // into LDS once, normalised in place (ln_tile320: the arithmetic of k_layernorm<8>), and the output columns are walked in chunks
-// of 320 - the weight chunk streams through a FOUR-slot ring in [320 x 32] stages (20 KB; 20 MFMAs per wavefront and barrier),
-// eight wavefronts (2 x 4) of 64 rows x 80 columns each.  The fragments are double-buffered in registers: a stage's LDS reads are
-// issued one stage ahead (right behind the barrier that certifies its DMA), so they run under the previous stage's MFMAs - with
-// one barrier per stage the two wavefronts of a SIMD are in lockstep and would otherwise read together, then multiply together
-// (measured: 1 200-1 450 cycles per stage for 640 of matrix work).  The epilogue needs no LDS: two v_permlane16_swap per pair of
-// accumulator tiles give every lane eight consecutive columns, i.e. one 16-byte store per pair (64-byte row segments).
-// LDS: x 80 KB | ring 4 x 20 KB = 163,840 B.
+// of 320 - the weight chunk streams through a 3-slot ring in [320 x 32] stages (20 KB; 20 MFMAs per wavefront and barrier),
+// eight wavefronts (2 x 4) of 64 rows x 80 columns each.  A chunk's [128 x 320] result goes out through a per-wavefront staging
+// buffer (16 rows at a time, wavefront-local synchronisation only: whole 160-byte row runs per store) while the next chunk's
+// first stages are already in flight.
+// LDS: x 80 KB | ring 3 x 20 KB | staging 8 x 2.5 KB = 163,840 B.
+// (Tried and measured slower on the same shapes, profiles/r04/lnqkv_ab.txt: a 4-slot ring with the fragments double-buffered in
+// registers and an LDS-free epilogue by v_permlane16_swap - its 64-byte row segments cost more than the k-loop gained; the chunk's
+// stores interleaved into the next chunk's k-loop.)
 constexpr int Q_SLOT = F_C * 32 * 2;                  // 20,480: [320 rows x 32 k] of the weight chunk, 64-byte rows
 constexpr int Q_RING = F_X_BYTES;
-constexpr int Q_SLOTS = 4;
-constexpr int Q_LDS = Q_RING + Q_SLOTS * Q_SLOT;      // 163,840
+constexpr int Q_ST = Q_RING + 3 * Q_SLOT;             // 143,360
+constexpr int Q_ST_WAVE = 16 * WN * 2;                // 2,560: 16 rows x 80 columns
+constexpr int Q_LDS = Q_ST + 8 * Q_ST_WAVE;           // 163,840
 
 struct LnLinParams {
     const __half* x; long long ldx;      // [M, 320]
@@ -1708,9 +1710,6 @@ __global__ void __launch_bounds__(512, 2) k_lnlin320(LnLinParams p) {
     auto issue_next = [&]() {
         if (ig >= nstage) return;
         const int c = ig / 10, ks = ig - c * 10;
-#ifdef SYN3R_Q_NODMA       // timing experiment (wrong results): the weight stream stops after the first stages
-        if (ig >= Q_SLOTS) { ++ig; if (++islot == Q_SLOTS) islot = 0; return; }
-#endif
         const __half* src = w_lane + (long long)c * (F_C * F_C) + ks * 32;
         char* slot = ring + islot * Q_SLOT;
 #pragma unroll
@@ -1718,10 +1717,10 @@ __global__ void __launch_bounds__(512, 2) k_lnlin320(LnLinParams p) {
             if (i < nbw)
                 __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + i * 16 * F_C), (lds_void_t*)(slot + (b_first + i) * 1024), 16, 0, 0);
         ++ig;
-        if (++islot == Q_SLOTS) islot = 0;
+        if (++islot == 3) islot = 0;
     };
 
-    // ---- prologue: the x tile (as k_ffn320) and the first three weight stages, then the LayerNorm in place
+    // ---- prologue: the x tile (as k_ffn320) and the first two weight stages, then the LayerNorm in place
     {
         const int prow = lane >> 3;
         const int csrc = (lane & 7) ^ prow;
@@ -1737,36 +1736,18 @@ __global__ void __launch_bounds__(512, 2) k_lnlin320(LnLinParams p) {
     }
     issue_next();
     issue_next();
-    issue_next();
-#ifdef SYN3R_Q_NOLN
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#else
     ln_tile320(smem_raw, tid, m0, p.M, (float)p.C, p.ln_g, p.ln_b, p.ln_eps, nullptr, 1);   // waits for every DMA above, ends on a barrier
-#endif
 
     const int fr = lane & 15, fq = lane >> 4;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
     const unsigned sw0 = (unsigned)(((0 + fq) ^ (fr & 7)) << 4), sw1 = (unsigned)(((4 + fq) ^ (fr & 7)) << 4);
     const unsigned x_row = lds0 + (unsigned)((wm * 64 + fr) * 128);                       // + kt * 16384 + i * 2048 + sw
-    const unsigned w_row = lds0 + Q_RING + (unsigned)((wn * 80 + fr) * 64) + (unsigned)((fq ^ h_swz(fr)) << 4);   // + slot * Q_SLOT + j * 1024
+    const unsigned w_row = (unsigned)((wn * 80 + fr) * 64) + (unsigned)((fq ^ h_swz(fr)) << 4);   // inside a slot, + j * 1024
+    const unsigned st_base = lds0 + Q_ST + (unsigned)(wv * Q_ST_WAVE);
+    const unsigned st_wr = st_base + (unsigned)(fr * (WN * 2) + fq * 8);                  // + j * 32
     typedef _Float16 half4e __attribute__((ext_vector_type(4)));
 
-    half8 a[2][TM], b[2][TN];
-#define Q_READS(BUF, KS, SLOT)                                                                                           \
-    {                                                                                                                    \
-        const unsigned xa_ = x_row + (unsigned)(((KS) >> 1) * 16384) + (((KS) & 1) ? sw1 : sw0);                         \
-        const unsigned wa_ = w_row + (unsigned)((SLOT) * Q_SLOT);                                                        \
-        DS_READ128(a[BUF][0], xa_, 0); DS_READ128(a[BUF][1], xa_, 2048); DS_READ128(a[BUF][2], xa_, 4096); DS_READ128(a[BUF][3], xa_, 6144); \
-        DS_READ128(b[BUF][0], wa_, 0); DS_READ128(b[BUF][1], wa_, 1024); DS_READ128(b[BUF][2], wa_, 2048); DS_READ128(b[BUF][3], wa_, 3072); \
-        DS_READ128(b[BUF][4], wa_, 4096);                                                                                \
-    }
-#define Q_MFMA(BUF, J)                                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[BUF][J], a[BUF][i], acc[i][J], 0, 0, 0); \
-    __builtin_amdgcn_sched_barrier(0);
-
-    int rslot = 1, g = 0;                 // rslot: ring slot of stage g + 1
-    Q_READS(0, 0, 0);                     // stage 0 (landed: the LayerNorm waited for it)
+    int cslot = 0, g = 0;
     const int nchunks = p.N / F_C;
     for (int c = 0; c < nchunks; ++c) {
         float4v acc[TM][TN];
@@ -1776,62 +1757,77 @@ __global__ void __launch_bounds__(512, 2) k_lnlin320(LnLinParams p) {
             for (int j = 0; j < TN; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 10; ++ks, ++g) {
-            const bool more = g + 1 < nstage;
-            if (more) {
-                // Stage g + 1 has landed once only what was issued AFTER its DMA is still in flight (vmcnt retires in order): DMA
-                // g + 2 (3 or 2 instructions per wavefront) and, in the first two stages after a chunk's stores (10 per wavefront;
-                // a block with rows past M may skip store instructions and counts none: it then waits for the stores too), those.
-                const bool after = g + 2 < nstage;
-                if (ks < 2 && c > 0 && full) {
-                    if (wv < 4) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                } else if (after) {
-                    if (wv < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();     // ... for every wavefront's pieces; and every wavefront is past the MFMAs of stage g - 1
-                if (ks & 1) { Q_READS(0, (ks + 1) % 10, rslot); } else { Q_READS(1, (ks + 1) % 10, rslot); }
-                if (++rslot == Q_SLOTS) rslot = 0;
-                issue_next();                     // stage g + 3 into the slot of stage g - 1
-                if (ks & 1) asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]), "+v"(b[1][4]));
-                else asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[0][4]));
+            // Stage g has landed once only what was issued AFTER its DMA is still in flight (vmcnt retires in order): the next
+            // stage's DMA (3 or 2 instructions per wavefront) and, in the first two stages after a chunk's stores (12 per wavefront;
+            // a block with rows past M may skip store instructions and counts none: it then waits for the stores too), those.
+            if (g + 1 >= nstage) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (ks < 2 && c > 0 && full) {
+                if (wv < 4) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
             } else {
-                if (ks & 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]), "+v"(b[1][4]));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[0][4]));
+                if (wv < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             }
-            if (ks & 1) { Q_MFMA(1, 0) Q_MFMA(1, 1) Q_MFMA(1, 2) Q_MFMA(1, 3) Q_MFMA(1, 4) }
-            else { Q_MFMA(0, 0) Q_MFMA(0, 1) Q_MFMA(0, 2) Q_MFMA(0, 3) Q_MFMA(0, 4) }
-        }
-        // ---- the chunk's 64 x 80 block of this wavefront, straight from the accumulators (acc[i][j][r] = C[row i*16 + (lane & 15)]
-        // [col j*16 + (lane >> 4)*4 + r]): for a pair of tiles (X, Y), v_permlane16_swap leaves the even 16-lane rows with columns
-        // fq*4 .. fq*4 + 7 of X and the odd rows with columns (fq-1)*4 .. + 7 of Y - one 16-byte store per lane and pair
-        __half* const obase = p.out + (long long)c * F_C + wn * WN;
-        auto store_pair = [&](const float4v& X, const float4v& Y, int rowX, int colX, int rowY, int colY) {
-            union { half4e h; unsigned u[2]; } x, y;
+            __builtin_amdgcn_s_barrier();
+            const unsigned xa = x_row + (unsigned)((ks >> 1) * 16384) + ((ks & 1) ? sw1 : sw0);
+            const unsigned wa = lds0 + Q_RING + (unsigned)(cslot * Q_SLOT) + w_row;
+            half8 a[TM], b[TN];
+            DS_READ128(a[0], xa, 0); DS_READ128(a[1], xa, 2048); DS_READ128(a[2], xa, 4096); DS_READ128(a[3], xa, 6144);
+            DS_READ128(b[0], wa, 0); DS_READ128(b[1], wa, 1024); DS_READ128(b[2], wa, 2048); DS_READ128(b[3], wa, 3072);
+            DS_READ128(b[4], wa, 4096);
+            issue_next();                 // stage g + 2 into the slot every wavefront finished reading before this barrier
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { x.h[r] = (_Float16)X[r]; y.h[r] = (_Float16)Y[r]; }
-            const auto r0 = __builtin_amdgcn_permlane16_swap(x.u[0], y.u[0], false, false);
-            const auto r1 = __builtin_amdgcn_permlane16_swap(x.u[1], y.u[1], false, false);
-            union { half8 h; unsigned u[4]; } o;
-            o.u[0] = r0[0]; o.u[1] = r1[0]; o.u[2] = r0[1]; o.u[3] = r1[1];
-            const int row = (fq & 1) ? rowY : rowX, col = ((fq & 1) ? colY : colX) + (fq >> 1) * 8;
-            const int m = m0 + wm * WM + row + fr;
-#ifndef SYN3R_Q_NOSTORE
-            if (m < p.M) *(half8*)(obase + (long long)m * p.ldc + col) = o.h;
-#else
-            if (m < -1) *(half8*)(obase + (long long)m * p.ldc + col) = o.h;
-#endif
-        };
+            for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[0], a[i], acc[i][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(b[1]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[1], a[i], acc[i][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(b[2]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[2], a[i], acc[i][2], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(b[3]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[3], a[i], acc[i][3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[4]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[4], a[i], acc[i][4], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (++cslot == 3) cslot = 0;
+        }
+        // ---- the chunk's 64 x 80 block of this wavefront: 16 rows at a time through its own staging buffer (no block barrier;
+        // acc[i][j][r] = C[row i*16 + (lane & 15)][col j*16 + (lane >> 4)*4 + r], see gemm_epilogue); every lane executes every LDS
+        // instruction (an inline-asm output written under a divergent branch would be merged before its data has arrived)
+        __half* const orow = p.out + (long long)c * F_C + wn * WN;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            store_pair(acc[i][0], acc[i][1], i * 16, 0, i * 16, 16);
-            store_pair(acc[i][2], acc[i][3], i * 16, 32, i * 16, 48);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                half4e o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)acc[i][j][r];
+                DS_WRITE64(st_wr + (unsigned)(j * 32), o);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            half8 v[3];
+            DS_READ128(v[0], st_base + (unsigned)(lane * 16), 0);
+            DS_READ128(v[1], st_base + (unsigned)(lane * 16), 1024);
+            DS_READ128(v[2], st_base + (unsigned)((lane & 31) * 16), 2048);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int q = lane + it * 64;
+                const int row = q / (WN / 8), ch = q - row * (WN / 8);
+                const int m = m0 + wm * WM + i * 16 + row;
+                if (q < 16 * (WN / 8) && m < p.M) *(half8*)(orow + (long long)m * p.ldc + ch * 8) = v[it];
+            }
         }
-        store_pair(acc[0][4], acc[1][4], 0, 64, 16, 64);
-        store_pair(acc[2][4], acc[3][4], 32, 64, 48, 64);
     }
-#undef Q_READS
-#undef Q_MFMA
 }
 
 int launch_lnlin320(const LnLinParams& p, hipStream_t stream) {
