@@ -308,7 +308,9 @@ int syn3r_gemm_2src_f16(const void* A1, long long lda1, int K1, const void* A2, 
  * contraction kernel family this thread's next launches use.  0 = chosen per shape (default); -128 / -256 = the 160-column
  * LDS-DMA kernel of that block height; -320 = the persistent 256 x 320 kernel wherever it admits the shape; -321 = the
  * 128 x 320 two-blocks-per-CU kernel (dense contractions; the convolutions keep the default); -322 = the software-pipelined
- * persistent 256 x 320 kernel (round 4: dense, two-source and implicit-GEMM convolution modes) wherever it admits the shape. */
+ * persistent 256 x 320 kernel (round 4: dense, two-source and implicit-GEMM convolution modes) wherever it admits the shape.
+ * -3200 / -3201 (independent of the above, sticky until changed): the fused feed-forward entries (syn3r_feedforward_fused*_f16) run
+ * the kernel with the x tile in LDS / in registers (default -3201; both give the same bits). */
 int syn3r_gemm_set_tile(int bm);
 
 /* Split-K scratch, PER CALLING THREAD (round 4).  With a workspace set, the contractions (syn3r_gemm_f16, syn3r_gemm_2src_f16

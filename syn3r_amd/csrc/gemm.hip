@@ -1643,11 +1643,354 @@ __global__ void __launch_bounds__(512, 2) k_ffn320(FfnParams q) {
     gemm_epilogue<1, true>(p, acc, smem_raw, lane, wv, wm, wn, m0, 0, 0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_ffn320r: the fused feed-forward with the x tile in REGISTERS (round 4).  In k_ffn320 the resident x tile is half of the LDS:
+// the weight ring has three slots (two stages of look-ahead), every stage re-reads the x fragments from LDS (320 of the 624 KB
+// a chunk reads), and the block is alone on its CU.  Here the eight wavefronts are 4 (row groups of 32) x 2 (column halves): a
+// wavefront keeps ITS 32 rows of x as MFMA fragments (2 x 10 x 16 B per lane = 80 registers, normalised in registers with the
+// arithmetic and summation order of k_layernorm<8>), which frees 80 KB: the ring has SEVEN 20 KB slots (a chunk's five W1 k-tiles
+// and two W2 halves), so a chunk needs THREE barriers instead of six (k-tiles 0-2 | k-tiles 3-4, gate | W2 + h) with every stage
+// issued two barrier intervals ahead, and inside an interval the weight fragments of k-step t + 1 are read under the MFMAs of
+// k-step t (two 4-fragment buffers); phase 1 reads only weight fragments (8 instead of 12 ds_read_b128 per k-tile and wavefront),
+// phase 2 reads the wavefront's own W2 half.  Same arithmetic, same accumulation order as k_ffn320: bit-identical output.
+// Measured inside the unit, same box: 11.9 ms against 12.6-13.0 (15 launches at M = 258 048); with one barrier per stage and no
+// read-ahead the same kernel ran 14.0 ms, with 13 spilled registers (scratch reloads drain the DMA queue) 16.8 ms.
+// Registers: x 80 + out 32 x 160 (80) + S 32 x 64 (32) + fragments.  LDS: ring 7 x 20 KB | h 16 KB | bias 4 KB = 163,840 B.
+constexpr int R_SLOTS = 7;
+constexpr int R_H = R_SLOTS * F_SLOT;                // 143,360
+constexpr int R_BIAS = R_H + F_BM * F_HC * 2;        // 159,744
+constexpr int R_LDS = R_BIAS + 8 * 512;              // 163,840
+
+__global__ void __launch_bounds__(512, 2) k_ffn320r(FfnParams q) {
+    const GemmParams& p = q.e;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;              // 4 row groups of 32 rows x 2 column halves
+    const int tiles_m = (p.M + F_BM - 1) / F_BM;
+    const int m0 = (int)xcd_remap(blockIdx.x, (unsigned)tiles_m) * F_BM;
+    const int nchunks = q.D / F_HC;
+    const long long D = q.D;
+    const int fr = lane & 15, fq = lane >> 4;
+    typedef _Float16 half4e __attribute__((ext_vector_type(4)));
+
+    // ---- weight DMA (as k_ffn320): W1 k-tile = 16 pieces of 8 rows x 128 B (2 per wavefront), W2 half = 20 pieces (3 / 2)
+    const int prow = lane >> 3;
+    const int csrc = (lane & 7) ^ prow;
+    const int nbw = wv < 4 ? 3 : 2;
+    const int b_first = wv < 4 ? wv * 3 : 12 + (wv - 4) * 2;
+    // per-lane 32-bit byte offsets; the stage's base stays a scalar (opaque to the optimiser, as in k_attn_spatial), so the copies
+    // take the scalar-base + lane-offset form and no 64-bit per-lane pointer lives across the chunk loop
+    unsigned ow1 = (unsigned)((((wv * 2) * 8 + prow) * F_C + csrc * 8) * 2);
+    unsigned ow2 = (unsigned)(((long long)(b_first * 8 + prow) * D + csrc * 8) * 2);
+    unsigned ob1 = (unsigned)(lane * 4);
+    char* const bias_line = smem_raw + R_BIAS + wv * 512;
+    // Ring: slots 0..4 = the chunk's five W1 k-tiles, slots 5, 6 = its two W2 halves.  THREE barriers per chunk (k-tiles 0-2, k-tiles
+    // 3-4, W2 + h; k_ffn320: six); behind each one the stages whose slots the barrier just released are issued:
+    //   I1(j): W2(j)          I2(j): W1(j+1, 0..2)          I3(j): W1(j+1, 3), W1(j+1, 4)
+    // i.e. every stage is issued two barrier intervals before it is needed.  Per-wavefront DMA instructions: W1 k-tile 2 (+ 1 bias
+    // line with k-tile 0), W2 2 * nbw.
+    auto issue_w1 = [&](int ij, int ir) {
+        asm volatile("" : "+v"(ow1), "+v"(ob1));
+        long long soff = ((long long)ij * (128 * F_C) + ir * BK) * 2;
+        asm volatile("" : "+s"(soff));
+        const char* src = (const char*)q.w1 + soff;
+        char* slot = smem_raw + ir * F_SLOT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + i * (8 * F_C * 2) + (size_t)ow1), (lds_void_t*)(slot + (wv * 2 + i) * 1024), 16, 0, 0);
+        if (ir == 0) {
+            long long boff = (long long)ij * 256;
+            asm volatile("" : "+s"(boff));
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)q.b1 + boff + (size_t)ob1), (lds_void_t*)(bias_line + (ij & 1) * 256), 4, 0, 0);
+        }
+    };
+    auto issue_w2 = [&](int ij) {
+        asm volatile("" : "+v"(ow2));
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            long long soff = ((long long)hh * 160 * D + (long long)ij * F_HC) * 2;
+            asm volatile("" : "+s"(soff));
+            const char* src = (const char*)p.W + soff;
+            char* slot = smem_raw + (5 + hh) * F_SLOT;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < nbw)
+                    __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + (long long)i * 8 * D * 2 + (size_t)ow2), (lds_void_t*)(slot + (b_first + i) * 1024), 16, 0, 0);
+        }
+    };
+    auto wait_vm = [&](int n) {
+        switch (n) {
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+
+    // ---- x fragments: lane (fr, fq) holds, for row tile i and k-step ks (32 wide), x[row i*16 + fr][ks*32 + fq*8 .. +8]
+    half8 xf[2][10];
+    {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int m = m0 + wm * 32 + i * 16 + fr;
+            m = m < p.M ? m : p.M - 1;
+            const __half* xr = p.A + (long long)m * p.lda + fq * 8;
+#pragma unroll
+            for (int ks = 0; ks < 10; ++ks) xf[i][ks] = *(const half8*)(xr + ks * 32);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 5; ++s) issue_w1(0, s);      // chunk 0's W1 k-tiles; its W2 halves follow behind the first barrier
+    if (q.ln_g) {
+        // LayerNorm in registers: the 16-byte chunk c = 4 ks + fq of a row belongs to k_layernorm<8>'s lane sub = c % 8, i.e. this
+        // lane holds sub = fq (even ks) and sub = fq + 4 (odd ks), each in k_layernorm's order; its xor tree 4, 2, 1 is
+        // (own pair) , lane ^ 32 , lane ^ 16 here.  Same expressions as ln_tile320 / k_layernorm: the same bits.
+        const float cf = (float)p.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (q.ln_add) {
+                int m = m0 + wm * 32 + i * 16 + fr;
+                m = m < p.M ? m : p.M - 1;
+                const __half* av = q.ln_add + (long long)(m / q.ln_add_rpv) * F_C + fq * 8;
+#pragma unroll
+                for (int ks = 0; ks < 10; ++ks) xf[i][ks] = xf[i][ks] + *(const half8*)(av + ks * 32);   // fp16 add, as k_layernorm
+            }
+            float sa = 0.f, sb = 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sa += (float)xf[i][2 * k][e]; sb += (float)xf[i][2 * k + 1][e]; }
+            float s = sa + sb;
+            s += __shfl_xor(s, 32, 64);
+            s += __shfl_xor(s, 16, 64);
+            const float mean = s / cf;
+            float qa = 0.f, qb = 0.f;
+            {
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float da = (float)xf[i][2 * k][e] - mean, db = (float)xf[i][2 * k + 1][e] - mean;
+                        const float da2 = da * da, db2 = db * db;
+                        qa += da2; qb += db2;
+                    }
+            }
+            float qq = qa + qb;
+            qq += __shfl_xor(qq, 32, 64);
+            qq += __shfl_xor(qq, 16, 64);
+            const float rstd = rsqrtf(qq / cf + q.ln_eps);
+#pragma unroll
+            for (int ks = 0; ks < 10; ++ks) {
+                const half8 g = *(const half8*)(q.ln_g + ks * 32 + fq * 8), b = *(const half8*)(q.ln_b + ks * 32 + fq * 8);
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)(((float)xf[i][ks][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+                xf[i][ks] = o;
+            }
+        }
+    }
+
+    float4v acc[2][10];                   // out: 32 rows x 160 columns of this wavefront
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const unsigned sw0 = (unsigned)(((0 + fq) ^ (fr & 7)) << 4), sw1 = (unsigned)(((4 + fq) ^ (fr & 7)) << 4);
+    const unsigned w1_row = lds0 + (unsigned)((wn * 64 + fr) * 128);              // + slot * F_SLOT + t * 2048 (t: h0, g0, h1, g1) + sw
+    const unsigned w2_row = lds0 + (unsigned)((5 + wn) * F_SLOT + fr * 128);      // + jt * 2048 + sw
+    const unsigned h_rd = lds0 + R_H + (unsigned)((wm * 32 + fr) * 128);          // + i * 2048 + sw
+    const unsigned bias_rd = lds0 + R_BIAS + (unsigned)(wv * 512 + (wn * 64 + fq * 4) * 2);   // + u * 64 ; gate at + 32 ; + (j & 1) * 256
+    unsigned h_wr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int hc = (wn * 2 + u) * 16 + fq * 4;
+        h_wr[u] = lds0 + R_H + (unsigned)((wm * 32 + fr) * 128) + (unsigned)((((hc >> 3) ^ (fr & 7)) << 4) + (hc & 7) * 2);   // + i * 2048
+    }
+
+    for (int j = 0; j < nchunks; ++j) {
+        float4v S[2][4];                  // [row tile][h0, g0, h1, g1]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) S[i][t] = (float4v){0.f, 0.f, 0.f, 0.f};
+        half4e bh[2], bg[2];
+        const bool more = j + 1 < nchunks;
+        half8 b[2][4];
+#define R_RD(BUF, T)                                                                                                     \
+        {                                                                                                                \
+            const unsigned wa_ = w1_row + (unsigned)(((T) >> 1) * F_SLOT) + (((T) & 1) ? sw1 : sw0);                     \
+            DS_READ128(b[BUF][0], wa_, 0); DS_READ128(b[BUF][1], wa_, 2048); DS_READ128(b[BUF][2], wa_, 4096); DS_READ128(b[BUF][3], wa_, 6144); \
+        }
+#define R_MF(BUF, T, CNT)                                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(b[BUF][0]), "+v"(b[BUF][1]), "+v"(b[BUF][2]), "+v"(b[BUF][3]));    \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                    \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) S[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[BUF][t], xf[i][T], S[i][t], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);
+        // I1: k-tiles 0-2 have landed once only k-tiles 3, 4 (issued after them) may still be in flight
+        wait_vm(4);
+        __builtin_amdgcn_s_barrier();
+        R_RD(0, 0) R_RD(1, 1)
+        issue_w2(j);
+        R_MF(0, 0, 4) R_RD(0, 2) R_MF(1, 1, 4) R_RD(1, 3) R_MF(0, 2, 4) R_RD(0, 4) R_MF(1, 3, 4) R_RD(1, 5) R_MF(0, 4, 4) R_MF(1, 5, 0)
+        // I2: k-tiles 3, 4: behind them this chunk's W2
+        wait_vm(2 * nbw);
+        __builtin_amdgcn_s_barrier();
+        R_RD(0, 6) R_RD(1, 7)
+        if (more) { issue_w1(j + 1, 0); issue_w1(j + 1, 1); issue_w1(j + 1, 2); }
+        R_MF(0, 6, 4) R_RD(0, 8) R_MF(1, 7, 4) R_RD(1, 9) R_MF(0, 8, 4) R_MF(1, 9, 0)
+#undef R_RD
+#undef R_MF
+        // ---- gate (GEGLU.forward), as k_ffn320: fp16-rounded projection outputs, packed fp32 GELU, h as the k-tile image of phase 2
+        {   // the chunk's bias values (landed with its first stage), read only now: no registers held across the five stages
+            const unsigned ba = bias_rd + (unsigned)((j & 1) * 256);
+            DS_READ64(bh[0], ba, 0); DS_READ64(bg[0], ba, 32); DS_READ64(bh[1], ba, 64); DS_READ64(bg[1], ba, 96);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[0]), "+v"(bg[0]), "+v"(bh[1]), "+v"(bg[1]));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                half4e o;
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const syn3r_f2 hv = (syn3r_f2){(float)(_Float16)(S[i][2 * u][r] + (float)bh[u][r]), (float)(_Float16)(S[i][2 * u][r + 1] + (float)bh[u][r + 1])};
+                    const syn3r_f2 gv = (syn3r_f2){(float)(_Float16)(S[i][2 * u + 1][r] + (float)bg[u][r]), (float)(_Float16)(S[i][2 * u + 1][r + 1] + (float)bg[u][r + 1])};
+                    const syn3r_f2 y = hv * gelu_pk(gv);
+                    o[r] = (_Float16)y.x; o[r + 1] = (_Float16)y.y;
+                }
+                DS_WRITE64(h_wr[u] + (unsigned)(i * 2048), o);
+            }
+        wait_vm(more ? 7 : 0);            // I3: both W2 halves have landed: behind them the next chunk's k-tiles 0-2 (and its bias line)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // h is written
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: out[32 x 160] += h[32 x 64] . W2half[160 x 64]^T
+        {
+            half8 af[2][2], bf[2][5];
+            DS_READ128(af[0][0], h_rd + sw0, 0); DS_READ128(af[1][0], h_rd + sw0, 2048);
+            DS_READ128(bf[0][0], w2_row + sw0, 0); DS_READ128(bf[0][1], w2_row + sw0, 2048); DS_READ128(bf[0][2], w2_row + sw0, 4096);
+            DS_READ128(bf[0][3], w2_row + sw0, 6144); DS_READ128(bf[0][4], w2_row + sw0, 8192);
+            DS_READ128(bf[1][0], w2_row + sw0, 10240); DS_READ128(bf[1][1], w2_row + sw0, 12288); DS_READ128(bf[1][2], w2_row + sw0, 14336);
+            DS_READ128(bf[1][3], w2_row + sw0, 16384); DS_READ128(bf[1][4], w2_row + sw0, 18432);
+            if (more) { issue_w1(j + 1, 3); issue_w1(j + 1, 4); }   // into the slots of this chunk's k-tiles 3, 4
+            asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(af[0][0]), "+v"(af[1][0]), "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[0][2]), "+v"(bf[0][3]), "+v"(bf[0][4]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jt = 0; jt < 5; ++jt) acc[i][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[0][jt], af[i][0], acc[i][jt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DS_READ128(af[0][1], h_rd + sw1, 0); DS_READ128(af[1][1], h_rd + sw1, 2048);
+            half8 bg0[5];
+            DS_READ128(bg0[0], w2_row + sw1, 0); DS_READ128(bg0[1], w2_row + sw1, 2048); DS_READ128(bg0[2], w2_row + sw1, 4096);
+            DS_READ128(bg0[3], w2_row + sw1, 6144); DS_READ128(bg0[4], w2_row + sw1, 8192);
+            asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(bf[1][2]), "+v"(bf[1][3]), "+v"(bf[1][4]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jt = 0; jt < 5; ++jt) acc[i][5 + jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[1][jt], af[i][0], acc[i][5 + jt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            half8 bg1[5];
+            DS_READ128(bg1[0], w2_row + sw1, 10240); DS_READ128(bg1[1], w2_row + sw1, 12288); DS_READ128(bg1[2], w2_row + sw1, 14336);
+            DS_READ128(bg1[3], w2_row + sw1, 16384); DS_READ128(bg1[4], w2_row + sw1, 18432);
+            asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(af[0][1]), "+v"(af[1][1]), "+v"(bg0[0]), "+v"(bg0[1]), "+v"(bg0[2]), "+v"(bg0[3]), "+v"(bg0[4]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jt = 0; jt < 5; ++jt) acc[i][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bg0[jt], af[i][1], acc[i][jt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bg1[0]), "+v"(bg1[1]), "+v"(bg1[2]), "+v"(bg1[3]), "+v"(bg1[4]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jt = 0; jt < 5; ++jt) acc[i][5 + jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bg1[jt], af[i][1], acc[i][5 + jt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // every wavefront is done with the ring before the epilogue stages through it
+
+    // ---- epilogue (the arithmetic of gemm_epilogue): fp16((acc + bias) * s_acc) staged per wavefront [32 rows x 160 columns], then
+    // + s_res * residual (+ res_add first, an fp16 add) + s_aux * aux on whole 16-byte chunks
+    {
+        const int gm0 = m0 + wm * 32, gn0 = wn * 160;
+        __half* st = (__half*)smem_raw + wv * (32 * 168);            // 168-half rows (padded): 10,752 B per wavefront
+        half8 res[10], radd[10];
+        if (p.residual) {
+#pragma unroll
+            for (int it = 0; it < 10; ++it) {
+                const int qi = lane + it * 64;
+                const int row = qi / 20, ch = qi - row * 20;
+                const int m = gm0 + row, n = gn0 + ch * 8;
+                if (m < p.M) {
+                    res[it] = *(const half8*)(p.residual + (long long)m * p.ldr + n);
+                    if (p.res_add) radd[it] = *(const half8*)(p.res_add + (long long)(m / p.res_add_rpv) * p.N + n);
+                } else res[it] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < 10; ++jt) {
+            const int n = gn0 + jt * 16 + fq * 4;
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                const half4e b = *(const half4e*)(p.bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b4[r] = (float)b[r];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                half4e o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)((acc[i][jt][r] + b4[r]) * p.s_acc);
+                *(half4e*)(st + (i * 16 + fr) * 168 + jt * 16 + fq * 4) = o;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 10; ++it) {
+            const int qi = lane + it * 64;
+            const int row = qi / 20, ch = qi - row * 20;
+            const int m = gm0 + row, n = gn0 + ch * 8;
+            if (m >= p.M) continue;
+            half8 v = *(const half8*)(st + row * 168 + ch * 8);
+            if (p.residual || p.aux) {
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+                if (p.residual) {
+                    half8 rr = res[it];
+                    if (p.res_add) rr = rr + radd[it];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += p.s_res * (float)rr[e];
+                }
+                if (p.aux) {
+                    const half8 av = *(const half8*)(p.aux + (long long)m * p.ldaux + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += p.s_aux * (float)av[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (_Float16)f[e];
+            }
+            *(half8*)(p.out + (long long)m * p.ldc + n) = v;
+        }
+    }
+}
+
+thread_local int g_ffn_regx = 1;         // syn3r_gemm_set_tile(-3200 / -3201): k_ffn320 / k_ffn320r for the calling thread (tests)
+
 int launch_ffn320(const FfnParams& q, hipStream_t stream) {
     static bool attr_set = false;
+    static int reg_x = 1;              // SYN3R_FFN_REGX=0: the x tile in LDS (k_ffn320) instead of in registers (k_ffn320r); tuning
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn320, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(ffn320)");
+        e = hipFuncSetAttribute((const void*)k_ffn320r, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(ffn320r)");
+        const char* v = getenv("SYN3R_FFN_REGX");
+        reg_x = v ? atoi(v) : 1;
         attr_set = true;
     }
     const int tiles = (q.e.M + F_BM - 1) / F_BM;
@@ -1655,6 +1998,11 @@ int launch_ffn320(const FfnParams& q, hipStream_t stream) {
     if (trace_on()) {
         if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_ffn320[M%d,D%d,e%d]", q.e.M, q.D, q.e.residual != nullptr);
         else snprintf(name, sizeof(name), "k_gemm_ffn320");
+    }
+    if (reg_x && g_ffn_regx != 0 && (uintptr_t)q.e.A % 16 == 0 && q.e.lda % 8 == 0) {
+        SYN3R_LAUNCH_NAMED(name, k_ffn320r, dim3(tiles), dim3(512), R_LDS, stream, q);
+        SYN3R_LAUNCH_CHECK("ffn320r launch");
+        return SYN3R_OK;
     }
     SYN3R_LAUNCH_NAMED(name, k_ffn320, dim3(tiles), dim3(512), F_LDS, stream, q);
     SYN3R_LAUNCH_CHECK("ffn320 launch");
@@ -2169,8 +2517,9 @@ extern "C" int syn3r_gemm_set_splitk_workspace(void* workspace, size_t bytes) {
 }
 
 extern "C" int syn3r_gemm_set_tile(int bm) {
+    if (bm == -3200 || bm == -3201) { g_ffn_regx = bm == -3201; return SYN3R_OK; }     // fused feed-forward: x tile in LDS / in registers
     SYN3R_REQUIRE(bm == 0 || bm == -128 || bm == -256 || bm == -320 || bm == -321 || bm == -322,
-                  "gemm_set_tile: bm must be 0, -128, -256, -320, -321 or -322");
+                  "gemm_set_tile: bm must be 0, -128, -256, -320, -321 or -322 (or -3200 / -3201 for the fused feed-forward)");
     g_dma_bm = (bm == -128 || bm == -256) ? -bm : bm;        // this thread's launches only (thread_local)
     return SYN3R_OK;
 }

@@ -748,3 +748,40 @@ def test_layernorm_linear_other_widths(gpu):
     out = torch.empty(200, 640, dtype=torch.float16, device=gpu)
     rc = lib.syn3r_layernorm_linear320_f16(x.data_ptr(), 640, ga.data_ptr(), be.data_ptr(), 1e-5, w.data_ptr(), out.data_ptr(), 640, 200, 640, 640, None)
     assert rc != 0 and b"320" in lib.syn3r_last_error()
+
+
+@pytest.mark.parametrize("M,D", [(128, 64), (700, 1280), (4097, 1280), (129, 192), (9216 * 3 + 40, 1280)])
+def test_feedforward_fused_register_and_lds_kernels_agree(M, D, gpu):
+    """The fused feed-forward has two kernels - x tile in LDS (k_ffn320) and x tile as register fragments with a 7-slot
+    weight ring (k_ffn320r, the default) - with the same arithmetic and accumulation order: bit-identical outputs, with and
+    without the in-kernel LayerNorm, the add vector (norm_in), residual, aux and scales; ragged M, strided x."""
+    from syn3r_amd import _lib
+    from syn3r_amd.unet import ops
+    lib = _lib.load()
+    C = 320
+    g = torch.Generator().manual_seed(M + 7 * D)
+    wide = rnd(g, M, 2 * C, dev=gpu)
+    x = wide[:, C // 2:C // 2 + C]
+    x[::7] += 3.0
+    ga, be = (1.0 + 0.2 * rnd(g, C, dev=gpu).float()).half(), (0.1 * rnd(g, C, dev=gpu).float()).half()
+    w1, b1 = rnd(g, 2 * D, C, scale=C ** -0.5, dev=gpu), rnd(g, 2 * D, dev=gpu)
+    w2, b2 = rnd(g, C, D, scale=D ** -0.5, dev=gpu), rnd(g, C, dev=gpu)
+    aux, res = rnd(g, M, C, dev=gpu), rnd(g, M, C, dev=gpu)
+    rpv = max(1, M // 3)
+    vec = rnd(g, (M + rpv - 1) // rpv, C, dev=gpu)
+    wc, bc, _ = ops.pack_geglu_chunked(w1, b1)
+    cases = [dict(), dict(residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25), dict(ln=(ga, be, 1e-5), residual=res),
+             dict(ln=(ga, be, 1e-5), addvec=(vec, rpv), aux=aux, s_acc=0.5, s_res=0.5, s_aux=0.5), dict(b2=None)]
+    outs = {}
+    try:
+        for mode in (-3200, -3201):
+            _lib.check(lib.syn3r_gemm_set_tile(mode), "set_tile")
+            outs[mode] = [ops.feedforward_fused(x, wc, bc, D, w2, kw.get("b2", b2), **{k: v for k, v in kw.items() if k != "b2"}) for kw in cases]
+    finally:
+        lib.syn3r_gemm_set_tile(-3201)
+    for a, b, kw in zip(outs[-3200], outs[-3201], cases):
+        assert torch.equal(a, b), (sorted(kw), (a.float() - b.float()).abs().max().item())
+    # and against the fp32 restatement (the register kernel is the default path of every other feed-forward test, too)
+    y = (x.float() @ w1.float().T + b1.float()).half().float()
+    h = (y[:, :D] * Fn.gelu(y[:, D:])).half().float()
+    close(outs[-3201][0], h @ w2.float().T + b2.float(), tol=4e-3)
