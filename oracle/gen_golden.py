@@ -58,11 +58,20 @@ def cuda_to_cpu():
             k["device"] = "cpu"
         return orig(self, *a, **k)
 
+    orig_tensor = torch.tensor
+
+    def tensor(*a, **k):                  # torch.tensor(x, device='cuda') at model/diffusionGS.py:1339-1344
+        if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+            k["device"] = "cpu"
+        return orig_tensor(*a, **k)
+
     torch.Tensor.to = to
+    torch.tensor = tensor
     try:
         yield
     finally:
         torch.Tensor.to = orig
+        torch.tensor = orig_tensor
 
 
 def gen_warp(consistency, forward_warp, inverse_warp):
@@ -606,6 +615,26 @@ def gen_orchestrator():
     print("orchestrator", {k: getattr(v, "shape", ()) for k, v in out.items()})
 
 
+def gen_orch_nearby():
+    """O4: the reference's own `consistency_check_from_nearby_images_bw` (model/diffusionGS.py:1300-1361) on five seeded
+    576 x 1024 frames.  The method touches `self.diffusion_width / diffusion_height` and `inverse_warp` only (no cv2, no
+    renderer, no FSGS), so a two-attribute stand-in for `self` and the cuda -> cpu redirect run it as it is."""
+    import types
+    DiffusionGS = _reference_diffusiongs()
+    K, poses, images, depths = GI.orch_nearby_case()
+    me = types.SimpleNamespace(diffusion_width=1024, diffusion_height=576)
+    with cuda_to_cpu():
+        um, im = DiffusionGS.consistency_check_from_nearby_images_bw(me, K, poses, images=images, depths=depths)
+    sy, sx = GI.ORCH_NEARBY_STRIDE
+    out = {"uncertainty": np.stack([u.numpy()[::sy, ::sx] for u in um]).astype(np.float32),
+           "intensity_uncertainty": np.stack([u.numpy()[::sy, ::sx] for u in im]).astype(np.float32),
+           "uncertainty_mean": np.array([float(u.double().mean()) for u in um]),
+           "intensity_uncertainty_mean": np.array([float(u.double().mean()) for u in im])}
+    np.savez_compressed(GOLD / "orch_nearby.npz", **out)
+    print("orch_nearby", {k: getattr(v, "shape", ()) for k, v in out.items()}, out["uncertainty_mean"],
+          out["intensity_uncertainty_mean"])
+
+
 def _reference_diffusiongs():
     """The reference's DiffusionGS class; the absent packages its module imports get empty placeholder modules (the
     methods called here never touch them, except the name `trimesh.Scene` that densify_views instantiates and drops)."""
@@ -723,6 +752,8 @@ def main():
         gen_clip_preprocess()
     if "orch" in which:
         gen_orchestrator()
+    if "orch_nearby" in which:            # ~1 min of CPU: eight full-size reference inverse warps
+        gen_orch_nearby()
     if "n2" in which:
         gen_n2()
     if "unet" in which:

@@ -131,6 +131,33 @@ def orch_masks():
     return [lo, hi, ramp]
 
 
+ORCH_NEARBY_STRIDE = (9, 11)
+
+
+def orch_nearby_case(H=576, W=1024, n=5):
+    """Five frames at the diffusion resolution for consistency_check_from_nearby_images_bw (diffusionGS.py:1300-1361):
+    a camera sliding sideways with a small yaw, smooth per-frame depth maps that nearly agree with each other, and smooth
+    textured images whose neighbours differ by a few hundredths (so the intensity confidence exp(-(|d|/0.1)^3) is neither
+    0 nor 1 everywhere).  Returns K (3,3) f32, poses [n] (4,4) f32 w2c, images [n] (H,W,3) f32, depths [n] (H,W) f32."""
+    rng = np.random.default_rng(57)
+    sc = W / 1024.0
+    K = np.array([[800.0 * sc, 0, W / 2.0], [0, 800.0 * sc, H / 2.0], [0, 0, 1]], dtype=f32)
+    base = (_rot_x(0.3) @ np.eye(4))
+    base[:3, 3] = [0.01, -0.02, 0.0]
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    poses, images, depths = [], [], []
+    for i in range(n):
+        T = _rot_y(0.2 * i) @ _rot_x(-0.05 * i)
+        T[:3, 3] = [0.02 * i, 0.003 * i, 0.004 * i]
+        poses.append((T @ base).astype(f32))
+        depths.append(_depth(H, W, (97.0 + 3 * i) * sc, (53.0 - 2 * i) * sc, base=2.0 + 0.01 * i))
+        im = np.stack([0.5 + 0.3 * np.sin(xs / ((23.0 + 7 * c) * sc) + 0.05 * i) * np.cos(ys / ((31.0 + 5 * c) * sc))
+                       for c in range(3)], axis=-1)
+        images.append((im + 0.01 * rng.standard_normal(im.shape)).astype(f32))
+    depths[2][40:60, 100:180] = 0.0           # an unrendered hole in the middle frame
+    return K, poses, images, depths
+
+
 def n2_view_poses(V, seed=0):
     """V input-view w2c poses on a gently curving, unevenly spaced path (key-frame selection has something to choose)."""
     rng = np.random.default_rng(100 + seed)

@@ -106,6 +106,7 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 #ifndef ATTN_WAVES
 #define ATTN_WAVES 3
 #endif
+#ifdef ATTN_MFMA32
 __global__ void __launch_bounds__(ATHREADS, ATTN_WAVES) k_attn_spatial(AttnParams p) {
     __shared__ __attribute__((aligned(1024))) __half Ks[2][BKV * 64];
     __shared__ __attribute__((aligned(1024))) __half Vs[2][BKV * 64];
@@ -365,6 +366,267 @@ __global__ void __launch_bounds__(ATHREADS, ATTN_WAVES) k_attn_spatial(AttnParam
             }
     }
 }
+
+#else
+// Round 5: the same algorithm on v_mfma_f32_16x16x32_f16.  Under this kernel the chip is clock-throttled with the matrix pipe
+// exposed (profiles/r04/pmc: MFMA busy 0.68 at 1.4-1.5 GHz), and MI355X_MICROARCH.md (DVFS give-back, item 7) measures 1.12-1.15x
+// the FLOP/s for the 16x16x32 shape in exactly that regime at equal cycles per FLOP.  What changes with the shape:
+//   * a score tile S^T[16 keys][16 queries] leaves the pipe with the lane owning query (lane & 15) and keys 4 (lane >> 4) + r,
+//     r = 0..3: a wavefront's 32 queries x 64 keys are 4 key groups x 2 query groups = 8 accumulator quads (32 registers, as before);
+//   * the softmax reference is subtracted through the C operand: the first k-step of every score tile takes the 4-register tuple
+//     {-m, -m, -m, -m} of the lane's query as C (a 16-register tuple was what hipcc copied per tile; round 4's extra k-step with
+//     (-m_hi, -m_lo) against ones is gone with its two 32-cycle MFMAs per tile: m is fp32 now);
+//   * P as the B operand of O^T += V^T.P: k-slot 8 (lane >> 4) + j of the 32-key group G is key 32 G + 4 (lane >> 4) + j for
+//     j < 4 and 32 G + 16 + 4 (lane >> 4) + (j - 4) otherwise - the two score quads (2G, 2G+1) of the lane as they stand; the
+//     matching A fragment of V^T comes from two ds_read_b64_tr_b16 (keys 32 G + 4 (lane >> 4) + 0..3 and + 16);
+//   * the lazy reference needs no cross-lane traffic in the common case: the test "some score exceeds m by more than 2^8" is a
+//     ballot over per-lane partial maxima; the exact per-query maximum (two v_permlane swaps per query group) is only formed
+//     on the path that moves the reference.
+// LDS images: K as before (k_off: ds_read_b128 rows lane & 15, 16-byte chunk 4 ks + (lane >> 4), conflict-free in all four
+// lane groups); V with the 32-byte granule of a row XORed with (key >> 1) & 3 (v16_off): a 32-lane half of a transposed read
+// covers 8 consecutive keys x 32 bytes = all 64 banks once.
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ int v16_off(int key, int d) { return key * 64 + ((((d >> 4) ^ ((key >> 1) & 3)) << 4) | (d & 15)); }
+
+// A fragment of O^T += V^T.P for d = d0 + (lane & 15): keys r0 + {0..3} and r0 + 16 + {0..3}, r0 = 32 G + 4 (lane >> 4)
+__device__ __forceinline__ half8 v16_frag_tr(const __half* vs, int r0, int d0, int lane) {
+    const int i = lane & 15, q = i >> 2, pc = i & 3;
+    const int c = d0 + 4 * pc;
+    typedef __attribute__((address_space(3))) fp16x4 lds4;
+    fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds4*)(vs + v16_off(r0 + q, c)));
+    fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds4*)(vs + v16_off(r0 + 16 + q, c)));
+    half8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r[e] = (_Float16)a[e]; r[4 + e] = (_Float16)b[e]; }
+    return r;
+}
+
+__global__ void __launch_bounds__(ATHREADS, ATTN_WAVES) k_attn_spatial(AttnParams p) {
+    __shared__ __attribute__((aligned(1024))) __half Ks[2][BKV * 64];
+    __shared__ __attribute__((aligned(1024))) __half Vs[2][BKV * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA targets in SGPRs
+    const int l16 = lane & 15, g4 = lane >> 4;
+    const int qblocks = (p.S + BQ - 1) / BQ;
+    // all query blocks of one (sequence, head) share its K/V (2.4 MB at S = 9216): keep them on one XCD's L2
+    int bid = (int)xcd_chunk_remap(blockIdx.x, gridDim.x);
+    const int qb = bid % qblocks; bid /= qblocks;
+    const int hd = bid % p.heads;
+    const int seq = bid / p.heads;
+    const long long row0 = (long long)seq * p.S;
+    const int q0 = qb * BQ + wv * 32;
+    const __half* qp = p.q + hd * 64;
+    const __half* kp = p.k + hd * 64 + row0 * p.ld;
+    const __half* vp = p.v + hd * 64 + row0 * p.ld;
+
+    // Q fragments (B operand: query qg 16 + (lane & 15), d = 32 ks + 8 (lane >> 4) + j), prescaled by log2(e) / 8
+    half8 qf[2][2];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+        int qi = q0 + qg * 16 + l16;
+        if (qi > p.S - 1) qi = p.S - 1;
+        const __half* src = qp + (row0 + qi) * p.ld;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 t = *(const half8*)(src + ks * 32 + 8 * g4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = (_Float16)((float)t[j] * (0.125f * kLog2e));
+            qf[qg][ks] = t;
+        }
+    }
+
+    // LDS-DMA staging: a wavefront copies 1 KiB (8 keys x 128 B) per instruction, lane -> LDS slot (key = lane / 8,
+    // stored chunk = lane % 8); wavefront wv owns keys 16 wv .. 16 wv + 15 of K and of V (two pieces each).
+    unsigned ok[2], ov[2];            // per-lane byte offsets of the two source chunks inside a tile
+    const int s_key = wv * 16 + (lane >> 3), s_c = lane & 7;
+    const unsigned ldb = (unsigned)p.ld * 2u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int key = s_key + 8 * i;
+        ok[i] = (unsigned)key * ldb + (unsigned)((s_c ^ ((key >> 1) & 7)) << 4);
+        ov[i] = (unsigned)key * ldb + (unsigned)((s_c ^ (((key >> 1) & 3) << 1)) << 4);
+    }
+    auto dma_tile = [&](int kv0, int buf) {
+        // the tile's base stays a SCALAR (opaque to loop strength reduction, which would otherwise carry six per-lane
+        // 64-bit pointers through the loop): the copies take the scalar-base + 32-bit lane-offset form
+        long long tile_off = (long long)kv0 * p.ld * 2;
+        asm volatile("" : "+s"(tile_off));
+        const char* kb = (const char*)kp + tile_off;
+        const char* vb = (const char*)vp + tile_off;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(ok[i]), "+v"(ov[i]));   // keep the lane offsets 32-bit registers
+        if (kv0 + BKV <= p.S) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(kb + (size_t)ok[i]), (lds_void_t*)(&Ks[buf][(wv * 2 + i) * 512]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(vb + (size_t)ov[i]), (lds_void_t*)(&Vs[buf][(wv * 2 + i) * 512]), 16, 0, 0);
+            }
+        } else {
+            // the sequence's last, partial tile: keys beyond it are masked out of the scores below, their K / V rows only
+            // have to be finite, so they re-read the sequence's last row
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int key = s_key + 8 * i;
+                const int back = kv0 + key > p.S - 1 ? kv0 + key - (p.S - 1) : 0;
+                const unsigned d = (unsigned)back * ldb;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(kb + (size_t)(ok[i] - d)), (lds_void_t*)(&Ks[buf][(wv * 2 + i) * 512]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(vb + (size_t)(ov[i] - d)), (lds_void_t*)(&Vs[buf][(wv * 2 + i) * 512]), 16, 0, 0);
+            }
+        }
+    };
+
+    float4v ot[4][2];                 // O^T: d = 16 dt + 4 (lane >> 4) + r, query 16 qg + (lane & 15)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) ot[dt][qg] = (float4v){0.f, 0.f, 0.f, 0.f};
+    float4v lsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float4v negm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // C operand of a score tile's first k-step: -m of the lane's query
+    const half4 ones4 = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+
+    const int ntiles = (p.S + BKV - 1) / BKV;
+    // one KV tile; CUR (the LDS buffer) is a compile-time constant so every fragment address is base + immediate
+    auto tile = [&](int t, auto CUR) {
+        constexpr int cur = decltype(CUR)::value;
+        // Fragment reads are issued in batches AHEAD of the MFMAs that consume them: the four K fragments of a k-step before
+        // its eight MFMAs, and all eight V fragments before the softmax, whose VALU work then covers their latency.
+        float4v st[4][2];
+        half8 kf[4];
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) kf[kg] = *(const half8*)(&Ks[cur][k_off(kg * 16 + l16, g4)]);
+        __builtin_amdgcn_sched_barrier(0);
+        // The QK^T MFMAs issue at raised priority: VALU arbitration between the waves of a SIMD is by priority, then
+        // age, and at equal priority the other waves' softmax VALU starves this wave's matrix issue (+5 %).
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+            for (int qg = 0; qg < 2; ++qg) st[kg][qg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kg], qf[qg][0], negm[qg], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) kf[kg] = *(const half8*)(&Ks[cur][k_off(kg * 16 + l16, 4 + g4)]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+            for (int qg = 0; qg < 2; ++qg) st[kg][qg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kg], qf[qg][1], st[kg][qg], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        half8 vf[2][4];
+#pragma unroll
+        for (int G = 0; G < 2; ++G)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) vf[G][dt] = v16_frag_tr(Vs[cur], G * 32 + 4 * g4, dt * 16, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < ntiles) dma_tile((t + 1) * BKV, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int kv0 = t * BKV;
+        if (kv0 + BKV > p.S) {   // wave-uniform: mask keys beyond the sequence
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kv0 + kg * 16 + 4 * g4 + r;
+                    if (key >= p.S) { st[kg][0][r] = kNegBig; st[kg][1][r] = kNegBig; }
+                }
+        }
+        // per-lane partial maxima of the two queries (relative to the reference the matrix pipe subtracted)
+        float mq[2];
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) {
+            // v_max3_f32 written out: fmaxf() on matrix-pipe results makes hipcc canonicalise every operand first (42 v_max
+            // per tile instead of 16)
+            float a = max3(st[0][qg][0], st[0][qg][1], st[0][qg][2]), b = max3(st[1][qg][0], st[1][qg][1], st[1][qg][2]);
+            float c = max3(st[2][qg][0], st[2][qg][1], st[2][qg][2]), d = max3(st[3][qg][0], st[3][qg][1], st[3][qg][2]);
+            a = max3(a, st[0][qg][3], st[1][qg][3]);
+            c = max3(c, st[2][qg][3], st[3][qg][3]);
+            mq[qg] = max3(max3(a, b, c), d, d);
+        }
+        // m does not have to be the exact running maximum: softmax is invariant to it, it only has to keep exp2(s - m) inside
+        // fp16 (P <= 2^kLazy) and the sums inside fp32.  It is set by the first tile and moved (scores shifted, running sums
+        // rescaled, the C tuple rewritten) only when some query of the wavefront exceeds it by more than kLazy = 8.
+        const bool first = t == 0;
+        if (first || __ballot(fmaxf(mq[0], mq[1]) > kLazy) != 0ull) {
+#pragma unroll
+            for (int qg = 0; qg < 2; ++qg) {
+                float mx = mq[qg];
+                {
+                    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(mx), __float_as_int(mx), false, false);
+                    mx = fmaxf(__int_as_float(sw[0]), __int_as_float(sw[1]));
+                    auto sx = __builtin_amdgcn_permlane16_swap(__float_as_int(mx), __float_as_int(mx), false, false);
+                    mx = fmaxf(__int_as_float(sx[0]), __int_as_float(sx[1]));
+                }
+                const float delta = first ? mx : fmaxf(mx, 0.f);     // the reference moves up by delta
+                if (!first) {
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ot[dt][qg][r] *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lsum[qg][r] *= alpha;
+                }
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[kg][qg][r] -= delta;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) negm[qg][r] -= delta;
+            }
+        }
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+            for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[kg][qg][r] = __builtin_amdgcn_exp2f(st[kg][qg][r]);
+        // O^T += V^T . P, row sums += 1 . P
+#pragma unroll
+        for (int G = 0; G < 2; ++G)
+#pragma unroll
+            for (int qg = 0; qg < 2; ++qg) {
+                half8 pf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { pf[j] = (_Float16)st[2 * G][qg][j]; pf[4 + j] = (_Float16)st[2 * G + 1][qg][j]; }
+                lsum[qg] = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, __builtin_shufflevector(pf, pf, 0, 1, 2, 3), lsum[qg], 0, 0, 0);
+                lsum[qg] = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, __builtin_shufflevector(pf, pf, 4, 5, 6, 7), lsum[qg], 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) ot[dt][qg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[G][dt], pf, ot[dt][qg], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's K / V have landed
+        __syncthreads();
+    };
+    dma_tile(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int t = 0; t < ntiles; t += 2) {
+        tile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
+    }
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+        // a query's normaliser: the four lanes (lane & 15, every lane >> 4) hold its partial sums
+        float l = lsum[qg][0];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int qi = q0 + qg * 16 + l16;
+        if (qi < p.S) {
+            __half* dst = p.o + (row0 + qi) * p.ldo + hd * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                half4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = (_Float16)(ot[dt][qg][e] * inv);
+                *(half4*)(dst + dt * 16 + 4 * g4) = o4;
+            }
+        }
+    }
+}
+#endif
 
 // One wavefront per (batch, pixel, head); 4 wavefronts per block.
 __global__ void __launch_bounds__(ATHREADS, 2) k_attn_temporal(AttnParams p, long long nitems) {

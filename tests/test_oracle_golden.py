@@ -57,6 +57,25 @@ def test_forward_warp_oracle_matches_reference(name, golden_dir):
     assert d.max() <= 1 and np.mean(d > 0) < 1e-3
 
 
+def test_nearby_consistency_oracle_matches_reference(golden_dir):
+    """O4: oracle/orchestrator_oracle.nearby_consistency against the reference's own
+    consistency_check_from_nearby_images_bw (model/diffusionGS.py:1300-1361) run on five seeded 576 x 1024 frames
+    (oracle/gen_golden.py orch_nearby).  Tolerances are the inverse warp's (W2): soft masks 2e-4, nearest-neighbour picks
+    may flip on exact half-pixel ties on < 0.2 % of the pixels."""
+    from oracle import orchestrator_oracle as OO
+    K, poses, images, depths = GI.orch_nearby_case()
+    g = np.load(golden_dir / "orch_nearby.npz")
+    sy, sx = GI.ORCH_NEARBY_STRIDE
+    um, im = OO.nearby_consistency(K, poses, images, depths)
+    assert len(um) == len(im) == 5
+    for i in range(5):
+        assert_mostly_close(um[i][::sy, ::sx], g["uncertainty"][i], atol=2e-4, rtol=0, max_frac=2e-3, hard=0.6)
+        # the mean of nearest-sampled colours moves by a whole texel where the rounding of the sample position differs
+        assert_mostly_close(im[i][::sy, ::sx], g["intensity_uncertainty"][i], atol=2e-3, rtol=0, max_frac=2e-3)
+        assert abs(float(um[i].astype(np.float64).mean()) - g["uncertainty_mean"][i]) < 2e-4
+        assert abs(float(im[i].astype(np.float64).mean()) - g["intensity_uncertainty_mean"][i]) < 1e-3
+
+
 def test_sigma_schedule_matches_reference(golden_dir):
     g = np.load(golden_dir / "sched_sigmas.npz")
     s = GI.karras_sigmas(100)

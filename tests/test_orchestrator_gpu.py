@@ -159,6 +159,26 @@ def test_nearby_consistency_vs_cpu_oracle():
         assert np.mean(d > 2e-3) < 5e-3, float(np.mean(d > 2e-3))
 
 
+def test_nearby_consistency_vs_reference_golden(golden_dir):
+    """O4 pinned: the HIP path against the REFERENCE's own consistency_check_from_nearby_images_bw
+    (model/diffusionGS.py:1300-1361) run on five seeded 576 x 1024 frames (tests/golden/orch_nearby.npz, written by
+    oracle/gen_golden.py orch_nearby), with the inverse warp's tolerances (tests/test_warp_gpu.py)."""
+    from oracle import golden_inputs as GI
+    from syn3r_amd import orchestrator as O
+    from tests.test_oracle_golden import assert_mostly_close
+    K, poses, images, depths = GI.orch_nearby_case()
+    g = np.load(golden_dir / "orch_nearby.npz")
+    sy, sx = GI.ORCH_NEARBY_STRIDE
+    um, im = O.consistency_check_from_nearby_images_bw(K, poses, images, depths, device="cuda:0")
+    assert len(um) == len(im) == 5 and tuple(um[0].shape) == (576, 1024)
+    for i in range(5):
+        u, v = um[i].cpu().numpy(), im[i].cpu().numpy()
+        assert_mostly_close(u[::sy, ::sx], g["uncertainty"][i], atol=2e-4, rtol=0, max_frac=2e-3, hard=0.6)
+        assert_mostly_close(v[::sy, ::sx], g["intensity_uncertainty"][i], atol=2e-3, rtol=0, max_frac=2e-3)
+        assert abs(float(u.astype(np.float64).mean()) - g["uncertainty_mean"][i]) < 2e-4
+        assert abs(float(v.astype(np.float64).mean()) - g["intensity_uncertainty_mean"][i]) < 1e-3
+
+
 def test_warp_images_forward_variant_vs_cpu_oracle():
     """`warp_images` (diffusionGS.py:1512-1606, --interp_type forward_warp) on the HIP fp64 splat against the oracle's
     numpy splat + post-processing: the splat agrees to <= 1 uint8 step on < 0.1 % of the pixels (test_warp_gpu), so the
