@@ -635,6 +635,33 @@ def gen_orch_nearby():
           out["intensity_uncertainty_mean"])
 
 
+def gen_train_flags():
+    """The (flag, default, choices, type, action, nargs) of every `parser.add_argument` the reference's CLI declares itself
+    (scripts/train.py:28-69; the FSGS parameter groups it also instantiates live in the absent submodule).  The script
+    cannot be imported here (FSGS), so the calls are read off its syntax tree; only this table - data - is committed
+    (tests/golden/train_flags.json), and tests/test_dist_cpu.py holds syn3r_amd/launch.py to it."""
+    import ast
+    import json
+    tree = ast.parse((REF / "scripts" / "train.py").read_text())
+    rows = []
+    for node in ast.walk(tree):
+        if not (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "add_argument"):
+            continue
+        if not (isinstance(node.func.value, ast.Name) and node.func.value.id == "parser"):
+            continue
+        flags = [ast.literal_eval(a) for a in node.args]
+        kw = {}
+        for k in node.keywords:
+            if k.arg == "type":
+                kw["type"] = k.value.id
+            elif k.arg in ("default", "choices", "action", "nargs"):
+                kw[k.arg] = ast.literal_eval(k.value)
+        rows.append(dict(flags=flags, line=node.lineno, **kw))
+    rows.sort(key=lambda r: r["line"])
+    (GOLD / "train_flags.json").write_text(json.dumps(rows, indent=1) + "\n")
+    print("train_flags", len(rows), [r["flags"][0] for r in rows])
+
+
 def _reference_diffusiongs():
     """The reference's DiffusionGS class; the absent packages its module imports get empty placeholder modules (the
     methods called here never touch them, except the name `trimesh.Scene` that densify_views instantiates and drops)."""
@@ -752,6 +779,8 @@ def main():
         gen_clip_preprocess()
     if "orch" in which:
         gen_orchestrator()
+    if "train_flags" in which:
+        gen_train_flags()
     if "orch_nearby" in which:            # ~1 min of CPU: eight full-size reference inverse warps
         gen_orch_nearby()
     if "n2" in which:

@@ -9,14 +9,13 @@
 //                    one wavefront per (batch, pixel, head); tokens are addressed with the frame
 //                    stride, so the reference's permutes (attention.py:487-489,527-529) never happen.
 //
-// CDNA4 mapping (both): scores are computed transposed, S^T = K.Q^T with v_mfma_f32_32x32x16_f16,
-// so a lane owns ONE query column and its keys sit in the accumulator registers: the row max /
-// sum is a register reduction plus one lane^32 exchange (no 32-lane shuffles).  The probability
-// tile is then used directly from the accumulator as the B operand of O^T += V^T.P (the k order
-// of an accumulator-sourced fragment is permuted: element j of lane half h is key 16s + 8(j>>2) + 4h + (j&3)).
-// V stays row-major [key][d] in LDS (16-byte pieces, LDS-DMA in k_attn_spatial) and its transposed A fragments come from
-// gfx950's ds_read_b64_tr_b16: each 16-lane group fetches a 4-key x 16-d block column-major, two reads
-// (keys r0..r0+3 and r0+8..r0+11) make exactly the permuted 8-key fragment.
+// CDNA4 mapping (both): scores are computed transposed, S^T = K.Q^T, so a lane owns ONE query column and its keys sit in
+// the accumulator registers; the probability tile is used directly from the accumulator as the B operand of
+// O^T += V^T.P (the k order of an accumulator-sourced fragment is a permutation of the keys, applied to V^T's fragment
+// as well).  V stays row-major [key][d] in LDS and its transposed A fragments come from gfx950's ds_read_b64_tr_b16 (each
+// 16-lane group fetches a 4-key x 16-d block column-major).  k_attn_spatial uses v_mfma_f32_16x16x32_f16 (round 5, below),
+// k_attn_temporal v_mfma_f32_32x32x16_f16 (one 32 x 32 score tile IS its whole problem: element j of lane half h is key
+// 16s + 8(j>>2) + 4h + (j&3), two transposed reads - keys r0..r0+3 and r0+8..r0+11 - make the permuted 8-key fragment).
 #include "common.h"
 #include <type_traits>
 
@@ -84,307 +83,39 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-// k_attn_spatial: what one 32-query x 64-key score tile costs a wavefront is 16 MFMAs (32 x 32 x 16), 32 v_exp_f32,
-// 24 max, 16 cvt_pk and 24 LDS fragment reads; under this kernel the chip runs at ~1.4 GHz (GRBM_GUI_ACTIVE), the SIMD has
-// an instruction active 97 % of the time and the vector port 66 % (profiles/r04/attention_v2.txt).  Everything the
-// algorithm does not need is kept off the vector port, partly by giving it to the matrix pipe:
-//   * Q is prescaled by log2(e)/8 (one fp32 multiply, one rounding to fp16), and the running maximum is subtracted BY THE
-//     MATRIX PIPE: one extra k-step per 32-key group, A = a constant fragment with ones in k-slots 0 and 1, B = a fragment
-//     holding (-m_hi, -m_lo) of the lane's query in those slots (m = m_hi + m_lo exactly, two fp16), so the accumulator
-//     leaves the pipe as s*log2e - m, ready for v_exp_f32.  The B fragment is rewritten only when a query's maximum moved
-//     (wave-uniform test; after the first tiles of a sequence it almost never does): the 16 v_pk_fma per tile are gone for
-//     two MFMAs (16 issue cycles).  (A 16-register C tuple holding -m does the same without the extra MFMAs, but hipcc
-//     ties the second MFMA's C to its D and copies the tuple per tile: measured 3 % slower.)
-//   * the row sums come from the matrix pipe too: v_mfma_f32_4x4x4_16b_f16 with an all-ones A operand returns, in each
-//     lane, the fp32 sum of that lane's own four fp16 B values (tools/ubench/mfma4x4_rowsum.hip) — 8 two-pass MFMAs per
-//     tile replace 16 v_pk_add_f32 + their moves, and the normaliser sums exactly the fp16 probabilities the O^T MFMAs use.
+// k_attn_spatial (round 5: v_mfma_f32_16x16x32_f16).  Under this kernel the chip is clock-throttled with the matrix pipe
+// exposed (profiles/r04/pmc: MFMA busy 0.68 at 1.4-1.5 GHz), and MI355X_MICROARCH.md (DVFS give-back, item 7) measures
+// 1.12-1.15x the FLOP/s for the 16x16x32 shape in exactly that regime at equal cycles per FLOP.  One 32-query x 64-key score
+// tile costs a wavefront 36 MFMAs of 16 cycles (16 QK^T, 16 PV, 4 row sums), 32 v_exp_f32, 16 v_max3_f32, 16 v_cvt_pk and
+// 8 + 16 LDS fragment reads.  Everything the algorithm does not need is kept off the vector port:
+//   * Q is prescaled by log2(e)/8 (one fp32 multiply, one rounding to fp16);
+//   * a score tile S^T[16 keys][16 queries] leaves the pipe with the lane owning query (lane & 15) and keys 4 (lane >> 4) + r,
+//     r = 0..3: a wavefront's 32 queries x 64 keys are 4 key groups x 2 query groups = 8 accumulator quads (32 registers);
+//   * the softmax reference m is subtracted BY THE MATRIX PIPE through the C operand: the first k-step of every score tile
+//     takes the 4-register tuple {-m, -m, -m, -m} of the lane's query as C, so the accumulator leaves the pipe as
+//     s*log2e - m, ready for v_exp_f32 (hipcc emits the three-address MFMA form: no tuple copy; round 4's 32 x 32 kernel
+//     needed an extra k-step against a ones fragment for this, two 32-cycle MFMAs per tile);
+//   * m is moved lazily, and the test needs no cross-lane traffic: "some score exceeds m by more than 2^8" is a ballot over
+//     per-lane partial maxima; the exact per-query maximum (two v_permlane swaps per query group) is only formed on the
+//     path that moves the reference;
+//   * P as the B operand of O^T += V^T.P: k-slot 8 (lane >> 4) + j of the 32-key group G is key 32 G + 4 (lane >> 4) + j for
+//     j < 4 and 32 G + 16 + 4 (lane >> 4) + (j - 4) otherwise - the two score quads (2G, 2G+1) of the lane as they stand; the
+//     matching A fragment of V^T comes from two ds_read_b64_tr_b16 (keys 32 G + 4 (lane >> 4) + 0..3 and + 16);
+//   * the row sums come from the matrix pipe too: a 17th "d" tile of V^T that is all ones (a constant register fragment)
+//     gives every lane its query's COMPLETE sum over the 32 keys - one 16-cycle MFMA per (key group, query group), no
+//     cross-lane step at the end, and the normaliser sums exactly the fp16 probabilities the O^T MFMAs use (the per-lane
+//     v_mfma_f32_4x4x4_16b_f16 sums of round 4 cost twice the issue slots: +2.7 % on this kernel, same box);
 //   * K and V tiles go global -> LDS by LDS-DMA (global_load_lds, 16 B per lane; the bank swizzles are applied on the
 //     per-lane SOURCE address, both are XOR involutions of the 16-byte chunk index): no staging registers, no ds_write, and
 //     the copy is issued after the tile's last fragment read so that hipcc's conservative vmcnt(0) in front of LDS reads
 //     never waits on a copy in flight.
-// ATTN_X_* : timing experiments (wrong results), tools/build_variant.sh with SRC=attn; record in profiles/r04/attention_v2.txt
+// LDS images: K (k_off): ds_read_b128 rows lane & 15, 16-byte chunk 4 ks + (lane >> 4), conflict-free in all four lane
+// groups; V (v16_off): the 32-byte granule of a row XORed with (key >> 1) & 3 - a 32-lane half of a transposed read covers
+// 8 consecutive keys x 32 bytes = all 64 banks once.
+// Measured (profiles/r05/attention_v3.txt): 3.33-3.34 -> 3.02-3.12 ms at the level-0 shape (28 x 5 heads x 9216).
 #ifndef ATTN_WAVES
 #define ATTN_WAVES 3
 #endif
-#ifdef ATTN_MFMA32
-__global__ void __launch_bounds__(ATHREADS, ATTN_WAVES) k_attn_spatial(AttnParams p) {
-    __shared__ __attribute__((aligned(1024))) __half Ks[2][BKV * 64];
-    __shared__ __attribute__((aligned(1024))) __half Vs[2][BKV * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA targets in SGPRs
-    const int lq = lane & 31, h = lane >> 5;
-    const int qblocks = (p.S + BQ - 1) / BQ;
-    // all query blocks of one (sequence, head) share its K/V (2.4 MB at S = 9216): keep them on one XCD's L2
-    int bid = (int)xcd_chunk_remap(blockIdx.x, gridDim.x);
-    const int qb = bid % qblocks; bid /= qblocks;
-    const int hd = bid % p.heads;
-    const int seq = bid / p.heads;
-    const long long row0 = (long long)seq * p.S;
-    const int q0 = qb * BQ + wv * 32;
-    const __half* qp = p.q + hd * 64;
-    const __half* kp = p.k + hd * 64 + row0 * p.ld;
-    const __half* vp = p.v + hd * 64 + row0 * p.ld;
-
-    // Q fragments (B operand), prescaled by log2(e) / 8
-    half8 qf[4];
-    {
-        int qi = q0 + lq;
-        if (qi > p.S - 1) qi = p.S - 1;
-        const __half* src = qp + (row0 + qi) * p.ld;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            half8 t = *(const half8*)(src + ks * 16 + 8 * h);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = (_Float16)((float)t[j] * (0.125f * kLog2e));
-            qf[ks] = t;
-        }
-    }
-
-    // LDS-DMA staging: a wavefront copies 1 KiB (8 keys x 128 B) per instruction, lane -> LDS slot (key = lane / 8,
-    // stored chunk = lane % 8); wavefront wv owns keys 16 wv .. 16 wv + 15 of K and of V (two pieces each).
-    unsigned ok[2], ov[2];            // per-lane byte offsets of the two source chunks inside a tile
-    const int s_key = wv * 16 + (lane >> 3), s_c = lane & 7;
-    const unsigned ldb = (unsigned)p.ld * 2u;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int key = s_key + 8 * i;
-        ok[i] = (unsigned)key * ldb + (unsigned)((s_c ^ ((key >> 1) & 7)) << 4);
-        ov[i] = (unsigned)key * ldb + (unsigned)((s_c ^ (((key >> 1) & 1) << 2)) << 4);
-    }
-    auto dma_tile = [&](int kv0, int buf) {
-        // the tile's base stays a SCALAR (opaque to loop strength reduction, which would otherwise carry six per-lane
-        // 64-bit pointers through the loop): the copies take the scalar-base + 32-bit lane-offset form
-        long long tile_off = (long long)kv0 * p.ld * 2;
-        asm volatile("" : "+s"(tile_off));
-        const char* kb = (const char*)kp + tile_off;
-        const char* vb = (const char*)vp + tile_off;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(ok[i]), "+v"(ov[i]));   // keep the lane offsets 32-bit registers
-        if (kv0 + BKV <= p.S) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)(kb + (size_t)ok[i]), (lds_void_t*)(&Ks[buf][(wv * 2 + i) * 512]), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)(vb + (size_t)ov[i]), (lds_void_t*)(&Vs[buf][(wv * 2 + i) * 512]), 16, 0, 0);
-            }
-        } else {
-            // the sequence's last, partial tile: keys beyond it are masked out of the scores below, their K / V rows only
-            // have to be finite, so they re-read the sequence's last row
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int key = s_key + 8 * i;
-                const int back = kv0 + key > p.S - 1 ? kv0 + key - (p.S - 1) : 0;
-                const unsigned d = (unsigned)back * ldb;
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)(kb + (size_t)(ok[i] - d)), (lds_void_t*)(&Ks[buf][(wv * 2 + i) * 512]), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)(vb + (size_t)(ov[i] - d)), (lds_void_t*)(&Vs[buf][(wv * 2 + i) * 512]), 16, 0, 0);
-            }
-        }
-    };
-
-    float16v ot[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; }
-    // the max-subtracting k-step: kx = ones in k-slots 0 and 1 (lane half 0 holds slots 0-7), qx = (-m_hi, -m_lo) there
-    half8 kx, qx;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { kx[j] = (_Float16)(j < 2 ? 1.f : 0.f); qx[j] = (_Float16)0.f; }
-    float4v lsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    float m_ref = 0.f;
-    const half4 ones4 = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
-
-    const int ntiles = (p.S + BKV - 1) / BKV;
-    // one KV tile; CUR (the LDS buffer) is a compile-time constant so every fragment address is base + immediate
-    auto tile = [&](int t, auto CUR) {
-        constexpr int cur = decltype(CUR)::value;
-        // Fragment reads are issued in batches AHEAD of the MFMAs that consume them (hipcc otherwise emits
-        // read / wait / MFMA triples, exposing one LDS round trip per MFMA): all eight K fragments before QK^T, and
-        // all eight V fragments before the softmax, whose VALU work then covers their latency.
-        float16v st[2];
-        half8 kf[2][2];
-#ifdef ATTN_X_NOLDS
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) { kf[g][ks] = qf[ks]; asm volatile("" : "+v"(kf[g][ks])); }
-#else
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) kf[g][ks] = *(const half8*)(&Ks[cur][k_off(g * 32 + lq, ks * 2 + h)]);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        // The QK^T MFMAs issue at raised priority: VALU arbitration between the waves of a SIMD is by priority, then
-        // age, and at equal priority the other waves' softmax VALU starves this wave's matrix issue (+5 %).
-        const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int g = 0; g < 2; ++g) st[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kx, qx, zero16, 0, 0, 0);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int g = 0; g < 2; ++g) st[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[g][ks], qf[ks], st[g], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef ATTN_X_NOLDS
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) { kf[g][ks] = qf[ks + 2]; asm volatile("" : "+v"(kf[g][ks])); }
-#else
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) kf[g][ks] = *(const half8*)(&Ks[cur][k_off(g * 32 + lq, (ks + 2) * 2 + h)]);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int g = 0; g < 2; ++g) st[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[g][ks], qf[ks + 2], st[g], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        half8 vf[2][2][2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-#ifdef ATTN_X_NOLDS
-                for (int dt = 0; dt < 2; ++dt) { vf[g][s][dt] = qf[dt + s]; asm volatile("" : "+v"(vf[g][s][dt])); }
-#else
-                for (int dt = 0; dt < 2; ++dt) vf[g][s][dt] = v_frag_tr(Vs[cur], g * 32 + s * 16 + 4 * h, dt * 32, lane);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-#ifndef ATTN_X_NODMA
-        if (t + 1 < ntiles) dma_tile((t + 1) * BKV, cur ^ 1);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        const int kv0 = t * BKV;
-        if (kv0 + BKV > p.S) {   // wave-uniform: mask keys beyond the sequence
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int key = kv0 + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (key >= p.S) st[g][r] = kNegBig;
-                }
-        }
-        // four independent max chains (then a 2-level combine) instead of one 32-long dependent chain
-#ifdef ATTN_X_NOMAX
-        float mx = st[0][0];
-#else
-        float mq[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) mq[c] = st[c >> 1][(c & 1) * 8];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 1; r < 8; ++r) mq[c] = fmaxf(mq[c], st[c >> 1][(c & 1) * 8 + r]);
-        float mx = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
-#endif
-        {
-            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(mx), __float_as_int(mx), false, false);
-            mx = fmaxf(__int_as_float(sw[0]), __int_as_float(sw[1]));
-        }
-        // mx is the tile's maximum RELATIVE to the reference m the matrix pipe subtracted.  m does not have to be the exact
-        // running maximum: softmax is invariant to it, it only has to keep exp2(s - m) inside fp16 (P <= 2^kLazy) and the
-        // sums inside fp32.  So m is set by the first tile and moved (scores shifted, running sums rescaled, the B fragment
-        // rewritten) only when some query of the wavefront exceeds it by more than kLazy = 8 (a factor 256): with random
-        // scores the exact maximum of SOME of a wavefront's 32 queries moves in most tiles (the shift path cost 11 % of the
-        // kernel), a jump of 5.5 nats above the first tile's maximum is rare.
-        const bool first = t == 0;
-#ifdef ATTN_X_NOUPD
-        if (first) {
-#else
-        if (first || __ballot(mx > kLazy) != 0ull) {
-#endif
-            // new maximum as the two fp16 the matrix pipe will subtract; delta = what that changes against this tile's scores
-            const float m_new = m_ref + (first ? mx : fmaxf(mx, 0.f));
-            const _Float16 m_hi = (_Float16)m_new;
-            const _Float16 m_lo = (_Float16)(m_new - (float)m_hi);
-            const float m_rep = (float)m_hi + (float)m_lo;
-            const float delta = m_rep - m_ref;
-            if (!first) {
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { lsum[0][r] *= alpha; lsum[1][r] *= alpha; }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { st[0][r] -= delta; st[1][r] -= delta; }
-            m_ref = m_rep;
-            qx[0] = h == 0 ? -m_hi : (_Float16)0.f;
-            qx[1] = h == 0 ? -m_lo : (_Float16)0.f;
-        }
-#ifndef ATTN_X_NOEXP
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[g][r] = __builtin_amdgcn_exp2f(st[g][r]);
-#endif
-        // O^T += V^T . P, row sums += 1 . P
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                half8 pf = pack8(st[g], s);
-#ifndef ATTN_X_NOSUM
-                lsum[0] = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, __builtin_shufflevector(pf, pf, 0, 1, 2, 3), lsum[0], 0, 0, 0);
-                lsum[1] = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, __builtin_shufflevector(pf, pf, 4, 5, 6, 7), lsum[1], 0, 0, 0);
-#endif
-#ifdef ATTN_X_NOPV
-                asm volatile("" :: "v"(pf), "v"(vf[g][s][0]), "v"(vf[g][s][1]));
-#else
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[g][s][dt], pf, ot[dt], 0, 0, 0);
-#endif
-            }
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's K / V have landed
-#ifndef ATTN_X_NOBAR
-        __syncthreads();
-#endif
-    };
-    dma_tile(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    for (int t = 0; t < ntiles; t += 2) {
-        tile(t, std::integral_constant<int, 0>{});
-        if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
-    }
-    const float l_run = lsum[0][0] + lsum[1][0];
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int qi = q0 + lq;
-    if (qi < p.S) {
-        __half* dst = p.o + (row0 + qi) * p.ldo + hd * 64;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                half4 o4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o4[e] = (_Float16)(ot[dt][4 * g + e] * inv);
-                *(half4*)(dst + dt * 32 + 8 * g + 4 * h) = o4;
-            }
-    }
-}
-
-#else
-// Round 5: the same algorithm on v_mfma_f32_16x16x32_f16.  Under this kernel the chip is clock-throttled with the matrix pipe
-// exposed (profiles/r04/pmc: MFMA busy 0.68 at 1.4-1.5 GHz), and MI355X_MICROARCH.md (DVFS give-back, item 7) measures 1.12-1.15x
-// the FLOP/s for the 16x16x32 shape in exactly that regime at equal cycles per FLOP.  What changes with the shape:
-//   * a score tile S^T[16 keys][16 queries] leaves the pipe with the lane owning query (lane & 15) and keys 4 (lane >> 4) + r,
-//     r = 0..3: a wavefront's 32 queries x 64 keys are 4 key groups x 2 query groups = 8 accumulator quads (32 registers, as before);
-//   * the softmax reference is subtracted through the C operand: the first k-step of every score tile takes the 4-register tuple
-//     {-m, -m, -m, -m} of the lane's query as C (a 16-register tuple was what hipcc copied per tile; round 4's extra k-step with
-//     (-m_hi, -m_lo) against ones is gone with its two 32-cycle MFMAs per tile: m is fp32 now);
-//   * P as the B operand of O^T += V^T.P: k-slot 8 (lane >> 4) + j of the 32-key group G is key 32 G + 4 (lane >> 4) + j for
-//     j < 4 and 32 G + 16 + 4 (lane >> 4) + (j - 4) otherwise - the two score quads (2G, 2G+1) of the lane as they stand; the
-//     matching A fragment of V^T comes from two ds_read_b64_tr_b16 (keys 32 G + 4 (lane >> 4) + 0..3 and + 16);
-//   * the lazy reference needs no cross-lane traffic in the common case: the test "some score exceeds m by more than 2^8" is a
-//     ballot over per-lane partial maxima; the exact per-query maximum (two v_permlane swaps per query group) is only formed
-//     on the path that moves the reference.
-// LDS images: K as before (k_off: ds_read_b128 rows lane & 15, 16-byte chunk 4 ks + (lane >> 4), conflict-free in all four
-// lane groups); V with the 32-byte granule of a row XORed with (key >> 1) & 3 (v16_off): a 32-lane half of a transposed read
-// covers 8 consecutive keys x 32 bytes = all 64 banks once.
 __device__ __forceinline__ float max3(float a, float b, float c) {
     float d;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -485,7 +216,9 @@ __global__ void __launch_bounds__(ATHREADS, ATTN_WAVES) k_attn_spatial(AttnParam
         for (int qg = 0; qg < 2; ++qg) ot[dt][qg] = (float4v){0.f, 0.f, 0.f, 0.f};
     float4v lsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float4v negm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // C operand of a score tile's first k-step: -m of the lane's query
-    const half4 ones4 = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+    half8 ones8;                      // A operand of the row sums: a 17th "d" tile of V^T that is all ones
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones8[j] = (_Float16)1.f;
 
     const int ntiles = (p.S + BKV - 1) / BKV;
     // one KV tile; CUR (the LDS buffer) is a compile-time constant so every fragment address is base + immediate
@@ -567,7 +300,7 @@ __global__ void __launch_bounds__(ATHREADS, ATTN_WAVES) k_attn_spatial(AttnParam
 #pragma unroll
                         for (int r = 0; r < 4; ++r) ot[dt][qg][r] *= alpha;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) lsum[qg][r] *= alpha;
+                    for (int r = 0; r < 4; ++r) lsum[qg][r] *= alpha;     // (only row 0 is read at the end)
                 }
 #pragma unroll
                 for (int kg = 0; kg < 4; ++kg)
@@ -591,8 +324,7 @@ __global__ void __launch_bounds__(ATHREADS, ATTN_WAVES) k_attn_spatial(AttnParam
                 half8 pf;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { pf[j] = (_Float16)st[2 * G][qg][j]; pf[4 + j] = (_Float16)st[2 * G + 1][qg][j]; }
-                lsum[qg] = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, __builtin_shufflevector(pf, pf, 0, 1, 2, 3), lsum[qg], 0, 0, 0);
-                lsum[qg] = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, __builtin_shufflevector(pf, pf, 4, 5, 6, 7), lsum[qg], 0, 0, 0);
+                lsum[qg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf, lsum[qg], 0, 0, 0);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) ot[dt][qg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[G][dt], pf, ot[dt][qg], 0, 0, 0);
             }
@@ -608,11 +340,8 @@ __global__ void __launch_bounds__(ATHREADS, ATTN_WAVES) k_attn_spatial(AttnParam
     }
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg) {
-        // a query's normaliser: the four lanes (lane & 15, every lane >> 4) hold its partial sums
-        float l = lsum[qg][0];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = 1.0f / l;
+        // a query's normaliser: every row of the ones tile is the complete sum over the keys
+        const float inv = 1.0f / lsum[qg][0];
         const int qi = q0 + qg * 16 + l16;
         if (qi < p.S) {
             __half* dst = p.o + (row0 + qi) * p.ldo + hd * 64;
@@ -626,7 +355,6 @@ __global__ void __launch_bounds__(ATHREADS, ATTN_WAVES) k_attn_spatial(AttnParam
         }
     }
 }
-#endif
 
 // One wavefront per (batch, pixel, head); 4 wavefronts per block.
 __global__ void __launch_bounds__(ATHREADS, 2) k_attn_temporal(AttnParams p, long long nitems) {

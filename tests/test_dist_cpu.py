@@ -73,3 +73,47 @@ def test_launcher_arguments_and_assignment():
     import pytest
     with pytest.raises(SystemExit):
         launch.parse(["--scenes", "x", "--interp_type", "sideways"])
+
+
+def test_launcher_defaults_are_the_reference_scripts(golden_dir):
+    """Every flag scripts/train.py declares itself (:28-69) exists in the launcher with the reference's default, choices,
+    type and action - from tests/golden/train_flags.json, the table oracle/gen_golden.py train_flags read off the script."""
+    import json
+    from syn3r_amd import launch
+    rows = json.loads((golden_dir / "train_flags.json").read_text())
+    assert len(rows) == 29
+    a = launch.parse(["--scenes", "x"])
+    types = {"float": float, "int": int, "str": str, "bool": bool}
+    import argparse
+    ap_actions = {}
+    orig = argparse.ArgumentParser.add_argument
+
+    def spy(self, *flags, **kw):
+        act = orig(self, *flags, **kw)
+        ap_actions[flags[0]] = act
+        return act
+
+    argparse.ArgumentParser.add_argument = spy
+    try:
+        launch.parse(["--scenes", "x"])
+    finally:
+        argparse.ArgumentParser.add_argument = orig
+    for r in rows:
+        flag = r["flags"][0]
+        assert flag in ap_actions, flag
+        act = ap_actions[flag]
+        want = r.get("default", False if r.get("action") == "store_true" else None)
+        assert getattr(a, flag.lstrip("-")) == want, (flag, getattr(a, flag.lstrip("-")), want)
+        assert (list(act.choices) if act.choices else None) == r.get("choices"), flag
+        if "type" in r:
+            assert act.type is types[r["type"]], flag
+        if r.get("action") == "store_true":
+            assert isinstance(act, argparse._StoreTrueAction), flag
+        else:
+            assert act.nargs == r.get("nargs"), flag
+    # the batch scripts' command lines carry FSGS flags as well: accepted, reported as ignored
+    b = launch.parse("--scenes fern --iteration dgs1 --weight_clamp 0.2 --diffusion_type 2PassProbUncertainPost --interp_type backward_warp "
+                     "--cam_confidence 0.05 --pseudo_cam_sampling_rate 0.02 --densify_type interpolate_gs_v2 --refine_cycle_num 2 "
+                     "--num_views_for_pcd_densification 1 -s /data/fern --eval --n_views 3 --resolution 1 --use_dust3r 0".split())
+    assert b.refine_cycle_num == 2 and b.num_views_for_pcd_densification == 1 and b.weight_clamp == 0.2
+    assert b.ignored_flags == ["-s", "/data/fern", "--eval", "--n_views", "3", "--resolution", "1", "--use_dust3r", "0"]
