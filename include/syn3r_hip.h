@@ -19,7 +19,11 @@
  *     (a void* here so that the header needs no HIP include).
  *   - return value: 0 = ok, negative = error (SYN3R_E_*); the message is
  *     available from syn3r_last_error() (thread-local).
- *   - no global mutable state besides the thread-local error string.
+ *   - no process-wide settings: the library reads no environment variable and keeps no mutable state
+ *     shared between host threads that changes what a call computes or which kernel it launches.  What
+ *     state there is: the thread-local error string, the per-thread test hook and split-K workspace
+ *     (syn3r_gemm_set_tile, syn3r_gemm_set_splitk_workspace), the opt-in tracer (syn3r_trace_*), handles
+ *     the caller creates (syn3r_unet_create), and per-device launch attributes set on first use.
  */
 #ifndef SYN3R_HIP_H
 #define SYN3R_HIP_H
@@ -306,11 +310,10 @@ int syn3r_gemm_2src_f16(const void* A1, long long lda1, int K1, const void* A2, 
 
 /* Test / tuning hook, PER CALLING THREAD (thread-local: the library holds no state shared between host threads): the
  * contraction kernel family this thread's next launches use.  0 = chosen per shape (default); -128 / -256 = the 160-column
- * LDS-DMA kernel of that block height; -320 = the persistent 256 x 320 kernel wherever it admits the shape; -321 = the
- * 128 x 320 two-blocks-per-CU kernel (dense contractions; the convolutions keep the default); -322 = the software-pipelined
- * persistent 256 x 320 kernel (round 4: dense, two-source and implicit-GEMM convolution modes) wherever it admits the shape.
- * -3200 / -3201 (independent of the above, sticky until changed): the fused feed-forward entries (syn3r_feedforward_fused*_f16) run
- * the kernel with the x tile in LDS / in registers (default -3201; both give the same bits). */
+ * LDS-DMA kernel of that block height; -320 = the persistent 256 x 320 kernel wherever it admits the shape; -322 = the
+ * software-pipelined persistent 256 x 320 kernel (dense, two-source and implicit-GEMM convolution modes) wherever it admits
+ * the shape.  This hook and the split-K workspace below are the library's only settings, both per calling thread; it reads no
+ * environment variable (dispatch switches for A/B measurements exist in -DSYN3R_TUNING developer builds only). */
 int syn3r_gemm_set_tile(int bm);
 
 /* Split-K scratch, PER CALLING THREAD (round 4).  With a workspace set, the contractions (syn3r_gemm_f16, syn3r_gemm_2src_f16

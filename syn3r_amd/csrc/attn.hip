@@ -449,6 +449,7 @@ extern "C" int syn3r_attention_f16(const void* q, const void* k, const void* v, 
     SYN3R_REQUIRE(q && k && v && out, "attention: null tensor");
     SYN3R_REQUIRE(SYN3R_DIM_OK(nseq) && SYN3R_DIM_OK(S) && heads > 0 && heads <= 4096, "attention: bad sizes nseq=%d S=%d heads=%d", nseq, S, heads);
     SYN3R_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && ld >= 64 * heads && ldo >= 64 * heads, "attention: bad strides");
+    SYN3R_REQUIRE(ld < (1ll << 24), "attention: row stride %lld too large (the K / V tile offsets 64 * ld * 2 are 32-bit)", ld);
     SYN3R_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0, "attention: misaligned tensor");
     AttnParams p{};
     p.q = (const __half*)q; p.k = (const __half*)k; p.v = (const __half*)v; p.ld = ld;

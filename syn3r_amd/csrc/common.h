@@ -36,6 +36,16 @@ struct Mat3d { double m[9]; };
 
 }  // namespace syn3r
 
+// Dispatch switches for A/B measurements exist only in developer builds (-DSYN3R_TUNING through SYN3R_EXTRA_HIPCC_FLAGS,
+// syn3r_amd/build.py): the shipped library reads no environment variable and holds no mutable process-wide state
+// (include/syn3r_hip.h; tests/test_abi_cpu.py checks the sources and the built library for getenv).
+#ifdef SYN3R_TUNING
+#include <stdlib.h>
+inline int tune_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+constexpr int tune_env(const char*, int dflt) { return dflt; }
+#endif
+
 // Upper bound of every int size argument of the ABI (rows, channels, image sides, Gaussians ...): checked FIRST, so the
 // size arithmetic behind the other checks (products, round-ups) stays inside int / long long whatever the caller passes
 // (tests/test_abi_sanitize.py drives every entry point with INT_MAX and friends under UBSan).

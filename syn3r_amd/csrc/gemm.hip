@@ -17,19 +17,35 @@
 // per shape by launch_dma (DESIGN.md section 4 has the measurements behind every rule):
 //   k_gemm_widep   persistent 256 x 320 tile (dense contractions whose tiles fill the CUs): LDS-DMA 2-stage ring,
 //                  cross-tile prefetch, scalar addressing, lean epilogue, GEGLU gate in registers, two-source A
-//   k_gemm_w128    128 x 320 tile, two blocks per CU (K <= 320 with N > 640: the level-0 qkv projection)
-//   k_ffn320       FeedForward (GEGLU) for C = 320 in one kernel, hidden activation never leaves the CU
+//   k_gemm_z       the same tile with a software-pipelined main loop (gemm_z.h): gated projections, 3x3 convolutions
+//   k_ffn320r      FeedForward (GEGLU) for C = 320 in one kernel, hidden activation never leaves the CU
+//   k_lnlin320     LayerNorm + stacked q / k / v projection for C = 320 in one kernel
 //   k_gemm_dma     BM x 160 tile, LDS-DMA 3-stage ring (BM = 256, wavefronts 4-7 staggered; every convolution /
 //                  temporal convolution and the K = 320 residual projections) or 2-stage (BM = 128, small grids)
 //   k_gemm_skinny  M <= 16 rows (time embedding, folded cross-attention context)
 #include "common.h"
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 using namespace syn3r;
 
 namespace {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: remembered per (kernel, device), so a host that
+// drives several GPUs from one process gets the 160 KB LDS attribute on each of them.
+struct DevOnce { std::atomic<unsigned long long> done{0}; };
+inline int set_max_lds(DevOnce& once, const void* fn, int bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;       // devices beyond 63: set on every launch
+    if (bit && (once.done.load(std::memory_order_acquire) & bit)) return SYN3R_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return check_hip(e, what);
+    once.done.fetch_or(bit, std::memory_order_release);
+    return SYN3R_OK;
+}
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
@@ -1188,141 +1204,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm_dmap(GemmParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// 128 x 320 variant of the wide tile: the same 64 x 160 wavefront tile (160 accumulators), FOUR wavefronts,
-// 32-wide k stages (28,672 B; 2-stage ring 57,344 B) so that TWO blocks share a CU.  In one block the contraction
-// core, the GEGLU gate (vector ALU) and the output stores run one after the other (measured on the L0 gated
-// projection: 491 + 115 + 177 us); with a second, independent block on the CU one block's gate and store tail
-// overlap the other's k-loop.  Against the 256-row tile it re-reads the weight panel twice as often (0.70
-// instead of 0.45 staged bytes per MAC row; the 128 x 160 blocks: 0.90).  Dense mode only.
-// LDS rows are 64 bytes (4 chunks of 16 B): slot = chunk ^ s(row >> 2 & 3) with s = (0,2,3,1) keeps every
-// 16-lane group of a ds_read_b128 fragment read on 16 different 16-byte bank units.
-constexpr int HBK = 32;
-constexpr int H_A_BYTES = 128 * HBK * 2;                     // 8,192
-constexpr int H_B_BYTES = WBN * HBK * 2;                     // 20,480
-constexpr int H_STAGE = H_A_BYTES + H_B_BYTES;               // 28,672
-
+// 16-byte chunk swizzle of LDS images with 64-byte rows (4 chunks): slot = chunk ^ s(row >> 2 & 3) with s = (0,2,3,1) keeps every
+// 16-lane group of a ds_read_b128 fragment read on 16 different 16-byte bank units (k_lnlin320's weight stages).
 __device__ __forceinline__ int h_swz(int row_in_16) { return (0x78 >> (2 * (row_in_16 >> 2))) & 3; }
-
-__global__ void __launch_bounds__(256, 2) k_gemm_w128(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv >> 1, wn = wv & 1;
-    const int tiles_n = (p.N + WBN - 1) / WBN;
-    const int tiles_m = (p.M + 127) / 128;
-    const unsigned bid = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
-    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
-    const int m0 = tile_m * 128, n0 = tile_n * WBN;
-
-    // DMA pieces: 1 KiB = 16 rows x 64 B; lane -> (row, destination slot); per wavefront 2 of A, 5 of W
-    const int prow = lane >> 2;
-    const int csrc = (lane & 3) ^ h_swz(prow);
-    const __half* a_base[2];
-    const __half* b_base[5];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + (wv * 2 + i) * 16 + prow;
-        if (p.a_tiled) {
-            const int last_rb = (p.M + 127) >> 7, rb = (m >> 7) < last_rb ? (m >> 7) : last_rb - 1;
-            a_base[i] = p.A + (long long)rb * (p.K >> 6) * 8192 + (m & 127) * 64 + csrc * 8;
-        } else {
-            a_base[i] = p.A + (long long)(m < p.M ? m : p.M - 1) * p.lda + csrc * 8;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int n = n0 + (wv * 5 + j) * 16 + prow;
-        b_base[j] = p.W + (long long)(n < p.N ? n : p.N - 1) * p.K + csrc * 8;      // columns past N are never stored
-    }
-    auto issue_stage = [&](int s, int buf) {
-        char* st = smem_raw + buf * H_STAGE;
-        const int ka = p.a_tiled ? (s >> 1) * 8192 + (s & 1) * HBK : s * HBK;
-        const int kb = s * HBK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_base[i] + ka), (lds_void_t*)(st + (wv * 2 + i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_base[j] + kb), (lds_void_t*)(st + H_A_BYTES + (wv * 5 + j) * 1024), 16, 0, 0);
-    };
-
-    float4v acc[2][TM][TN];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[hh][i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
-
-    const int nks = p.K / HBK;
-    const int fr = lane & 15, fq = lane >> 4;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
-    const unsigned slot = (unsigned)((fq ^ h_swz(fr)) << 4);
-    const unsigned a_row = (unsigned)((wm * WM + fr) * 64) + slot;
-    const unsigned b_row = (unsigned)(H_A_BYTES + (wn * 160 + fr) * 64) + slot;
-
-    issue_stage(0, 0);
-    int buf = 0;
-    for (int s = 0; s < nks; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage s (the only one in flight) has landed
-        __builtin_amdgcn_s_barrier();
-        if (s + 1 < nks) issue_stage(s + 1, buf ^ 1);        // the slot every wavefront finished reading in step s-1
-        const unsigned aa = lds0 + (unsigned)buf * H_STAGE + a_row, ba = lds0 + (unsigned)buf * H_STAGE + b_row;
-        half8 af[TM], bf[WTN];
-        DS_READ128(af[0], aa, 0); DS_READ128(af[1], aa, 1024); DS_READ128(af[2], aa, 2048); DS_READ128(af[3], aa, 3072);
-        DS_READ128(bf[0], ba, 0); DS_READ128(bf[1], ba, 1024); DS_READ128(bf[2], ba, 2048); DS_READ128(bf[3], ba, 3072);
-        DS_READ128(bf[4], ba, 4096); DS_READ128(bf[5], ba, 5120); DS_READ128(bf[6], ba, 6144); DS_READ128(bf[7], ba, 7168);
-        DS_READ128(bf[8], ba, 8192); DS_READ128(bf[9], ba, 9216);
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]),
-                       "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7]), "+v"(bf[8]), "+v"(bf[9]));
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < WTN; ++j)
-                acc[j / TN][i][j % TN] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[j / TN][i][j % TN], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        buf ^= 1;
-    }
-    __syncthreads();   // every wavefront is done reading the ring before the epilogue reuses it
-
-    if (p.geglu_D > 0) {
-        // GEGLU.forward: the wavefront's 160 columns are one packed group [80 hidden | 80 gate]
-        const int gn = n0 + wn * 160;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = gn + j * 16 + fq * 4;
-            float bh[4], bg[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                bh[r] = (p.bias && n + r < p.N) ? __half2float(p.bias[n + r]) : 0.f;
-                bg[r] = (p.bias && n + 80 + r < p.N) ? __half2float(p.bias[n + 80 + r]) : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {       // pairs: the gate is packed fp32 arithmetic (gelu_pk, common.h)
-                    const syn3r_f2 hv = (syn3r_f2){(float)(_Float16)(acc[0][i][j][r] + bh[r]), (float)(_Float16)(acc[0][i][j][r + 1] + bh[r + 1])};
-                    const syn3r_f2 gv = (syn3r_f2){(float)(_Float16)(acc[1][i][j][r] + bg[r]), (float)(_Float16)(acc[1][i][j][r + 1] + bg[r + 1])};
-#ifdef SYN3R_EXP_NOGATE        // timing experiments (wrong results): compile the gate / the output stores out
-                    const syn3r_f2 y = hv + gv;
-#else
-                    const syn3r_f2 y = hv * gelu_pk(gv);
-#endif
-                    acc[0][i][j][r] = y.x; acc[0][i][j][r + 1] = y.y;
-                }
-        }
-        GemmParams q = p;
-        q.bias = nullptr; q.rowvec = nullptr; q.residual = nullptr; q.aux = nullptr; q.s_acc = 1.0f;
-        q.N = p.geglu_D; q.geglu_D = 0;
-        gemm_epilogue<0>(q, acc[0], smem_raw, lane, wv, wm, wn, m0, tile_n * 160, tile_n);
-        return;
-    }
-    gemm_epilogue<0>(p, acc[0], smem_raw, lane, wv, wm, wn * 2, m0, n0, tile_n);
-    __builtin_amdgcn_wave_barrier();
-    gemm_epilogue<0>(p, acc[1], smem_raw, lane, wv, wm, wn * 2 + 1, m0, n0, tile_n);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Fused feed-forward for C = 320 (the level-0 transformer blocks: FeedForward.forward, attention.py:608-665, with the
@@ -1437,210 +1321,6 @@ __device__ __forceinline__ void ln_tile320(char* smem_raw, int tid, int m0, int 
         __syncthreads();
     }
 
-}
-
-__global__ void __launch_bounds__(512, 2) k_ffn320(FfnParams q) {
-    const GemmParams& p = q.e;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv >> 2, wn = wv & 3;
-    const int tiles_m = (p.M + F_BM - 1) / F_BM;
-    const int m0 = (int)xcd_remap(blockIdx.x, (unsigned)tiles_m) * F_BM;
-    const int nchunks = q.D / F_HC;
-    const long long D = q.D;
-
-    // ---- DMA lane assignment (as k_gemm_dma): a wave-instruction moves 8 rows x 128 B; lane -> (row, slot), the
-    // XOR swizzle is applied to the SOURCE chunk and undone by the fragment reads.  Pieces per wavefront and stage:
-    // x / W1 k-tile (16 pieces) 2; W2 half (20 pieces) 3 (wavefronts 0-3) or 2 (4-7).
-    const int prow = lane >> 3;
-    const int csrc = (lane & 7) ^ prow;
-    const int nbw = wv < 4 ? 3 : 2;
-    const int b_first = wv < 4 ? wv * 3 : 12 + (wv - 4) * 2;
-    const __half* w1_lane = q.w1 + (long long)((wv * 2) * 8 + prow) * F_C + csrc * 8;      // + i * 8 * 320 per piece
-    const __half* w2_lane = p.W + (long long)(b_first * 8 + prow) * D + csrc * 8;           // + i * 8 * D per piece
-    const __half* b1_lane = q.b1 + lane * 2;
-    char* const ring = smem_raw + F_RING;
-    char* const bias_line = smem_raw + F_BIAS + wv * 512;
-
-    int ij = 0, ir = 0, islot = 0;       // issue cursor: chunk, stage within the chunk (0..4 = W1 k-tiles, 5..6 = W2 halves), ring slot
-    auto issue_next = [&]() {
-        if (ij >= nchunks) return;
-        char* slot = ring + islot * F_SLOT;
-        if (ir < 5) {
-            const __half* src = w1_lane + (long long)ij * (128 * F_C) + ir * BK;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + i * 8 * F_C), (lds_void_t*)(slot + (wv * 2 + i) * 1024), 16, 0, 0);
-            if (ir == 0)       // the chunk's 128 packed bias values ride with its first stage (one 4-byte DMA per lane)
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)(b1_lane + ij * 128), (lds_void_t*)(bias_line + (ij & 1) * 256), 4, 0, 0);
-        } else {
-            const __half* src = w2_lane + (long long)(ir - 5) * 160 * D + (long long)ij * F_HC;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (i < nbw)
-                    __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + (long long)i * 8 * D), (lds_void_t*)(slot + (b_first + i) * 1024), 16, 0, 0);
-        }
-        if (++ir == 7) { ir = 0; ++ij; }
-        if (++islot == 3) islot = 0;
-    };
-
-    // ---- prologue: the x tile (five k-tile images of [128 x 64]) and the first weight stage
-#pragma unroll
-    for (int kt = 0; kt < 5; ++kt)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int m = m0 + (wv * 2 + i) * 8 + prow;
-            m = m < p.M ? m : p.M - 1;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(p.A + (long long)m * p.lda + kt * BK + csrc * 8),
-                                             (lds_void_t*)(smem_raw + kt * 16384 + (wv * 2 + i) * 1024), 16, 0, 0);
-        }
-    issue_next();
-
-    // LayerNorm of the resident x tile (attention.py:430-453: norm3 in front of ff), so that the normalised activation is never
-    // written to / re-read from HBM
-    if (q.ln_g) ln_tile320(smem_raw, tid, m0, p.M, (float)p.N, q.ln_g, q.ln_b, q.ln_eps, q.ln_add, q.ln_add_rpv);
-
-    float4v acc[TM][TN];                  // out: 64 rows x 80 columns of this wavefront
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
-
-    const int fr = lane & 15, fq = lane >> 4;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
-    const unsigned sw0 = (unsigned)(((0 + fq) ^ (fr & 7)) << 4), sw1 = (unsigned)(((4 + fq) ^ (fr & 7)) << 4);
-    const unsigned x_row = lds0 + (unsigned)((wm * 64 + fr) * 128);               // + kt * 16384 + i * 2048 + sw
-    const unsigned w1_row = (unsigned)((wn * 32 + fr) * 128);                      // inside a slot: hidden tile, gate tile at + 2048
-    const unsigned w2_row = (unsigned)(((wn & 1) * 80 + fr) * 128);                // inside the wavefront's half slot, + jt * 2048
-    const unsigned h_rd = lds0 + F_H + (unsigned)((wm * 64 + fr) * 128);           // + i * 2048 + sw
-    // gate output: lane owns rows wm*64 + i*16 + fr, hidden columns c = wn*16 + fq*4 .. +3
-    const int hc = wn * 16 + fq * 4;
-    const unsigned h_wr = lds0 + F_H + (unsigned)((wm * 64 + fr) * 128) + (unsigned)((((hc >> 3) ^ (fr & 7)) << 4) + (hc & 7) * 2);
-    const unsigned bias_rd = lds0 + F_BIAS + (unsigned)(wv * 512 + (wn * 32 + fq * 4) * 2);   // + (j & 1) * 256 ; gate at + 32
-
-#ifdef SYN3R_TIMING      // tools/wide_timing.py --ffn: s_memtime ticks per chunk of [wait, barrier, reads+issue, mfma] of phase 1, gate, P wait+barrier, phase 2
-    unsigned long long ft[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f_a = __builtin_amdgcn_s_memtime();
-#define FSTAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ft[i] += t_ - f_a; f_a = t_; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define FSTAMP(i)
-#endif
-    int cslot = 0;
-    for (int j = 0; j < nchunks; ++j) {
-        float4v S[TM][2];                 // [row tile][0 = hidden tile | 1 = gate tile]
-#pragma unroll
-        for (int i = 0; i < TM; ++i) { S[i][0] = (float4v){0.f, 0.f, 0.f, 0.f}; S[i][1] = (float4v){0.f, 0.f, 0.f, 0.f}; }
-        half4v bh, bg;
-#pragma unroll
-        for (int kt = 0; kt < 5; ++kt) {
-            // stage (j, kt) has landed once only the stage issued after it is still in flight (per-wave DMA counts:
-            // W1 k-tile 2 (+1 bias line with k-tile 0), W2 half 3 or 2)
-            if (kt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (kt < 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (wv < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            FSTAMP(0);
-            __builtin_amdgcn_s_barrier();
-            FSTAMP(1);
-            const unsigned xa = x_row + (unsigned)(kt * 16384);
-            const unsigned wa = lds0 + F_RING + (unsigned)(cslot * F_SLOT) + w1_row;
-            half8 a0[TM], b0[2], a1[TM], b1[2];
-            DS_READ128(a0[0], xa + sw0, 0); DS_READ128(a0[1], xa + sw0, 2048); DS_READ128(a0[2], xa + sw0, 4096); DS_READ128(a0[3], xa + sw0, 6144);
-            DS_READ128(b0[0], wa + sw0, 0); DS_READ128(b0[1], wa + sw0, 2048);
-            DS_READ128(a1[0], xa + sw1, 0); DS_READ128(a1[1], xa + sw1, 2048); DS_READ128(a1[2], xa + sw1, 4096); DS_READ128(a1[3], xa + sw1, 6144);
-            DS_READ128(b1[0], wa + sw1, 0); DS_READ128(b1[1], wa + sw1, 2048);
-            if (kt == 0) {
-                const unsigned ba = bias_rd + (unsigned)((j & 1) * 256);
-                DS_READ64(bh, ba, 0); DS_READ64(bg, ba, 32);
-            }
-            // the next stage's DMA is issued AFTER this stage's fragment reads: its issue time (60-100 cycles per piece)
-            // covers the reads' latency instead of preceding it
-            issue_next();                 // into the slot every wavefront finished reading before this barrier
-            if (kt == 0) issue_next();    // ... and the second slot the previous chunk's phase 2 released
-            FSTAMP(2);
-            if (kt == 0) {
-                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(b0[0]), "+v"(b0[1]));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(b0[0]), "+v"(b0[1]));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                S[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0[0], a0[i], S[i][0], 0, 0, 0);
-                S[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0[1], a0[i], S[i][1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt == 0) {
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(b1[0]), "+v"(b1[1]), "+v"(bh), "+v"(bg));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(b1[0]), "+v"(b1[1]));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                S[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[0], a1[i], S[i][0], 0, 0, 0);
-                S[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[1], a1[i], S[i][1], 0, 0, 0);
-            }
-            if (++cslot == 3) cslot = 0;
-            FSTAMP(3);
-        }
-        // ---- gate (GEGLU.forward): hidden * gelu(gate) on the fp16-rounded projection outputs (packed fp32 pairs,
-        // gelu_pk), written as the k-tile image of the second contraction (same swizzle as the DMA'd tiles)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            half4v o;
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                const syn3r_f2 hv = (syn3r_f2){(float)(_Float16)(S[i][0][r] + (float)bh[r]), (float)(_Float16)(S[i][0][r + 1] + (float)bh[r + 1])};
-                const syn3r_f2 gv = (syn3r_f2){(float)(_Float16)(S[i][1][r] + (float)bg[r]), (float)(_Float16)(S[i][1][r + 1] + (float)bg[r + 1])};
-                const syn3r_f2 y = hv * gelu_pk(gv);
-                o[r] = (_Float16)y.x; o[r + 1] = (_Float16)y.y;
-            }
-            DS_WRITE64(h_wr + (unsigned)(i * 2048), o);
-        }
-        FSTAMP(4);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // both W2 halves have landed, h is written
-        __builtin_amdgcn_s_barrier();
-        FSTAMP(5);
-        // ---- phase 2: out[64 x 80] += h[64 x 64] . W2[80 x 64]^T ; the wavefront's columns sit in half wn >> 1
-        {
-            int bslot = cslot + (wn >> 1);
-            if (bslot >= 3) bslot -= 3;
-            const unsigned wa = lds0 + F_RING + (unsigned)(bslot * F_SLOT) + w2_row;
-            half8 af[TM], bf[TN], ag[TM], bgf[TN];
-            DS_READ128(af[0], h_rd + sw0, 0); DS_READ128(af[1], h_rd + sw0, 2048); DS_READ128(af[2], h_rd + sw0, 4096); DS_READ128(af[3], h_rd + sw0, 6144);
-            DS_READ128(bf[0], wa + sw0, 0); DS_READ128(bf[1], wa + sw0, 2048); DS_READ128(bf[2], wa + sw0, 4096); DS_READ128(bf[3], wa + sw0, 6144);
-            DS_READ128(bf[4], wa + sw0, 8192);
-            DS_READ128(ag[0], h_rd + sw1, 0); DS_READ128(ag[1], h_rd + sw1, 2048); DS_READ128(ag[2], h_rd + sw1, 4096); DS_READ128(ag[3], h_rd + sw1, 6144);
-            DS_READ128(bgf[0], wa + sw1, 0); DS_READ128(bgf[1], wa + sw1, 2048); DS_READ128(bgf[2], wa + sw1, 4096); DS_READ128(bgf[3], wa + sw1, 6144);
-            DS_READ128(bgf[4], wa + sw1, 8192);
-            issue_next();                 // next chunk's first W1 k-tile (+ bias line) into the slot of this chunk's last
-            asm volatile("s_waitcnt lgkmcnt(9)"
-                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jt = 0; jt < TN; ++jt) acc[i][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[jt], af[i], acc[i][jt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(ag[0]), "+v"(ag[1]), "+v"(ag[2]), "+v"(ag[3]), "+v"(bgf[0]), "+v"(bgf[1]), "+v"(bgf[2]), "+v"(bgf[3]), "+v"(bgf[4]));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jt = 0; jt < TN; ++jt) acc[i][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bgf[jt], ag[i], acc[i][jt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        cslot += 2;
-        if (cslot >= 3) cslot -= 3;
-        FSTAMP(6);
-    }
-#ifdef SYN3R_TIMING
-    if (blockIdx.x == gridDim.x / 2 && lane == 0)
-        for (int i = 0; i < 8; ++i) g_wide_timing[wv * 8 + i] = i < 7 ? ft[i] : (unsigned long long)nchunks;
-#endif
-#undef FSTAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // every wavefront is done with the tiles before the epilogue reuses the LDS
-    gemm_epilogue<1, true>(p, acc, smem_raw, lane, wv, wm, wn, m0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1979,33 +1659,18 @@ __global__ void __launch_bounds__(512, 2) k_ffn320r(FfnParams q) {
     }
 }
 
-thread_local int g_ffn_regx = 1;         // syn3r_gemm_set_tile(-3200 / -3201): k_ffn320 / k_ffn320r for the calling thread (tests)
-
 int launch_ffn320(const FfnParams& q, hipStream_t stream) {
-    static bool attr_set = false;
-    static int reg_x = 1;              // SYN3R_FFN_REGX=0: the x tile in LDS (k_ffn320) instead of in registers (k_ffn320r); tuning
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn320, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
-        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(ffn320)");
-        e = hipFuncSetAttribute((const void*)k_ffn320r, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
-        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(ffn320r)");
-        const char* v = getenv("SYN3R_FFN_REGX");
-        reg_x = v ? atoi(v) : 1;
-        attr_set = true;
-    }
+    static DevOnce once;
+    int rc = set_max_lds(once, (const void*)k_ffn320r, R_LDS, "hipFuncSetAttribute(ffn320r)");
+    if (rc) return rc;
     const int tiles = (q.e.M + F_BM - 1) / F_BM;
     char name[96];
     if (trace_on()) {
         if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_ffn320[M%d,D%d,e%d]", q.e.M, q.D, q.e.residual != nullptr);
         else snprintf(name, sizeof(name), "k_gemm_ffn320");
     }
-    if (reg_x && g_ffn_regx != 0 && (uintptr_t)q.e.A % 16 == 0 && q.e.lda % 8 == 0) {
-        SYN3R_LAUNCH_NAMED(name, k_ffn320r, dim3(tiles), dim3(512), R_LDS, stream, q);
-        SYN3R_LAUNCH_CHECK("ffn320r launch");
-        return SYN3R_OK;
-    }
-    SYN3R_LAUNCH_NAMED(name, k_ffn320, dim3(tiles), dim3(512), F_LDS, stream, q);
-    SYN3R_LAUNCH_CHECK("ffn320 launch");
+    SYN3R_LAUNCH_NAMED(name, k_ffn320r, dim3(tiles), dim3(512), R_LDS, stream, q);
+    SYN3R_LAUNCH_CHECK("ffn320r launch");
     return SYN3R_OK;
 }
 
@@ -2179,12 +1844,8 @@ __global__ void __launch_bounds__(512, 2) k_lnlin320(LnLinParams p) {
 }
 
 int launch_lnlin320(const LnLinParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_lnlin320, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
-        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(lnlin320)");
-        attr_set = true;
-    }
+    static DevOnce once;
+    if (int rc = set_max_lds(once, (const void*)k_lnlin320, (int)(Q_LDS), "hipFuncSetAttribute(lnlin320)")) return rc;
     const int tiles = (p.M + F_BM - 1) / F_BM;
     char name[96];
     if (trace_on()) {
@@ -2196,38 +1857,20 @@ int launch_lnlin320(const LnLinParams& p, hipStream_t stream) {
     return SYN3R_OK;
 }
 
-int launch_w128(const GemmParams& p, hipStream_t stream) {
-    constexpr size_t lds = (size_t)2 * H_STAGE;   // 57,344 B
-    static_assert(4 * WM * EPI_LD * sizeof(__half) <= lds, "epilogue staging must fit in the ring");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_w128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_w128)");
-        attr_set = true;
-    }
-    int tiles = ((p.M + 127) / 128) * ((p.N + WBN - 1) / WBN);
-    char name[96];
-    if (trace_on()) {
-        if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_w128[M%d,N%d,K%d,e%d]", p.M, p.N, p.K, p.geglu_D > 0 ? 2 : (p.residual != nullptr));
-        else snprintf(name, sizeof(name), "k_gemm_w128");
-    }
-    SYN3R_LAUNCH_NAMED(name, k_gemm_w128, dim3(tiles), dim3(256), lds, stream, p);
-    SYN3R_LAUNCH_CHECK("gemm_w128 launch");
-    return SYN3R_OK;
-}
-
-// grid of the persistent kernels: the CU count of the device (SYN3R_PERSISTENT_BLOCKS overrides, tuning only)
+// grid of the persistent kernels: the CU count of the CURRENT device (queried once per device; SYN3R_PERSISTENT_BLOCKS overrides
+// in tuning builds)
 int persistent_blocks() {
-    static int n = 0;
+    static std::atomic<int> cus_of[64];
+    static const int forced = tune_env("SYN3R_PERSISTENT_BLOCKS", 0);
+    if (forced > 0) return forced < 8 ? 8 : forced;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int n = cus_of[dev].load(std::memory_order_relaxed);
     if (n == 0) {
-        const char* e = getenv("SYN3R_PERSISTENT_BLOCKS");
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            int v = 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-        }
-        n = e ? atoi(e) : cus;
+        int v = 0;
+        n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
         if (n < 8) n = 8;
+        cus_of[dev].store(n, std::memory_order_relaxed);
     }
     return n;
 }
@@ -2240,8 +1883,7 @@ int persistent_blocks() {
 // calls); at K = 1280 the isolated gain ([16128,10240,1280] 432 -> 392 us) does not survive inside the unit (+0.5 %, and +4 % on
 // [4032,10240,1280]), and with at most four tile columns one band (A read once) is best.  SYN3R_Z_BAND overrides (tuning).
 int band_width(const GemmParams& p) {
-    static int band_env = -2;
-    if (band_env == -2) { const char* e = getenv("SYN3R_Z_BAND"); band_env = e ? atoi(e) : 0; }
+    static const int band_env = tune_env("SYN3R_Z_BAND", 0);
     if (band_env > 0) return band_env;
     return ((p.N + WBN - 1) / WBN > 4 && p.K <= 640) ? 3 : 4;
 }
@@ -2249,12 +1891,8 @@ int band_width(const GemmParams& p) {
 int launch_widep(const GemmParams& p, hipStream_t stream) {
     constexpr size_t lds = (size_t)2 * W_STAGE + 16384;   // 163,840 B: the ring + the tail the epilogue staging runs into
     static_assert(8 * WM * EPI_LD * sizeof(__half) <= lds - W_STAGE, "epilogue staging must fit behind ring slot 0");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_widep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_widep)");
-        attr_set = true;
-    }
+    static DevOnce once;
+    if (int rc = set_max_lds(once, (const void*)k_gemm_widep, (int)(lds), "hipFuncSetAttribute(gemm_widep)")) return rc;
     int tiles = ((p.M + WBM - 1) / WBM) * ((p.N + WBN - 1) / WBN);
     const int blocks = std::min(tiles, persistent_blocks());
     char name[96];
@@ -2271,14 +1909,10 @@ int launch_widep(const GemmParams& p, hipStream_t stream) {
 
 template <int MODE = MODE_DENSE>
 int launch_z(const GemmParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_z<false, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, Z_LDS);
-        if (e == hipSuccess && MODE == MODE_DENSE) e = hipFuncSetAttribute((const void*)k_gemm_z<true, MODE_DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, Z_LDS);
-        if (e == hipSuccess && MODE == MODE_CONV2D) e = hipFuncSetAttribute((const void*)k_gemm_z<false, MODE_CONV2D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Z_LDS);
-        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_z)");
-        attr_set = true;
-    }
+    static DevOnce once, once2;
+    if (int rc = set_max_lds(once, (const void*)k_gemm_z<false, MODE>, Z_LDS, "hipFuncSetAttribute(gemm_z)")) return rc;
+    if constexpr (MODE == MODE_DENSE) { if (int rc = set_max_lds(once2, (const void*)k_gemm_z<true, MODE_DENSE>, Z_LDS, "hipFuncSetAttribute(gemm_z)")) return rc; }
+    if constexpr (MODE == MODE_CONV2D) { if (int rc = set_max_lds(once2, (const void*)k_gemm_z<false, MODE_CONV2D, true>, Z_LDS, "hipFuncSetAttribute(gemm_z)")) return rc; }
     int tiles = ((p.M + WBM - 1) / WBM) * ((p.N + WBN - 1) / WBN);
     const int blocks = std::min(tiles, persistent_blocks());
     GemmParams q = p;
@@ -2311,8 +1945,7 @@ thread_local size_t g_splitk_bytes = 0;
 // slower on the residual-add ones, a wash on their sum (74.33 against 74.23 ms): it takes the gated shapes.
 // SYN3R_GEMM_Z overrides (tuning): 0 = never, 1 = every shape the 256 x 320 tile is chosen for.
 int wide_launch(const GemmParams& p, hipStream_t stream) {
-    static int z_env = -2;
-    if (z_env == -2) { const char* e = getenv("SYN3R_GEMM_Z"); z_env = e ? atoi(e) : -1; }
+    static const int z_env = tune_env("SYN3R_GEMM_Z", -1);
     const bool z = g_dma_bm == -322 ? true : (g_dma_bm == -320 ? false : (z_env < 0 ? p.geglu_D > 0 : z_env != 0));
     return z ? launch_z<MODE_DENSE>(p, stream) : launch_widep(p, stream);
 }
@@ -2329,18 +1962,14 @@ bool widep_admits(const GemmParams& p) {
 
 // Kernel family forced by the CALLING THREAD (syn3r_gemm_set_tile; tests and tuning tools): 0 = by shape, 128 / 256 = the
 // 160-column LDS-DMA kernel of that block height, -320 = the persistent 256 x 320 kernel k_gemm_widep wherever it admits the
-// shape, -321 = the 128 x 320 kernel, -322 = the software-pipelined 256 x 320 kernel k_gemm_z (dense, two-source, convolutions).  thread_local: no state shared between host threads.
+// shape, -322 = the software-pipelined 256 x 320 kernel k_gemm_z (dense, two-source, convolutions).  thread_local: no state shared between host threads.
 
 template <int MODE>
 int launch_dmap(const GemmParams& p, hipStream_t stream) {
     constexpr size_t lds = (size_t)3 * (256 * BK * 2 + DMA_B_BYTES);   // 159,744 B
     static_assert(8 * 32 * EPI_LD * sizeof(__half) <= 256 * BK * 2 + DMA_B_BYTES, "the two-pass epilogue staging must fit in one ring slot");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_dmap<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_dmap)");
-        attr_set = true;
-    }
+    static DevOnce once;
+    if (int rc = set_max_lds(once, (const void*)k_gemm_dmap<MODE>, (int)(lds), "hipFuncSetAttribute(gemm_dmap)")) return rc;
     const int tiles = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
     const int blocks = std::min(tiles, persistent_blocks());
     char name[96];
@@ -2356,8 +1985,7 @@ int launch_dmap(const GemmParams& p, hipStream_t stream) {
 template <int MODE, int BM>
 int launch_dma_bm(const GemmParams& p, hipStream_t stream) {
     if constexpr (BM == 256) {
-        static int pers_env = -2;       // SYN3R_DMA_PERSISTENT=0: the one-tile-per-block kernel (tuning)
-        if (pers_env == -2) { const char* e = getenv("SYN3R_DMA_PERSISTENT"); pers_env = e ? atoi(e) : 1; }
+        static const int pers_env = tune_env("SYN3R_DMA_PERSISTENT", 1);       // 0: the one-tile-per-block kernel (tuning builds)
         // the lean epilogue: no GEGLU gate, aux only together with a residual, whole 16-byte chunks of columns
         // measured inside the UNet unit, same box (SYN3R_DMA_PERSISTENT=0 against the default): dense K = 320 residual
         // projections -11 %, temporal convolutions -1..-5 %, 3x3 convolutions +1..+3 % (their k-loops are 45-360 k-tiles
@@ -2367,12 +1995,8 @@ int launch_dma_bm(const GemmParams& p, hipStream_t stream) {
     }
     constexpr size_t lds = (size_t)(BM == 256 ? 3 : 2) * (BM * BK * 2 + DMA_B_BYTES);   // 159,744 B / 73,728 B
     static_assert((BM / 32) * WM * EPI_LD * sizeof(__half) <= lds, "epilogue staging must fit in the ring");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_dma<MODE, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_dma)");
-        attr_set = true;
-    }
+    static DevOnce once;
+    if (int rc = set_max_lds(once, (const void*)k_gemm_dma<MODE, BM>, (int)lds, "hipFuncSetAttribute(gemm_dma)")) return rc;
     int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     char name[96];
     if (trace_on()) {
@@ -2399,12 +2023,8 @@ int launch_splitk(const GemmParams& p, hipStream_t stream, bool* done) {
         p.geglu_D > 0 || p.out_tiled || (p.A2 && (MODE != MODE_DENSE || p.a_tiled || (p.K1 / BK) % (nkt_all / S) != 0)))
         return SYN3R_OK;
     constexpr size_t lds = (size_t)3 * (256 * BK * 2 + DMA_B_BYTES);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_dma<MODE, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(gemm_dma)");
-        attr_set = true;
-    }
+    static DevOnce once;
+    if (int rc = set_max_lds(once, (const void*)k_gemm_dma<MODE, 256>, (int)lds, "hipFuncSetAttribute(gemm_dma)")) return rc;
     GemmParams q = p;
     q.ksplit = S; q.split_ws = (float*)g_splitk_ws;
     char name[96];
@@ -2422,12 +2042,8 @@ int launch_splitk(const GemmParams& p, hipStream_t stream, bool* done) {
 
 template <int MODE>
 int launch_dma(const GemmParams& p, hipStream_t stream) {
-    static int wide_env = -2;       // SYN3R_GEMM_WIDE: unset = by shape, 0 = never, 1 = always (tuning)
-    if (wide_env == -2) { const char* e = getenv("SYN3R_GEMM_WIDE"); wide_env = e ? atoi(e) : -1; }
-    static int w128_env = -2;       // SYN3R_GEMM_W128: unset = by shape; 0 = never, 1 = wherever the wide tile would run (tuning)
-    if (w128_env == -2) { const char* e = getenv("SYN3R_GEMM_W128"); w128_env = e ? atoi(e) : -1; }
+    static const int wide_env = tune_env("SYN3R_GEMM_WIDE", -1);       // -1 = by shape, 0 = never, 1 = always (tuning builds)
     const bool wide_ok = MODE == MODE_DENSE && widep_admits(p);
-    if (g_dma_bm == -321) { if constexpr (MODE == MODE_DENSE) return launch_w128(p, stream); }   // syn3r_gemm_set_tile(-321)
     if (g_dma_bm == -320 && wide_ok) return launch_widep(p, stream);                              // syn3r_gemm_set_tile(-320)
     if (g_dma_bm == -322 && wide_ok) return launch_z<MODE_DENSE>(p, stream);                      // syn3r_gemm_set_tile(-322)
     if (g_dma_bm == 0 && wide_env != 0 && wide_ok) {
@@ -2442,13 +2058,8 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
         // K = 640 / 1280 residual projections are 3..4 % faster on the wide tile; K = 320 stays 4 % slower there)
         const bool short_residual = p.residual != nullptr && p.K <= 320;
         if (wide_env == 1 || (fills && !short_residual)) {
-            // K <= 320 (5 k-tiles): the tile's time is its gate and store tail, which a second block on the CU
-            // overlaps: 128 x 320 blocks are 6 % faster on the L0 gated projection and 2 % on qkv; from K = 640 on
-            // the 256-row tile's weight reuse wins (+1..12 %) (tools/gemm_ab.py SYN3R_GEMM_W128 0 1, same box); on the
-            // residual-add projections it loses 7..25 % to the 128 x 160 blocks (no early residual prefetch either)
-            // (round 2, persistent 256-row kernel with the lean epilogue: it now wins the K = 320 shapes of one or two tile
-            // columns by 12..20 % and ties on qkv, N = 960, which stays here)
-            if constexpr (MODE == MODE_DENSE) { if (w128_env == 1 || (w128_env != 0 && p.K <= 320 && p.N > 640)) return launch_w128(p, stream); }
+            // (the 128 x 320 two-blocks-per-CU variant that took the K <= 320, N > 640 shapes until round 4 is gone: the level-0
+            // feed-forward and q / k / v projections it was built for run in k_ffn320r / k_lnlin320)
             return wide_launch(p, stream);
         }
     }
@@ -2460,17 +2071,16 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
     // without and +12 % with a residual (they stay), the 8-column output convolution +64 % (one 320-wide tile column for 8
     // columns: stays).  SYN3R_CONV_Z=0: never; 1: every admissible shape (tests, tuning).
     if constexpr (MODE != MODE_DENSE) {
-        static int cz_env = -2;
-        if (cz_env == -2) { const char* e = getenv("SYN3R_CONV_Z"); cz_env = e ? atoi(e) : -1; }
+        static const int cz_env = tune_env("SYN3R_CONV_Z", -1);
         const long long tiles = (long long)((p.M + WBM - 1) / WBM) * ((p.N + WBN - 1) / WBN);
         const long long rounds = (tiles + 255) / 256;
         const bool fills = tiles * 10 >= rounds * 256 * 8;
         const long long in_bytes = MODE == MODE_CONV2D ? (long long)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2 : (long long)p.M * p.Cin * 2;
-        static int czu_env = -2;            // SYN3R_CONV_Z_UPS=0: the fused-upsample convolutions stay on the 160-column kernel (tuning)
-        if (czu_env == -2) { const char* e = getenv("SYN3R_CONV_Z_UPS"); czu_env = e ? atoi(e) : 1; }
+        static const int czu_env = tune_env("SYN3R_CONV_Z_UPS", 1);       // 0: the fused-upsample convolutions stay on the 160-column kernel (tuning builds)
         const bool lean = !p.relu && !p.relu_mask && (!p.aux || p.residual) && p.geglu_D <= 0 && !p.A2 && !p.a_tiled &&
                           !(p.ups && (p.stride != 1 || p.pad != 1 || (czu_env == 0 && g_dma_bm != -322)));
-        const bool ok = lean && p.M % 8 == 0 && p.N % 8 == 0 && p.M >= 8 && p.N >= 8 && in_bytes < (1ll << 32) - (1 << 20) &&
+        // (p.M < 2^24: the pixel-index division of gemm_z.h is a float-reciprocal multiply with a +-1 correction, exact below that)
+        const bool ok = lean && p.M % 8 == 0 && p.N % 8 == 0 && p.M >= 8 && p.N >= 8 && p.M < (1 << 24) && in_bytes < (1ll << 32) - (1 << 20) &&
                         (long long)p.N * p.K < (1ll << 31) && p.Cin % BK == 0;
         const bool pays = MODE == MODE_CONV2D && p.N >= 320;
         if (g_dma_bm == -322 && ok) return launch_z<MODE>(p, stream);                             // syn3r_gemm_set_tile(-322)
@@ -2517,9 +2127,7 @@ extern "C" int syn3r_gemm_set_splitk_workspace(void* workspace, size_t bytes) {
 }
 
 extern "C" int syn3r_gemm_set_tile(int bm) {
-    if (bm == -3200 || bm == -3201) { g_ffn_regx = bm == -3201; return SYN3R_OK; }     // fused feed-forward: x tile in LDS / in registers
-    SYN3R_REQUIRE(bm == 0 || bm == -128 || bm == -256 || bm == -320 || bm == -321 || bm == -322,
-                  "gemm_set_tile: bm must be 0, -128, -256, -320, -321 or -322 (or -3200 / -3201 for the fused feed-forward)");
+    SYN3R_REQUIRE(bm == 0 || bm == -128 || bm == -256 || bm == -320 || bm == -322, "gemm_set_tile: bm must be 0, -128, -256, -320 or -322");
     g_dma_bm = (bm == -128 || bm == -256) ? -bm : bm;        // this thread's launches only (thread_local)
     return SYN3R_OK;
 }

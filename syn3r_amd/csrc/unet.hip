@@ -17,6 +17,8 @@
 #include <unistd.h>
 #include <math.h>
 #include <string.h>
+#include <ctype.h>
+#include <exception>
 #include <map>
 #include <memory>
 #include <algorithm>
@@ -116,7 +118,14 @@ struct JParser {
         while (p < e && *p != '"') {
             if (*p == '\\' && p + 1 < e) {
                 ++p;
-                switch (*p) { case 'n': s += '\n'; break; case 't': s += '\t'; break; case 'u': s += '?'; p += 4; break; default: s += *p; }
+                switch (*p) {
+                    case 'n': s += '\n'; break;
+                    case 't': s += '\t'; break;
+                    case 'u':                                  // \uXXXX: not needed for tensor names; the four digits must exist
+                        if (e - p < 5) { ok = false; return s; }
+                        s += '?'; p += 4; break;
+                    default: s += *p;
+                }
                 ++p;
             } else s += *p++;
         }
@@ -158,9 +167,15 @@ struct JParser {
         else if (lit("false")) { v.type = JVal::BOOL; v.num = 0; }
         else if (lit("null")) { v.type = JVal::NUL; }
         else {
+            // the header is a slice of an mmap'd file: not NUL-terminated, so the number is parsed from a bounded copy
+            char buf[64];
+            size_t n = 0;
+            while (p + n < e && n < sizeof(buf) - 1 && (isdigit((unsigned char)p[n]) || p[n] == '-' || p[n] == '+' || p[n] == '.' || p[n] == 'e' || p[n] == 'E')) ++n;
+            memcpy(buf, p, n);
+            buf[n] = 0;
             char* end = nullptr;
-            v.type = JVal::NUM; v.num = strtod(p, &end);
-            if (end == p || end > e) ok = false; else p = end;
+            v.type = JVal::NUM; v.num = n ? strtod(buf, &end) : 0.0;
+            if (n == 0 || end != buf + n || !(v.num == v.num)) ok = false; else p += n;
         }
         return v;
     }
@@ -203,9 +218,17 @@ struct StFile {
             if (!dt || !sh || !off || off->arr.size() != 2) { err = path + ": malformed entry " + kv.first; return false; }
             StEntry en;
             en.dtype = dt->str;
-            for (auto& d : sh->arr) en.shape.push_back((long long)d.num);
+            // dimensions and offsets are file contents: integers in [0, 2^53) only, the element count bounded by the file size
+            auto whole = [](const JVal& x) { return x.type == JVal::NUM && x.num >= 0 && x.num < 9007199254740992.0 && x.num == (double)(unsigned long long)x.num; };
+            if (sh->type != JVal::ARR || sh->arr.size() > 8 || !whole(off->arr[0]) || !whole(off->arr[1])) { err = path + ": malformed entry " + kv.first; return false; }
+            unsigned long long count = 1;
+            for (auto& d : sh->arr) {
+                if (!whole(d)) { err = path + ": bad shape in entry " + kv.first; return false; }
+                if (__builtin_mul_overflow(count, (unsigned long long)d.num, &count) || count > (unsigned long long)size) { err = path + ": shape of entry " + kv.first + " exceeds the file"; return false; }
+                en.shape.push_back((long long)d.num);
+            }
             en.begin = (size_t)off->arr[0].num; en.end = (size_t)off->arr[1].num;
-            if (en.end < en.begin || data0 + en.end > size) { err = path + ": entry " + kv.first + " outside the file"; return false; }
+            if (en.end < en.begin || en.end > size - data0) { err = path + ": entry " + kv.first + " outside the file"; return false; }
             entries.emplace(kv.first, std::move(en));
         }
         return true;
@@ -217,12 +240,16 @@ inline float f16_bits_to_f32(u16 b) { _Float16 h; memcpy(&h, &b, 2); return (flo
 
 // a checkpoint tensor as fp16 bits on the host (F16 as stored; F32 / BF16 rounded once, as `.to(torch.float16)` does)
 bool host_f16(const StFile& f, const StEntry& e, std::vector<u16>& out, std::string& err) {
-    long long n = 1;
-    for (long long d : e.shape) n *= d;
+    unsigned long long cnt = 1;
+    for (long long d : e.shape)
+        if (d < 0 || __builtin_mul_overflow(cnt, (unsigned long long)d, &cnt)) { err = "bad shape"; return false; }
+    const size_t esz = e.dtype == "F32" ? 4 : ((e.dtype == "F16" || e.dtype == "BF16") ? 2 : 0);
+    if (!esz) { err = "unsupported dtype " + e.dtype; return false; }
+    if (cnt > (e.end - e.begin) / esz || cnt * esz != e.end - e.begin) { err = "size mismatch"; return false; }   // before any allocation
+    const long long n = (long long)cnt;
     const unsigned char* src = f.map + f.data0 + e.begin;
     out.resize((size_t)n);
     if (e.dtype == "F16") {
-        if ((size_t)n * 2 != e.end - e.begin) { err = "size mismatch"; return false; }
         memcpy(out.data(), src, (size_t)n * 2);
     } else if (e.dtype == "F32") {
         if ((size_t)n * 4 != e.end - e.begin) { err = "size mismatch"; return false; }
@@ -250,7 +277,8 @@ struct syn3r_unet {
     std::unordered_map<std::string, std::pair<double, double>> alpha;   // mix_factor -> (alpha, 1 - alpha) as the fp16 values the reference uses
     std::unordered_map<std::string, std::pair<int, int>> temb_slice;
     std::vector<std::string> temb_names;
-    std::map<std::string, __half*> pos_cache;                           // frame-position embeddings per (block, F, B): functions of the weights only
+    struct PosEmb { __half* p = nullptr; hipEvent_t ready = nullptr; hipStream_t stream = nullptr; };
+    std::map<std::string, PosEmb> pos_cache;                            // frame-position embeddings per (block, F, B): functions of the weights only
     bool ff_ln = true, ln_qkv = true;
 };
 
@@ -459,9 +487,26 @@ int pack_weights(syn3r_unet& m, const StFile& f, std::vector<HostPack>& packs) {
 
 }  // namespace
 
+namespace {
+int unet_create_impl(const char* weights_dir, const char* variant, syn3r_unet** out);
+}
+// The loader parses files it does not control (config.json, the safetensors header): nothing may leave through extern "C" as a
+// C++ exception (bad_alloc / length_error from a hostile header would terminate a ctypes / cgo host).
 extern "C" int syn3r_unet_create(const char* weights_dir, const char* variant, syn3r_unet** out) {
     SYN3R_REQUIRE(weights_dir && out, "unet_create: null argument");
     *out = nullptr;
+    try {
+        return unet_create_impl(weights_dir, variant, out);
+    } catch (const std::exception& e) {
+        set_error("unet_create: %s", e.what());
+    } catch (...) {
+        set_error("unet_create: unexpected exception");
+    }
+    *out = nullptr;
+    return SYN3R_E_INVALID;
+}
+namespace {
+int unet_create_impl(const char* weights_dir, const char* variant, syn3r_unet** out) {
     const std::string dir(weights_dir);
     std::string cfg_text;
     if (!read_file(dir + "/config.json", cfg_text)) return fail("unet_create: cannot read %s/config.json", dir);
@@ -506,10 +551,8 @@ extern "C" int syn3r_unet_create(const char* weights_dir, const char* variant, s
         m->w[hp.name] = Wt{(__half*)(m->blob + off), hp.rows, hp.cols};
         off += (hp.d.size() * 2 + 255) / 256 * 256;
     }
-    const char* e = getenv("SYN3R_FF_LN");
-    m->ff_ln = !(e && !strcmp(e, "0"));
-    e = getenv("SYN3R_LN_QKV");
-    m->ln_qkv = !(e && !strcmp(e, "0"));
+    m->ff_ln = tune_env("SYN3R_FF_LN", 1) != 0;          // tuning builds only (common.h): the shipped library reads no environment
+    m->ln_qkv = tune_env("SYN3R_LN_QKV", 1) != 0;
     *out = m.release();
     {
         std::lock_guard<std::mutex> lk(g_unet_mu);
@@ -517,6 +560,7 @@ extern "C" int syn3r_unet_create(const char* weights_dir, const char* variant, s
     }
     return SYN3R_OK;
 }
+}  // namespace
 
 extern "C" int syn3r_unet_destroy(syn3r_unet* m) {
     if (!m) return SYN3R_OK;
@@ -524,7 +568,10 @@ extern "C" int syn3r_unet_destroy(syn3r_unet* m) {
         std::lock_guard<std::mutex> lk(g_unet_mu);
         if (!unet_registry().erase(m)) { set_error("unet_destroy: not a live handle"); return SYN3R_E_INVALID; }
     }
-    for (auto& kv : m->pos_cache) hipFree(kv.second);
+    for (auto& kv : m->pos_cache) {
+        if (kv.second.ready) hipEventDestroy(kv.second.ready);
+        hipFree(kv.second.p);
+    }
     if (m->blob) hipFree(m->blob);
     delete m;
     return SYN3R_OK;
@@ -814,7 +861,12 @@ struct Run {
     const __half* pos_embedding(const std::string& pre, int ch) {
         const std::string key = pre + "|" + std::to_string(F) + "|" + std::to_string(B);
         auto it = m.pos_cache.find(key);
-        if (it != m.pos_cache.end() && !dry) return it->second;
+        if (it != m.pos_cache.end() && !dry) {
+            // filled on the stream of the forward that created it: a forward on ANOTHER stream orders itself behind that fill
+            // (the header's "nothing synchronises" holds for the host; this is a device-side dependency)
+            if (it->second.stream != stream && it->second.ready) chk(check_hip(hipStreamWaitEvent(stream, it->second.ready, 0), "hipStreamWaitEvent(position embedding)"));
+            return it->second.p;
+        }
         T pos = make(F, ch);
         if (go()) hipLaunchKernelGGL(k_timestep_embedding, dim3((unsigned)((F * (ch / 2) + 255) / 256)), dim3(256), 0, stream, (const float*)nullptr, 0.0, 1.0f, F, ch, pos.p);
         T e1 = linear(pos, pre + ".time_pos_embed.linear_1.weight", pre + ".time_pos_embed.linear_1.bias");
@@ -829,8 +881,13 @@ struct Run {
             if (ok()) {
                 const long long n = (long long)B * F * ch;
                 hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, e2.p, keep, F, (long long)B * F, ch);
-                m.pos_cache[key] = keep;
-            }
+                syn3r_unet::PosEmb pe;
+                pe.p = keep; pe.stream = stream;
+                if (hipEventCreateWithFlags(&pe.ready, hipEventDisableTiming) == hipSuccess) {
+                    if (hipEventRecord(pe.ready, stream) != hipSuccess) { hipEventDestroy(pe.ready); pe.ready = nullptr; }
+                } else pe.ready = nullptr;
+                m.pos_cache[key] = pe;
+            } else if (keep) { hipFree(keep); keep = nullptr; }
         }
         drop(e2);
         return keep;
@@ -917,8 +974,7 @@ struct Run {
         {
             const int down = 1 << (m.boc.size() - 1);
             const long long m_low = (long long)B * F * (h / down) * (w / down);
-            const char* e = getenv("SYN3R_SPLITK");
-            if (!(e && !strcmp(e, "0")) && ((m_low + 255) / 256) * ((m.boc.back() + 159) / 160) * 2 <= 256) {
+            if (tune_env("SYN3R_SPLITK", 1) != 0 && ((m_low + 255) / 256) * ((m.boc.back() + 159) / 160) * 2 <= 256) {
                 const size_t bytes = (size_t)4 * m_low * m.boc.back() * 4;
                 splitk = ok() ? ar.alloc(bytes) : nullptr;
                 if (ok() && !splitk) { set_error("unet_forward: workspace too small (needs syn3r_unet_workspace_bytes)"); rc = SYN3R_E_WORKSPACE; }
@@ -1042,6 +1098,7 @@ int check_shape(const syn3r_unet* m, int B, int F, int h, int w, int ehs_rows, i
 
 extern "C" size_t syn3r_unet_workspace_bytes(syn3r_unet* m, int B, int F, int h, int w, int ehs_rows) {
     if (check_shape(m, B, F, h, w, ehs_rows, 0)) return 0;
+    try {
     Run r(*m);
     r.dry = true;
     r.ar.reset((char*)4096, (size_t)1 << 46);
@@ -1049,6 +1106,7 @@ extern "C" size_t syn3r_unet_workspace_bytes(syn3r_unet* m, int B, int F, int h,
     r.shared_ctx = B == 1 || ehs_rows == 1;
     r.forward(nullptr, 0.0, (const __half*)4096, r.shared_ctx ? 1 : B, nullptr, nullptr);
     return r.ok() ? r.ar.peak + 256 : 0;
+    } catch (...) { set_error("unet_workspace_bytes: unexpected exception"); return 0; }
 }
 
 extern "C" int syn3r_unet_forward(syn3r_unet* m, const void* sample, double timestep, const void* encoder_hidden_states, int ehs_rows,
@@ -1059,6 +1117,7 @@ extern "C" int syn3r_unet_forward(syn3r_unet* m, const void* sample, double time
     SYN3R_REQUIRE(sample && encoder_hidden_states && added_time_ids && out, "unet_forward: null tensor");
     SYN3R_REQUIRE(workspace && ((uintptr_t)workspace % 256) == 0, "unet_forward: workspace must be non-null and 256-byte aligned");
     SYN3R_REQUIRE((((uintptr_t)sample | (uintptr_t)encoder_hidden_states | (uintptr_t)out) % 16) == 0, "unet_forward: misaligned tensor");
+    try {
     Run r(*m);
     r.ar.reset((char*)workspace, workspace_bytes / 256 * 256);
     r.stream = (hipStream_t)stream;
@@ -1071,4 +1130,6 @@ extern "C" int syn3r_unet_forward(syn3r_unet* m, const void* sample, double time
         if (e != hipSuccess) return check_hip(e, "unet_forward launch");
     }
     return r.rc;
+    } catch (const std::exception& e) { set_error("unet_forward: %s", e.what()); return SYN3R_E_INVALID;
+    } catch (...) { set_error("unet_forward: unexpected exception"); return SYN3R_E_INVALID; }
 }

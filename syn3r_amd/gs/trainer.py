@@ -594,11 +594,15 @@ class GSTrainer:
         try:
             for _ in range(first_iter, n):
                 keys0 = self._capacity_keys() if self.densify else None
-                try:
-                    last = self.train_step()
-                except L.Syn3rError as e:            # raised by the render at the TOP of this step, about an earlier render
-                    late_overflow(e)                 # (whose step was applied): counted, reported in the scene record
-                    last = self.train_step()         # (`truncated_renders`), the capacity raised - this iteration runs now
+                cam = self._pick_camera()            # drawn ONCE per iteration: a retry renders the same view
+                for attempt in range(4):
+                    try:
+                        last = self.train_step(cam)
+                        break
+                    except L.Syn3rError as e:        # raised by the render at the TOP of this step, about an earlier render
+                        late_overflow(e)             # (whose step was applied): counted, reported in the scene record
+                        if attempt == 3:             # (`truncated_renders`), the capacity raised - this iteration runs now;
+                            raise                    # a retry may find ANOTHER pending truncated render: bounded
                 if keys0 is not None:
                     keys1 = self._capacity_keys()
                     if keys1 != keys0:               # densification changed N: every (N, H, W) key is new.  Check what

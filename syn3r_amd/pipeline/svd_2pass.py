@@ -28,6 +28,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
+from ..tuning import FLAGS as TUNE
 
 
 @dataclass
@@ -95,10 +96,9 @@ class StableVideoDiffusionPipeline:
         self.device = torch.device(device)
         self.vae_scale_factor = 8
         self._guidance_scale = None
-        import os
-        self.use_graphs = os.environ.get("SYN3R_UNET_GRAPH", "0") == "1"     # replay captured UNet launch sequences (hipGraph)
-        # the two passes of a Replace step on TWO HIP streams (see _streamed_replace): SYN3R_TWO_STREAMS=0 turns it off
-        self.two_streams = os.environ.get("SYN3R_TWO_STREAMS", "1") != "0" and self.device.type == "cuda"
+        self.use_graphs = TUNE["unet_graph"]     # replay captured UNet launch sequences (hipGraph)
+        # the two passes of a Replace step on TWO HIP streams (see _streamed_replace): tuning.FLAGS["two_streams"] = False turns it off
+        self.two_streams = TUNE["two_streams"] and self.device.type == "cuda"
         self._side = None               # the two side streams, created on first use
         self._streams_warm = set()      # shapes whose shared caches (frame-position embeddings, scratch buffers) exist
 
@@ -276,7 +276,7 @@ class StableVideoDiffusionPipeline:
         """(side stream 1, side stream 2), both waiting for the current stream - or the current stream twice for the FIRST call of
         `key`: that call creates what the sequences share (the UNet's frame-position embeddings of this batch size, folded
         contexts, the scheduler's kernel-side operands), and a cache entry written on one side stream must not be read on the
-        other before it exists.  None: SYN3R_TWO_STREAMS=0."""
+        other before it exists.  None: tuning.FLAGS["two_streams"] = False."""
         if not self.two_streams:
             return None
         if key not in self._streams_warm:
@@ -306,7 +306,7 @@ class StableVideoDiffusionPipeline:
         """The two passes of a Replace step (SVD_2pass_prob_uncertain.py:661-742), each on its own stream."""
         g = 2 if do_cfg else 1
         streams = self._fork(("replace", tuple(lat[0].shape)))
-        if streams is None:                                  # SYN3R_TWO_STREAMS=0: both passes stacked into one launch sequence
+        if streams is None:                                  # tuning.FLAGS["two_streams"] = False: both passes stacked into one launch sequence
             return self._merged_replace(i, t, lat, img4, ehs4, added4, ops2, do_cfg)
         out = []
         for k in range(2):
@@ -326,7 +326,7 @@ class StableVideoDiffusionPipeline:
         ehs_t, added_t, grp = tile_ctx
         # The CFG forwards do not depend on the guidance tiles (their input is built from the ORIGINAL latents, …post.py:786-792):
         # each pass's CFG forward goes to its own stream FIRST, the tile forwards follow on the current one - three launch
-        # sequences whose kernels fill each other's partly empty last rounds (see above).  SYN3R_TWO_STREAMS=0: one stacked
+        # sequences whose kernels fill each other's partly empty last rounds (see above).  tuning.FLAGS["two_streams"] = False: one stacked
         # B = 4 CFG call behind the tiles.
         streams = self._fork(("post", tuple(lat[0].shape)))
         noises = None
@@ -365,9 +365,8 @@ class StableVideoDiffusionPipeline:
         """The denoising loop (…post.py:656-831 / SVD_2pass_prob_uncertain.py:649-748) on prepared
         tensors.  latents [1,F,4,h,w]; image_latent_* [B,F,4,h,w]; emb_* [B,1,D]; temp_cond_latents
         [2,F,4,h,w] fp32 (already divided by factor_s); mask [1,F-2,4,h,w]; lambda_ts [steps,F] f64.
-        `merge_passes` (default: on when the UNet takes `ctx_group`, i.e. the HIP UNet; SYN3R_MERGE_PASSES=0 turns it off):
+        `merge_passes` (default: on when the UNet takes `ctx_group`, i.e. the HIP UNet; tuning.FLAGS["merge_passes"] = False turns it off):
         the two passes of a step share their UNet launches."""
-        import os
         dev = self.device
         F = latents.shape[1]
         do_cfg = max_guidance_scale > 1.0
@@ -384,7 +383,7 @@ class StableVideoDiffusionPipeline:
         tops_fw = self._tile_operands(temp_cond_latents, mask) if post else None
         tops_bw = self._tile_operands(cond_bw, mask_bw) if post and not one_pass else None
         if merge_passes is None:
-            merge_passes = os.environ.get("SYN3R_MERGE_PASSES") != "0"
+            merge_passes = TUNE["merge_passes"]
         merged = bool(merge_passes) and not one_pass and getattr(self.unet, "supports_ctx_group", False)
         if merged:
             g = 2 if do_cfg else 1

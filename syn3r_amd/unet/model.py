@@ -20,13 +20,13 @@ Restructurings relative to the reference graph (each keeps the reference's resul
 from __future__ import annotations
 
 import math
-import os
 from typing import Dict, Optional, Sequence, Tuple, Union
 
 import torch
 import torch.nn.functional as Fn
 
 from .. import _lib as L
+from ..tuning import FLAGS as TUNE
 from . import ops
 
 H = torch.float16
@@ -297,7 +297,7 @@ class UNetSpatioTemporalConditionModel:
         for k in list(p.t):
             if k.endswith(".net.0.proj.weight"):
                 pre = k[: -len("weight")]
-                if p.t[k].shape[1] == ops.FUSED_FF_CHANNELS and os.environ.get("SYN3R_FF_FUSED") != "0":
+                if p.t[k].shape[1] == ops.FUSED_FF_CHANNELS and TUNE["ff_fused"]:
                     # C = 320: the single-kernel feed-forward (per-64-chunk packing); the two-kernel packing is not kept
                     wp, bp, D = ops.pack_geglu_chunked(p.t[k], p.t[pre + "bias"])
                     pk[pre + "geglu_cw"], pk[pre + "geglu_cb"] = wp, bp
@@ -405,7 +405,7 @@ class UNetSpatioTemporalConditionModel:
         residual (norm_in / ff_in, attention.py:500-517): also inside the fused kernel at C = 320."""
         D = self.p.shapes[pre + ".net.0.proj.weight"][0] // 2
         cw = self.packed.get(pre + ".net.0.proj.geglu_cw")
-        fuse = os.environ.get("SYN3R_FF_LN") != "0"
+        fuse = TUNE["ff_ln"]
         if addvec is not None and not (cw is not None and fuse):         # the sum as a tensor, then the plain path
             x, hmix = ops.layernorm(x, self.w(norm + ".weight"), self.w(norm + ".bias"), addvec=addvec[0], rows_per_vec=addvec[1],
                                     want_sum=True)
@@ -419,7 +419,7 @@ class UNetSpatioTemporalConditionModel:
         if norm:
             x = ops.layernorm(x, self.w(norm + ".weight"), self.w(norm + ".bias"))
         wp = self.w(pre + ".net.0.proj.geglu_w")
-        if os.environ.get("SYN3R_FF_TILED") == "0":      # tuning: row-major intermediate, two separate calls
+        if not TUNE["ff_tiled"]:      # tuning: row-major intermediate, two separate calls
             return ops.linear(ops.linear_geglu(x, wp, self.w(pre + ".net.0.proj.geglu_b"), D),
                               self.w(pre + ".net.2.weight"), self.w(pre + ".net.2.bias"), **epilogue)
         return ops.feedforward(x, wp, self.w(pre + ".net.0.proj.geglu_b"), D, self.w(pre + ".net.2.weight"),
@@ -427,9 +427,9 @@ class UNetSpatioTemporalConditionModel:
 
     def _norm_qkv(self, blk: str, x: torch.Tensor) -> torch.Tensor:
         """attn1's stacked q / k / v projection of norm1(x) (attention.py:340-352, 509-512): one kernel at C = 320
-        (SYN3R_LN_QKV=0: the two launches, tuning)."""
+        (tuning.FLAGS["ln_qkv"] = False: the two launches, tuning)."""
         W = self.w
-        if os.environ.get("SYN3R_LN_QKV") == "0":
+        if not TUNE["ln_qkv"]:
             return ops.linear(ops.layernorm(x, W(blk + ".norm1.weight"), W(blk + ".norm1.bias")), W(blk + ".attn1.qkv"))
         return ops.layernorm_linear(x, W(blk + ".norm1.weight"), W(blk + ".norm1.bias"), W(blk + ".attn1.qkv"))
 
@@ -510,7 +510,7 @@ class UNetSpatioTemporalConditionModel:
         down = 2 ** (len(boc) - 1)
         m_low = B * F * (h // down) * (w_ // down)
         splitk = None
-        if os.environ.get("SYN3R_SPLITK") != "0" and ((m_low + 255) // 256) * ((boc[-1] + 159) // 160) * 2 <= 256:
+        if TUNE["splitk"] and ((m_low + 255) // 256) * ((boc[-1] + 159) // 160) * 2 <= 256:
             nbytes = 4 * m_low * boc[-1] * 4                 # up to four fp32 partial tiles of the lowest level's widest output
             splitk = L.workspace(dev, nbytes, "splitk")
             # (the REQUESTED size, not the cached buffer's: which launches split must not depend on what ran before)
@@ -577,7 +577,7 @@ class UNetSpatioTemporalConditionModel:
             i = blk["idx"]
             for j, (cin, cout) in enumerate(blk["layers"]):
                 sk, sk_ch = skips.pop()
-                if os.environ.get("SYN3R_UNET_CAT") == "1":      # tuning: materialise the concatenation
+                if TUNE["unet_cat"]:      # tuning: materialise the concatenation
                     x = self._resblock(f"up_blocks.{i}.resnets.{j}", torch.cat([x, sk], dim=1), st, cin, cout)
                 else:                                            # the skip is read in place (norm1 + shortcut take two sources)
                     x = self._resblock(f"up_blocks.{i}.resnets.{j}", x, st, cin, cout, x2=sk)

@@ -66,3 +66,41 @@ def test_product_does_not_import_oracle():
     for p in (ROOT / "syn3r_amd").rglob("*.py"):
         src = p.read_text()
         assert "import oracle" not in src and "from oracle" not in src, p
+
+
+def test_library_reads_no_environment():
+    """include/syn3r_hip.h: the shipped library has no process-wide switches.  The sources call getenv only inside
+    `#ifdef SYN3R_TUNING` (developer builds), the built library does not import it, and the Python host reads the environment
+    only for the developer library override and the torchrun rank variables."""
+    import shutil
+    import subprocess
+    csrc = ROOT / "syn3r_amd" / "csrc"
+    for f in sorted(csrc.glob("*.hip")) + sorted(csrc.glob("*.h")):
+        lines = f.read_text().splitlines()
+        depth_tuning = []
+        stack = []
+        for i, ln in enumerate(lines):
+            t = ln.strip()
+            if t.startswith("#if"):
+                stack.append("SYN3R_TUNING" in t and t.startswith("#ifdef"))
+            elif t.startswith("#else") and stack:
+                stack[-1] = False
+            elif t.startswith("#endif") and stack:
+                stack.pop()
+            code = ln.split("//")[0]
+            if re.search(r"\bgetenv\s*\(", code):
+                assert any(stack), f"{f.name}:{i + 1}: getenv outside #ifdef SYN3R_TUNING"
+    nm = shutil.which("nm")
+    so = ROOT / "syn3r_amd" / "lib" / "libsyn3r_hip.so"
+    if nm and so.exists():
+        out = subprocess.run([nm, "-D", "--undefined-only", str(so)], capture_output=True, text=True, check=True).stdout
+        assert "getenv" not in out
+    allowed = {"SYN3R_LIB_OVERRIDE", "SYN3R_EXTRA_HIPCC_FLAGS", "HIPCC", "RANK", "WORLD_SIZE", "LOCAL_RANK"}
+    for p in (ROOT / "syn3r_amd").rglob("*.py"):
+        if p.name == "tuning.py":          # from_env(): called by tools/ only
+            continue
+        for m in re.finditer(r"environ(?:\.get\(|\[)\s*[\"']([A-Z0-9_]+)", p.read_text()):
+            assert m.group(1) in allowed or m.group(1).startswith("MASTER_"), (p, m.group(1))
+    for p in (ROOT / "syn3r_amd").rglob("*.py"):
+        if p.name != "tuning.py":
+            assert "from_env" not in p.read_text(), p

@@ -259,13 +259,13 @@ def test_ops_reject_bad_input(gpu):
 @pytest.fixture
 def every_contraction_kernel():
     """Run a test body once per contraction kernel: the per-shape default and every forced variant of
-    `syn3r_gemm_set_tile` (LDS-DMA 128/256, the two persistent 256x320 kernels and the 128x320 wide tile)."""
+    `syn3r_gemm_set_tile` (LDS-DMA 128/256 and the two persistent 256x320 kernels)."""
     from syn3r_amd import _lib
     lib = _lib.load()
 
     def run(body):
         try:
-            for tile in (0, -128, -256, -320, -321, -322):
+            for tile in (0, -128, -256, -320, -322):
                 _lib.check(lib.syn3r_gemm_set_tile(tile), "set_tile")
                 body(tile)
         finally:
@@ -362,7 +362,7 @@ def test_feedforward_tiled_intermediate(M, C, D, gpu):
     wp, bp, _ = ops.pack_geglu(w1, b1)
     lib = _lib.load()
     try:
-        for tile in (0, -128, -256, -320, -321, -322):
+        for tile in (0, -128, -256, -320, -322):
             _lib.check(lib.syn3r_gemm_set_tile(tile), "set_tile")
             ref = ops.linear(ops.linear_geglu(x, wp, bp, D), w2, b2, residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25)
             out = ops.feedforward(x, wp, bp, D, w2, b2, residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25)
@@ -751,13 +751,11 @@ def test_layernorm_linear_other_widths(gpu):
 
 
 @pytest.mark.parametrize("M,D", [(128, 64), (700, 1280), (4097, 1280), (129, 192), (9216 * 3 + 40, 1280)])
-def test_feedforward_fused_register_and_lds_kernels_agree(M, D, gpu):
-    """The fused feed-forward has two kernels - x tile in LDS (k_ffn320) and x tile as register fragments with a 7-slot
-    weight ring (k_ffn320r, the default) - with the same arithmetic and accumulation order: bit-identical outputs, with and
-    without the in-kernel LayerNorm, the add vector (norm_in), residual, aux and scales; ragged M, strided x."""
-    from syn3r_amd import _lib
+def test_feedforward_fused_in_kernel_layernorm_equals_two_launches(M, D, gpu):
+    """k_ffn320r (x tile as register fragments) normalises in registers with k_layernorm<8>'s arithmetic and summation order: the
+    in-kernel LayerNorm (norm3 -> ff) and the add-vector form (norm_in / ff_in) equal the LayerNorm LAUNCH followed by the same
+    kernel bit for bit, with residual, aux and scales; ragged M, strided x.  And the plain call against the fp32 restatement."""
     from syn3r_amd.unet import ops
-    lib = _lib.load()
     C = 320
     g = torch.Generator().manual_seed(M + 7 * D)
     wide = rnd(g, M, 2 * C, dev=gpu)
@@ -770,18 +768,21 @@ def test_feedforward_fused_register_and_lds_kernels_agree(M, D, gpu):
     rpv = max(1, M // 3)
     vec = rnd(g, (M + rpv - 1) // rpv, C, dev=gpu)
     wc, bc, _ = ops.pack_geglu_chunked(w1, b1)
-    cases = [dict(), dict(residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25), dict(ln=(ga, be, 1e-5), residual=res),
-             dict(ln=(ga, be, 1e-5), addvec=(vec, rpv), aux=aux, s_acc=0.5, s_res=0.5, s_aux=0.5), dict(b2=None)]
-    outs = {}
-    try:
-        for mode in (-3200, -3201):
-            _lib.check(lib.syn3r_gemm_set_tile(mode), "set_tile")
-            outs[mode] = [ops.feedforward_fused(x, wc, bc, D, w2, kw.get("b2", b2), **{k: v for k, v in kw.items() if k != "b2"}) for kw in cases]
-    finally:
-        lib.syn3r_gemm_set_tile(-3201)
-    for a, b, kw in zip(outs[-3200], outs[-3201], cases):
-        assert torch.equal(a, b), (sorted(kw), (a.float() - b.float()).abs().max().item())
-    # and against the fp32 restatement (the register kernel is the default path of every other feed-forward test, too)
+    xc = x.contiguous()
+    # norm3 -> ff
+    a = ops.feedforward_fused(x, wc, bc, D, w2, b2, ln=(ga, be, 1e-5), residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25)
+    b = ops.feedforward_fused(ops.layernorm(xc, ga, be, 1e-5), wc, bc, D, w2, b2, residual=res, aux=aux, s_acc=0.4, s_res=0.6, s_aux=0.25)
+    assert torch.equal(a, b), (a.float() - b.float()).abs().max().item()
+    # norm_in -> ff_in: x + vec is normalised AND is the residual
+    a = ops.feedforward_fused(x, wc, bc, D, w2, b2, ln=(ga, be, 1e-5), addvec=(vec, rpv), aux=aux, s_acc=0.5, s_res=0.5, s_aux=0.5)
+    y, xsum = ops.layernorm(xc, ga, be, 1e-5, addvec=vec, rows_per_vec=rpv, want_sum=True)
+    b = ops.feedforward_fused(y, wc, bc, D, w2, b2, residual=xsum, aux=aux, s_acc=0.5, s_res=0.5, s_aux=0.5)
+    assert torch.equal(a, b), (a.float() - b.float()).abs().max().item()
+    # no bias on the second projection
+    a = ops.feedforward_fused(x, wc, bc, D, w2, None)
+    b = ops.feedforward_fused(x, wc, bc, D, w2, torch.zeros_like(b2))
+    assert torch.equal(a, b)
+    # and against the fp32 restatement
     y = (x.float() @ w1.float().T + b1.float()).half().float()
     h = (y[:, :D] * Fn.gelu(y[:, D:])).half().float()
-    close(outs[-3201][0], h @ w2.float().T + b2.float(), tol=4e-3)
+    close(ops.feedforward_fused(x, wc, bc, D, w2, b2), h @ w2.float().T + b2.float(), tol=4e-3)
