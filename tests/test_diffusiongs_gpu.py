@@ -143,7 +143,9 @@ def test_scene_parallel_launcher_single_rank(gpu, tmp_path, capsys):
     from syn3r_amd import launch
     rc = launch.main(["--scenes", "synthetic:3:600,synthetic:4:600", "--model_path", str(tmp_path), "--iterations", "30",
                       "--refine_cycle_num", "1", "--num_inference_steps", "2", "--interp_type", "backward_warp",
-                      "--diffusion_type", "2PassProbUncertain", "--pseudo_cam_sampling_rate", "0.3", "--checkpoint_iterations", "30"])
+                      "--diffusion_type", "2PassProbUncertain", "--pseudo_cam_sampling_rate", "0.3", "--checkpoint_iterations", "30",
+                      "--densify_type", "interpolate_gs_v2", "--num_views_for_pcd_densification", "1"])   # (the reference's defaults for
+    # these two - 'interpolate', 4 - are a densify type its orchestrator rejects and the dust3r path; its batch scripts pass both)
     assert rc == 0
     out = capsys.readouterr().out
     lines = [l for l in out.splitlines() if l.strip()]
