@@ -514,6 +514,18 @@ int syn3r_photo_loss_backward(const float* image, const float* target, int C, in
 int syn3r_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                     float beta1, float beta2, float eps, int step, void* stream);
 
+/* The parameter activations of the published 3DGS model that FSGS' trainer applies before every render inside
+ * gsTrainer.training() / finetune() (model/diffusionGS.py:139,1640; GaussianModel.get_scaling / get_rotation / get_opacity):
+ * scales = exp(log_scales) [N,3], rotations_n = rotations / max(|rotations|_2, 1e-12) [N,4], opacities = sigmoid(logits) [N],
+ * in one launch; and their chain rule (torch's formulas) in one launch: d_log_scales = d_scales * scales,
+ * d_rotations = (g - qhat (qhat . g)) / max(|q|, 1e-12), d_opacity_logits = d_opacities * s (1 - s).  fp32, caller-owned. */
+int syn3r_gaussian_activate(int N, const float* log_scales, const float* rotations, const float* opacity_logits, float* scales,
+                            float* rotations_n, float* opacities, void* stream);
+int syn3r_gaussian_activate_backward(int N, const float* rotations, const float* scales, const float* rotations_n,
+                                     const float* opacities, const float* d_scales, const float* d_rotations_n,
+                                     const float* d_opacities, float* d_log_scales, float* d_rotations, float* d_opacity_logits,
+                                     void* stream);
+
 /* out[i] = mean of the three smallest squared Euclidean distances from point i to the OTHER points of the cloud
  * (points [n,3] fp32, n >= 4): the quantity FSGS' GaussianModel.create_from_pcd takes from `distCUDA2` of the
  * simple-knn CUDA extension to initialise the Gaussian scales (reached from reset_gaussians_from_pcd,

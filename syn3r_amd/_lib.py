@@ -62,6 +62,8 @@ SIGNATURES = {
                                     c_p, c_p, c_p, c_p, c_sz, c_p]),
     "syn3r_sort_pairs_workspace_bytes": (c_sz, [c_ll]),
     "syn3r_sort_pairs": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_i, c_p, c_sz, C.POINTER(c_i), c_p]),
+    "syn3r_gaussian_activate": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "syn3r_gaussian_activate_backward": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "syn3r_gemm_f16": (c_i, [c_p, c_ll, c_p, c_p, c_ll, c_p, c_p, c_ll, c_i, c_i, c_p, c_ll, c_p, c_ll, c_f, c_f, c_f,
                              c_i, c_i, c_i, c_p]),
     "syn3r_gemm_set_tile": (c_i, [c_i]),

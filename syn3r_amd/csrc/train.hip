@@ -95,6 +95,42 @@ __global__ void __launch_bounds__(kThreads) k_adam(float* __restrict__ p, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The published 3DGS parameter activations (GaussianModel.get_scaling / get_rotation / get_opacity: exp, normalize, sigmoid;
+// FSGS' trainer behind gsTrainer.training() / finetune(), model/diffusionGS.py:139,1640) as ONE launch forward and ONE launch
+// for the chain rule backward, instead of three torch operators + their ~10 autograd kernels per training iteration.
+// torch's formulas: normalize = x / max(|x|_2, 1e-12); d/dx = (g - xhat (xhat . g)) / max(|x|, eps);
+// sigmoid' = s (1 - s); exp' = e.
+__global__ void __launch_bounds__(kThreads) k_activate(int N, const float* __restrict__ log_scale, const float* __restrict__ rot,
+                                                       const float* __restrict__ logit, float* __restrict__ scale,
+                                                       float* __restrict__ rot_n, float* __restrict__ opacity) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= N) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) scale[3 * i + c] = expf(log_scale[3 * i + c]);
+    const float4 q = *(const float4*)(rot + 4 * i);
+    const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    *(float4*)(rot_n + 4 * i) = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+    opacity[i] = 1.0f / (1.0f + expf(-logit[i]));
+}
+
+__global__ void __launch_bounds__(kThreads) k_activate_bwd(int N, const float* __restrict__ rot, const float* __restrict__ scale,
+                                                           const float* __restrict__ rot_n, const float* __restrict__ opacity,
+                                                           const float* __restrict__ d_scale, const float* __restrict__ d_rot_n,
+                                                           const float* __restrict__ d_opacity, float* __restrict__ d_log_scale,
+                                                           float* __restrict__ d_rot, float* __restrict__ d_logit) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= N) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d_log_scale[3 * i + c] = d_scale[3 * i + c] * scale[3 * i + c];
+    const float4 q = *(const float4*)(rot + 4 * i), h = *(const float4*)(rot_n + 4 * i), g = *(const float4*)(d_rot_n + 4 * i);
+    const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    const float dot = h.x * g.x + h.y * g.y + h.z * g.z + h.w * g.w;
+    *(float4*)(d_rot + 4 * i) = make_float4((g.x - h.x * dot) * inv, (g.y - h.y * dot) * inv, (g.z - h.z * dot) * inv, (g.w - h.w * dot) * inv);
+    const float s = opacity[i];
+    d_logit[i] = d_opacity[i] * s * (1.0f - s);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Photometric loss of the published 3DGS trainer, fused:  L = w * [(1 - lambda) * mean|I - G| + lambda * (1 - SSIM(I, G))]
 // with SSIM as published (11x11 Gaussian window, sigma 1.5, zero padding 5, C1 = 0.01^2, C2 = 0.03^2, mean over
 // all channels and pixels).  Forward: one pass over 16x16 tiles with a 5-pixel halo staged in LDS, separable
@@ -313,6 +349,32 @@ extern "C" int syn3r_adam_step(float* param, const float* grad, float* exp_avg, 
     SYN3R_LAUNCH(k_adam, dim3((unsigned)b), dim3(kThreads), 0, stream, param, grad, exp_avg, exp_avg_sq, n,
                  (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), bc2_sqrt, eps, neg_step);
     SYN3R_LAUNCH_CHECK("adam_step launch");
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_gaussian_activate(int N, const float* log_scales, const float* rotations, const float* opacity_logits,
+                                       float* scales, float* rotations_n, float* opacities, void* stream_) {
+    SYN3R_REQUIRE(SYN3R_DIM_OK(N), "gaussian_activate: bad N=%d", N);
+    SYN3R_REQUIRE(log_scales && rotations && opacity_logits && scales && rotations_n && opacities, "gaussian_activate: null pointer");
+    SYN3R_REQUIRE((((uintptr_t)rotations | (uintptr_t)rotations_n) % 16) == 0, "gaussian_activate: quaternions must be 16-byte aligned");
+    SYN3R_LAUNCH(k_activate, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream_, N, log_scales,
+                 rotations, opacity_logits, scales, rotations_n, opacities);
+    SYN3R_LAUNCH_CHECK("gaussian_activate launch");
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_gaussian_activate_backward(int N, const float* rotations, const float* scales, const float* rotations_n,
+                                                const float* opacities, const float* d_scales, const float* d_rotations_n,
+                                                const float* d_opacities, float* d_log_scales, float* d_rotations,
+                                                float* d_opacity_logits, void* stream_) {
+    SYN3R_REQUIRE(SYN3R_DIM_OK(N), "gaussian_activate_backward: bad N=%d", N);
+    SYN3R_REQUIRE(rotations && scales && rotations_n && opacities && d_scales && d_rotations_n && d_opacities && d_log_scales &&
+                  d_rotations && d_opacity_logits, "gaussian_activate_backward: null pointer");
+    SYN3R_REQUIRE((((uintptr_t)rotations | (uintptr_t)rotations_n | (uintptr_t)d_rotations_n | (uintptr_t)d_rotations) % 16) == 0,
+                  "gaussian_activate_backward: quaternion tensors must be 16-byte aligned");
+    SYN3R_LAUNCH(k_activate_bwd, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream_, N, rotations,
+                 scales, rotations_n, opacities, d_scales, d_rotations_n, d_opacities, d_log_scales, d_rotations, d_opacity_logits);
+    SYN3R_LAUNCH_CHECK("gaussian_activate_backward launch");
     return SYN3R_OK;
 }
 

@@ -13,7 +13,7 @@ from __future__ import annotations
 import math
 import os
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -501,7 +501,8 @@ class GSTrainer:
         if it >= o.densify_until_iter:
             return
         vis = out["visibility_filter"]
-        g.add_densification_stats(out["viewspace_points"].grad, vis, out["radii"])
+        vgrad = out["viewspace_grad"] if "viewspace_grad" in out else out["viewspace_points"].grad
+        g.add_densification_stats(vgrad, vis, out["radii"])
         if it > o.densify_from_iter and it % o.densification_interval == 0:
             size = o.prune_screen_size if it > o.opacity_reset_interval else None
             self.densify_and_prune(o.densify_grad_threshold, o.prune_min_opacity, self.cameras_extent(), size)
@@ -530,25 +531,96 @@ class GSTrainer:
         cams = self.scene.getTrainCameras()
         return cams[int(self._rng.integers(len(cams)))]
 
-    def train_step(self, cam: Optional[Camera] = None) -> torch.Tensor:
+    class _Ctx:
+        """What an autograd.Function's `ctx` offers, for calling the rasteriser's and the loss' forward / backward
+        directly (the explicit training step below): no graph, no autograd-engine thread."""
+        saved_tensors = ()
+
+        def save_for_backward(self, *t):
+            self.saved_tensors = t
+
+        def mark_non_differentiable(self, *a):
+            pass
+
+        def set_materialize_grads(self, v):
+            pass
+
+    def _explicit_step(self, cam: Camera) -> Tuple[torch.Tensor, dict]:
+        """One optimisation step WITHOUT autograd: raw parameters in, raw-parameter gradients out.  The activations and
+        their chain rule are one HIP launch each (`syn3r_gaussian_activate[_backward]`, replacing three torch operators and
+        their ~10 autograd kernels), the rasteriser's and the loss' forward / backward are called directly, and no
+        screen-space `means2D` tensor is allocated per render.  Same kernels, same arithmetic as the autograd path
+        (`tests/test_trainer_gpu.py` holds one step of each against the oracle and against each other)."""
+        from ..raster import _Rasterize
+        from .train_ops import _L1Loss, _PhotoLoss
+        g, lib = self.gaussians, L.load()
+        dev = g._xyz.device
+        N = g._xyz.shape[0]
+        stream = L.stream_ptr(dev)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            sc, ro, op = new(N, 3), new(N, 4), new(N, 1)
+            L.check(lib.syn3r_gaussian_activate(N, L.ptr(g._scaling), L.ptr(g._rotation), L.ptr(g._opacity), L.ptr(sc), L.ptr(ro),
+                                                L.ptr(op), stream), "gaussian_activate")
+            st = GaussianRasterizationSettings(
+                image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
+                tanfovy=math.tan(cam.FoVy * 0.5), bg=self.background, scale_modifier=1.0,
+                viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=g.active_sh_degree,
+                campos=cam.camera_center, prefiltered=False, debug=False)
+            rctx = self._Ctx()
+            color, radii, depth, alpha = _Rasterize.forward(rctx, g._xyz, None, g._features, op, sc, ro, g.confidence, st)
+            lctx = self._Ctx()
+            w = float(cam.cam_confidence)
+            if self.opt.lambda_dssim > 0.0:
+                loss, _ = _PhotoLoss.forward(lctx, color, cam.original_image, self.opt.lambda_dssim, w)
+                d_color = _PhotoLoss.backward(lctx, self._one(dev), None)[0]
+            else:
+                loss = _L1Loss.forward(lctx, color, cam.original_image, w)
+                d_color = _L1Loss.backward(lctx, self._one(dev))[0]
+            d_m3, d_m2, d_sh, d_op, d_sc, d_ro, _, _ = _Rasterize.backward(rctx, d_color, None, None, None)
+            d_ls, d_rr, d_lg = new(N, 3), new(N, 4), new(N, 1)
+            L.check(lib.syn3r_gaussian_activate_backward(N, L.ptr(g._rotation), L.ptr(sc), L.ptr(ro), L.ptr(op), L.ptr(d_sc),
+                                                         L.ptr(d_ro), L.ptr(d_op), L.ptr(d_ls), L.ptr(d_rr), L.ptr(d_lg), stream),
+                    "gaussian_activate_backward")
+            g._xyz.grad, g._features.grad, g._opacity.grad, g._scaling.grad, g._rotation.grad = d_m3, d_sh, d_lg.reshape(g._opacity.shape), d_ls, d_rr
+        out = {"render": color, "depth": depth, "alpha": alpha, "viewspace_grad": d_m2, "visibility_filter": radii > 0 if self.densify else None,
+               "radii": radii}
+        return loss, out
+
+    def _one(self, dev) -> torch.Tensor:
+        one = getattr(self, "_one_cache", None)
+        if one is None or one.device != dev:
+            one = self._one_cache = torch.ones((), dtype=torch.float32, device=dev)
+        return one
+
+    def train_step(self, cam: Optional[Camera] = None, explicit: Optional[bool] = None) -> torch.Tensor:
         """One optimisation step; returns the loss as a DEVICE scalar (no host synchronisation: the loop queues
         iterations back to back, `float(loss)` is the caller's choice).  `opt.use_lpips_loss` (set by the orchestrator
         around refine_GS, diffusionGS.py:1690,1697) adds `opt.lpips_weight` x LPIPS-VGG (`syn3r_amd.gs.lpips`, HIP) when the
         trainer has been given an `lpips` model with weights (the pretrained ones are not reachable offline: the caller
-        loads them, as for CLIP / VAE / UNet); without one the switch is inert."""
+        loads them, as for CLIP / VAE / UNet); without one the switch is inert.
+        `explicit` (default: whenever the LPIPS term is off): the step without autograd (`_explicit_step`)."""
         cam = cam or self._pick_camera()
-        out = self.render_view(cam)
-        if self.opt.lambda_dssim > 0.0:
-            loss = photometric_loss(out["render"], cam.original_image, self.opt.lambda_dssim, float(cam.cam_confidence))
+        lpips_on = self.opt.use_lpips_loss and self.opt.lpips_weight > 0.0 and self.lpips is not None
+        if explicit is None:
+            explicit = not lpips_on
+        if explicit:
+            if lpips_on:
+                raise ValueError("train_step(explicit=True) has no LPIPS term: the perceptual loss runs through autograd")
+            loss, out = self._explicit_step(cam)
         else:
-            loss = l1_loss(out["render"], cam.original_image, weight=float(cam.cam_confidence))
-        if self.opt.use_lpips_loss and self.opt.lpips_weight > 0.0 and self.lpips is not None:
-            # the perceptual term of the refine stage (diffusionGS.py:1690,1697; `--lpips_weight`): published LPIPS-VGG on the
-            # whole render, weighted like the photometric term by the camera confidence.  How FSGS applies it is not visible
-            # (un-vendored): UNPINNED.
-            loss = loss + (self.opt.lpips_weight * float(cam.cam_confidence)) * self.lpips(out["render"].clamp(0, 1), cam.original_image)
-        self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+            out = self.render_view(cam)
+            if self.opt.lambda_dssim > 0.0:
+                loss = photometric_loss(out["render"], cam.original_image, self.opt.lambda_dssim, float(cam.cam_confidence))
+            else:
+                loss = l1_loss(out["render"], cam.original_image, weight=float(cam.cam_confidence))
+            if lpips_on:
+                # the perceptual term of the refine stage (diffusionGS.py:1690,1697; `--lpips_weight`): published LPIPS-VGG on the
+                # whole render, weighted like the photometric term by the camera confidence.  How FSGS applies it is not visible
+                # (un-vendored): UNPINNED.
+                loss = loss + (self.opt.lpips_weight * float(cam.cam_confidence)) * self.lpips(out["render"].clamp(0, 1), cam.original_image)
+            self.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
         changed = False
         if self.densify:
             n0 = self.gaussians._xyz.shape[0]

@@ -40,10 +40,14 @@ def test_lpips_value_and_gradient_vs_oracle(gpu, H, W):
     ao = a.double().requires_grad_(True)
     ref = LO.lpips(ao, b.double(), sd)
     (3.0 * ref).backward()
-    assert abs(float(loss) - float(ref)) < 2e-2 * abs(float(ref)), (float(loss), float(ref))
     gh, go = pred.grad.double().cpu(), ao.grad
     rel = float((gh - go).norm() / go.norm())
     cos = float((gh * go).sum() / (gh.norm() * go.norm()))
+    from tests.conftest import record_measurement
+    record_measurement(f"lpips:{H}x{W}", value_rel=abs(float(loss) - float(ref)) / abs(float(ref)), grad_rel=rel, grad_cos=cos)
+    # measured (round 5, gpurun_out/test_measurements.jsonl): value 9e-7 .. 2.5e-5 relative, gradient 5.4-5.7e-2 relative, cosine
+    # 0.9983-0.9986 (the gradient's error is the 13 fp16 backward-data convolutions, profiles/r04/lpips_layers.txt)
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-4 * abs(float(ref.detach())), (float(loss.detach()), float(ref.detach()))
     assert rel < 6e-2 and cos > 0.998, (rel, cos)              # fp16 activations / gradients against float64
     # a second call with the same target object reuses its cached features and gives the same number
     assert float(m(pred.detach(), target)) == float(loss)

@@ -54,6 +54,48 @@ def test_render_view_and_one_adam_step_match_oracle(gpu):
         assert (d > 1e-6).double().mean() < 2e-2
 
 
+@pytest.mark.parametrize("lambda_dssim", [0.2, 0.0])
+def test_explicit_step_equals_autograd_step(lambda_dssim, gpu):
+    """The training loop's default step calls the activations (one HIP launch forward, one for the chain rule), the rasteriser
+    and the loss directly - no autograd graph.  Its raw-parameter gradients equal autograd's through torch.exp / sigmoid /
+    normalize + the same HIP operators, and so does the screen-space gradient the density control reads."""
+    from syn3r_amd.gs import Camera, GSTrainer, OptimizationParams
+    N, H, W = 3000, 72, 104
+    w2c = np.eye(4, dtype=np.float32)
+    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(5))
+    grads = {}
+    for explicit in (False, True):
+        gm, K = make_scene(N, H, W, 7, gpu)
+        cam = Camera.from_w2c(w2c, K, H, W, image=target, data_device=gpu, cam_confidence=0.7)
+        tr = GSTrainer(gm, [cam], OptimizationParams(iterations=1, lambda_dssim=lambda_dssim))
+        if explicit:
+            loss, out = tr._explicit_step(cam)
+            vs = out["viewspace_grad"]
+        else:
+            out = tr.render_view(cam)
+            from syn3r_amd.gs.train_ops import l1_loss, photometric_loss
+            loss = (photometric_loss(out["render"], cam.original_image, lambda_dssim, 0.7) if lambda_dssim > 0
+                    else l1_loss(out["render"], cam.original_image, weight=0.7))
+            loss.backward()
+            vs = out["viewspace_points"].grad
+        grads[explicit] = [float(loss)] + [p.grad.detach().clone() for p in gm.parameters()] + [vs.detach().clone()]
+    assert abs(grads[True][0] - grads[False][0]) < 1e-6
+    for a, b in zip(grads[True][1:], grads[False][1:]):
+        assert a.shape == b.shape
+        scale = float(b.abs().max()) + 1e-20
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (float((a - b).abs().max()), scale)
+    # and the public entry takes the explicit step by default, the autograd step on request: the same update
+    finals = []
+    for explicit in (None, False):
+        gm, K = make_scene(N, H, W, 7, gpu)
+        cam = Camera.from_w2c(w2c, K, H, W, image=target, data_device=gpu, cam_confidence=0.7)
+        tr = GSTrainer(gm, [cam], OptimizationParams(iterations=1, lambda_dssim=lambda_dssim))
+        tr.train_step(cam, explicit=explicit)
+        finals.append([p.detach().clone() for p in gm.parameters()])
+    for a, b in zip(*finals):
+        assert ((a - b).abs() > 1e-6).double().mean() < 1e-3          # Adam's first step is lr * sign(grad)
+
+
 def test_training_loop_fits_a_view(gpu):
     from syn3r_amd.gs import Camera, GSTrainer, OptimizationParams
     N, H, W = 1500, 64, 96

@@ -6,9 +6,10 @@ with the DEFAULT kernel dispatch — the contraction / attention variants bench.
     launch: [2,14,8,72,128] (bench unit), [1,25,8,40,72] / [1,25,8,48,72] (Post guidance tiles), [2,25,8,72,128];
   * oracle/unet_oracle.py (pinned by unet_small.npz) at a small shape, run live.
 
-Tolerance: fp16 storage / fp32 accumulate through ~300 layers against fp32.  Measured on MI355X (round 2): max 1.2-1.8e-3,
-mean 2.0-3.3e-4 of the output scale over the four shapes; the bar is 1e-2 max / 1.5e-3 mean (5x the measurement, a third
-of the small-configuration test's bar)."""
+Tolerance: fp16 storage / fp32 accumulate through ~300 layers against fp32.  Measured on MI355X (round 5, recorded by
+tests/conftest.py:record_measurement, gpurun_out/test_measurements.jsonl): max 1.23-1.97e-3, mean 2.0-3.3e-4 of the output scale
+over the four shapes and the live oracle shape; the bar is 4e-3 max / 6.6e-4 mean = 2x the largest measurement (VERDICT r04:
+a 4x regression of the accumulated error used to pass)."""
 import numpy as np
 import pytest
 import torch
@@ -18,6 +19,7 @@ from oracle import unet_weights as UW
 pytestmark = pytest.mark.gpu
 
 FULL_SEED = 5      # oracle/gen_golden.py gen_unet_full
+MAX_BAR, MEAN_BAR = 4e-3, 6.6e-4
 
 
 @pytest.fixture(scope="module")
@@ -32,7 +34,9 @@ def full_unet(gpu):
 def _compare(y, ref, what):
     scale = float(np.abs(ref).max())
     err = np.abs(y - ref)
-    assert err.max() < 1e-2 * scale and err.mean() < 1.5e-3 * scale, (what, float(err.max()), float(err.mean()), scale)
+    from tests.conftest import record_measurement
+    record_measurement("unet_full:" + what, max_over_scale=float(err.max()) / scale, mean_over_scale=float(err.mean()) / scale)
+    assert err.max() < MAX_BAR * scale and err.mean() < MEAN_BAR * scale, (what, float(err.max()), float(err.mean()), scale)
     return float(err.max()) / scale, float(err.mean()) / scale
 
 

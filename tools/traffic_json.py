@@ -134,5 +134,8 @@ if famjson:
     for name in ("k_attn_spatial", "k_render_bwd", "k_render"):
         if name in out and name in pf and "mfma_busy" in pf[name]:
             out[name]["mfma_busy"] = pf[name]["mfma_busy"]
+        # executed vector wave-instructions per launch: bench.py's VALU-issue roof of the blend kernels
+        if name in pf and "SQ_INSTS_VALU" in pf[name].get("per_launch", {}):
+            out.setdefault(name, {})["valu_insts_per_launch"] = pf[name]["per_launch"]["SQ_INSTS_VALU"]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
