@@ -86,6 +86,12 @@ struct GemmParams {
     int Ho, Wo, Hi, Wi, Cin, stride, ups, pad;   // pad: zero rows/cols before the first pixel (1, or 0 for the (0,1,0,1) pad)
     // temporal conv: F frames of HW rows each (row = (b*F + f)*HW + p)
     int F, HW;
+    // k_gemm_dmap<MODE_TCONV>: tile order with the FRAME index minor (tc_pb = HW / 256 pixel blocks per frame, tc_nf = M / HW
+    // frames; 0 = rows in memory order).  The three taps of a row tile read the same 256 pixels of frames f - 1, f, f + 1: in
+    // memory order those are 36 tiles apart at level 0 and every tap streams its rows from beyond the L2 (counted HBM bytes
+    // 2.14x the algorithmic ones, profiles/r04/traffic.json); with the frames of one pixel block consecutive, the 16 row tiles an
+    // XCD holds at a time are 16 frames of that block and two of a tile's three A taps are another tile's rows (L2 hits).
+    int tc_pb, tc_nf;
     // GEGLU epilogue: W rows are packed per 160-row tile as [80 hidden | 80 gate]; out has geglu_D columns
     int geglu_D;
     // A-tiled layout of a [M, D] matrix (the feed-forward's gated hidden activation, written by the GEGLU kernel and
@@ -333,8 +339,20 @@ __global__ void __launch_bounds__(BM * 2, 2) k_gemm_dma(GemmParams p) {
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const unsigned ntile = (unsigned)(tiles_m * tiles_n);
-    const int sp = p.ksplit > 1 ? (int)(blockIdx.x / ntile) : 0;             // split-K: which part of the K range
-    const unsigned bid = xcd_remap(blockIdx.x - (unsigned)sp * ntile, ntile);
+    // split-K: which part of the K range.  An XCD takes ONE K part (blocks b and b + 8 share an XCD: part = (b % 8) % S) and a
+    // contiguous chunk of that part's tiles, so that it streams 1 / S of the weight panel and 1 / (8 / S) of the rows instead of the
+    // whole panel (round 4's order gave every XCD both parts of its tiles: counted HBM bytes 4.1x the algorithmic ones on the
+    // M = 4 032 launches, profiles/r04/traffic.json).  Speed only: any placement computes the same partial tiles.
+    int sp = 0;
+    unsigned bid;
+    if (p.ksplit > 1 && (ntile * (unsigned)p.ksplit) % 8 == 0 && 8 % p.ksplit == 0) {
+        const unsigned xcd = blockIdx.x % 8, k = blockIdx.x / 8, S = (unsigned)p.ksplit;
+        sp = (int)(xcd % S);
+        bid = (xcd / S) * (ntile * S / 8) + k;
+    } else {
+        sp = p.ksplit > 1 ? (int)(blockIdx.x / ntile) : 0;
+        bid = xcd_remap(blockIdx.x - (unsigned)sp * ntile, ntile);
+    }
     const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -1038,8 +1056,15 @@ __global__ void __launch_bounds__(512, 2) k_gemm_dmap(GemmParams p) {
     int tap_next = 0, c_left = 0;
     unsigned itl = blockIdx.x / 8;                      // the cursor's position in this block's tile list ...
     int ikt = 0, islot = 0;                             // ... k-tile inside that tile, ring slot of the next stage
+    // row tile of position `rt` in the tile order (GemmParams::tc_pb: temporal convolutions walk the frames of a pixel block first)
+    auto row_tile = [&](unsigned rt) -> int {
+        if constexpr (MODE == MODE_TCONV) {
+            if (p.tc_pb > 0) { const unsigned pb = rt / (unsigned)p.tc_nf, fr_ = rt - pb * (unsigned)p.tc_nf; return (int)(fr_ * (unsigned)p.tc_pb + pb); }
+        }
+        return (int)rt;
+    };
     auto setup_issue_tile = [&](unsigned tile) {
-        const int m0 = (int)(tile / (unsigned)tiles_n) * BM, n0 = (int)(tile % (unsigned)tiles_n) * BN;
+        const int m0 = row_tile(tile / (unsigned)tiles_n) * BM, n0 = (int)(tile % (unsigned)tiles_n) * BN;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + wv * 32 + i * 8 + prow;
@@ -1136,7 +1161,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_dmap(GemmParams p) {
     bool first_tile = true;
     for (unsigned tl = blockIdx.x / 8; tl < t_len; tl += t_stride) {
         const unsigned tile = t_start + tl;
-        const int m0 = (int)(tile / (unsigned)tiles_n) * BM, n0 = (int)(tile % (unsigned)tiles_n) * BN;
+        const int m0 = row_tile(tile / (unsigned)tiles_n) * BM, n0 = (int)(tile % (unsigned)tiles_n) * BN;
         float4v acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1977,7 +2002,13 @@ int launch_dmap(const GemmParams& p, hipStream_t stream) {
         if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_dmap<%d>[M%d,N%d,K%d,e%d]", MODE, p.M, p.N, p.K, p.residual != nullptr);
         else snprintf(name, sizeof(name), "k_gemm_dmap<%d>", MODE);
     }
-    SYN3R_LAUNCH_NAMED(name, (k_gemm_dmap<MODE>), dim3(blocks), dim3(512), lds, stream, p);
+    GemmParams q = p;
+    q.tc_pb = q.tc_nf = 0;
+    if constexpr (MODE == MODE_TCONV) {
+        static const int tc_env = tune_env("SYN3R_TCONV_ORDER", 1);       // 0: rows in memory order (tuning builds)
+        if (tc_env != 0 && p.HW % 256 == 0 && p.M % p.HW == 0 && p.M / p.HW > 1) { q.tc_pb = p.HW / 256; q.tc_nf = p.M / p.HW; }
+    }
+    SYN3R_LAUNCH_NAMED(name, (k_gemm_dmap<MODE>), dim3(blocks), dim3(512), lds, stream, q);
     SYN3R_LAUNCH_CHECK("gemm_dmap launch");
     return SYN3R_OK;
 }
