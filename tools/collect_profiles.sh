@@ -30,6 +30,10 @@ if [ -n "$SQ_FILES" ]; then
 fi
 cp "$OUT/stats/bench_kernel_stats.csv" "$OUT/bench_kernel_stats.csv"
 ( timeout -k 10 200 python3 "$R/tools/unet_breakdown.py" 14 detail 2>/dev/null | grep -v amdgpu.ids > "$OUT/unet_shapes.txt" ) || true
+( timeout -k 10 200 python3 "$R/tools/unet_breakdown.py" 25 detail 2>/dev/null | grep -v amdgpu.ids > "$OUT/unet_shapes_f25.txt" ) || true
+# per-shape TFLOP/s of the SAME build (the tables used to predate the final kernels)
+python3 "$R/tools/shape_efficiency.py" "$OUT/unet_shapes.txt" > "$OUT/shape_efficiency_f14.txt" || true
+python3 "$R/tools/shape_efficiency.py" "$OUT/unet_shapes_f25.txt" > "$OUT/shape_efficiency_f25.txt" || true
 if [ -f "$OUT/fetch/p_counter_collection.csv" ] && [ -f "$OUT/write/p_counter_collection.csv" ]; then
   python3 "$R/tools/traffic_json.py" "$OUT/fetch/p_counter_collection.csv" "$OUT/write/p_counter_collection.csv" "$OUT/traffic.json" $( [ -f "$OUT/pmc_counters_by_kernel.json" ] && echo "$OUT/pmc_counters_by_kernel.json" ) $( [ -s "$OUT/unet_shapes.txt" ] && echo "$OUT/unet_shapes.txt" ) > /dev/null
   python3 "$R/tools/pmc_by_kernel.py" "$OUT/fetch/p_counter_collection.csv" FETCH_SIZE > "$OUT/bench_FETCH_SIZE_by_kernel.csv"
