@@ -635,6 +635,36 @@ def gen_orch_nearby():
           out["intensity_uncertainty_mean"])
 
 
+def gen_orch_fusion():
+    """O5: the uncertainty fusion and condition-image selection of `_interpolate_between_gs_v3` (model/diffusionGS.py:821-867).  The
+    formula is inline in a 150-line method that needs a renderer, so it is not callable as a function; its STATEMENTS are: the block
+    from `def get_intensity_confidence(` to the line before `# save for debugging` is read from the reference file at generation
+    time and executed as it stands (dedented) on seeded inputs bound to the names it uses (`self.diffusion_type`, `aux`,
+    `pseudo_images`, the two nearby-consistency lists).  Nothing of the block is stored: the fixture holds its outputs."""
+    import textwrap
+    import types
+    lines = (REF / "model" / "diffusionGS.py").read_text().splitlines()
+    a = next(i for i, l in enumerate(lines) if i > 800 and l.strip().startswith("def get_intensity_confidence("))     # (a dead path holds a copy at :527)
+    b = next(i for i, l in enumerate(lines) if i > a and l.strip() == "# save for debugging")
+    assert 815 <= a + 1 <= 830 and 860 <= b + 1 <= 875, (a, b)          # the snapshot this build surveyed (SURVEY.md 8a, row O5)
+    block = textwrap.dedent("\n".join(lines[a:b]))
+    c = GI.orch_fusion_case()
+    ns = {"np": np, "torch": torch, "self": types.SimpleNamespace(diffusion_type="2PassProbUncertainPost"),
+          "aux": {"soft_masks_reproj": None, "soft_masks_reproj_ori": np.stack(c["soft_masks_reproj_ori"]), "cond_images_ori": c["cond_images_ori"]},
+          "pseudo_images": c["pseudo_images"],
+          "nearby_consistency_uncertainty": [torch.from_numpy(x) for x in c["nearby"]],
+          "nearby_inten_consistency_uncertainty": [torch.from_numpy(x) for x in c["nearby_inten"]]}
+    exec(compile(block, "diffusionGS.py:%d-%d" % (a + 1, b), "exec"), ns)
+    masks, cond = ns["masks"].numpy(), np.asarray(ns["cond_image"])
+    sy, sx = GI.ORCH_NEARBY_STRIDE
+    gs = np.stack(c["pseudo_images"][1:-1])
+    out = {"masks": masks.astype(np.float32), "cond_image": cond[:, ::sy, ::sx].astype(np.float32),
+           "took_gs": np.all(cond == gs, axis=-1)[:, ::sy, ::sx], "cond_image_mean": cond.astype(np.float64).mean(axis=(1, 2, 3)),
+           "geo_inten_uncertainty_debug": np.asarray(ns["geo_inten_uncertainty"])[:, ::sy, ::sx, 0].astype(np.float32)}
+    np.savez_compressed(GOLD / "orch_fusion.npz", **out)
+    print("orch_fusion", {k: getattr(v, "shape", ()) for k, v in out.items()}, masks.mean(axis=(1, 2)), out["took_gs"].mean(axis=(1, 2)))
+
+
 def gen_train_flags():
     """The (flag, default, choices, type, action, nargs) of every `parser.add_argument` the reference's CLI declares itself
     (scripts/train.py:28-69; the FSGS parameter groups it also instantiates live in the absent submodule).  The script
@@ -779,6 +809,8 @@ def main():
         gen_clip_preprocess()
     if "orch" in which:
         gen_orchestrator()
+    if "orch_fusion" in which:            # seconds: the reference's own statements on four 576 x 1024 frames
+        gen_orch_fusion()
     if "train_flags" in which:
         gen_train_flags()
     if "orch_nearby" in which:            # ~1 min of CPU: eight full-size reference inverse warps

@@ -158,6 +158,29 @@ def orch_nearby_case(H=576, W=1024, n=5):
     return K, poses, images, depths
 
 
+def orch_fusion_case(n=4, H=576, W=1024):
+    """Inputs of the uncertainty fusion / condition-image selection (diffusionGS.py:821-867) at the diffusion resolution: n interior
+    frames.  cond_images_ori: smooth warped images in [0,1] with unrendered holes (all-zero pixels); pseudo_images: the n + 2 renders
+    (close to the warps, further away in a band so that both sides of the 0.5 threshold occur); soft_masks_reproj_ori in [0,1];
+    the two nearby-consistency lists the block's debugging lines read.  Everything float32 (the reference mixes float32 / float64)."""
+    rng = np.random.default_rng(91)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    pseudo, cond, soft = [], [], []
+    for i in range(n + 2):
+        im = np.stack([0.5 + 0.35 * np.sin(xs / (29.0 + 5 * c) + 0.3 * i) * np.cos(ys / (37.0 + 3 * c)) for c in range(3)], axis=-1)
+        pseudo.append(im.astype(f32))
+    for i in range(n):
+        d = 0.02 * rng.standard_normal((H, W, 3)) + 0.6 * np.exp(-((xs - 300.0 - 90 * i) / 60.0) ** 2)[..., None]     # a band that disagrees
+        w = np.clip(pseudo[i + 1] + d, 0.0, 1.0).astype(f32)
+        w[60 + 40 * i:110 + 40 * i, 500:640] = 0.0                                                                  # holes
+        cond.append(w)
+        soft.append(np.clip(0.15 + 0.5 * np.sin(xs / 83.0 + i) ** 2 * np.cos(ys / 71.0) ** 2 + 0.05 * rng.random((H, W)), 0, 1).astype(f32))
+    soft[n - 1][:] = np.clip(soft[n - 1] + 0.7, 0, 1)          # one frame whose mean uncertainty exceeds 0.6 (the debugging branch)
+    near = [rng.random((H, W)).astype(f32) * 0.3 for _ in range(n + 2)]
+    near_i = [rng.random((H, W)).astype(f32) * 0.3 for _ in range(n + 2)]
+    return dict(pseudo_images=pseudo, cond_images_ori=cond, soft_masks_reproj_ori=soft, nearby=near, nearby_inten=near_i)
+
+
 def n2_view_poses(V, seed=0):
     """V input-view w2c poses on a gently curving, unevenly spaced path (key-frame selection has something to choose)."""
     rng = np.random.default_rng(100 + seed)

@@ -76,6 +76,28 @@ def test_nearby_consistency_oracle_matches_reference(golden_dir):
         assert abs(float(im[i].astype(np.float64).mean()) - g["intensity_uncertainty_mean"][i]) < 1e-3
 
 
+def test_uncertainty_fusion_oracle_matches_reference(golden_dir):
+    """O5: oracle/orchestrator_oracle.fuse_uncertainty (and the product's numpy host form) against the reference's own statements
+    (model/diffusionGS.py:821-867, executed on four seeded 576 x 1024 frames by oracle/gen_golden.py orch_fusion): pooled masks
+    [n,72,128], the condition images and which pixels took the GS render."""
+    from oracle import orchestrator_oracle as OO
+    c = GI.orch_fusion_case()
+    g = np.load(golden_dir / "orch_fusion.npz")
+    sy, sx = GI.ORCH_NEARBY_STRIDE
+    cond_ori, gs, soft = np.stack(c["cond_images_ori"]), np.stack(c["pseudo_images"][1:-1]), np.stack(c["soft_masks_reproj_ori"])
+    masks, cond, unc = OO.fuse_uncertainty(cond_ori, gs, soft, 72, 128)
+    np.testing.assert_allclose(masks, g["masks"], atol=2e-6)
+    cond = np.stack(cond)
+    np.testing.assert_allclose(cond[:, ::sy, ::sx], g["cond_image"], atol=1e-6)
+    assert np.array_equal(np.all(cond == gs, axis=-1)[:, ::sy, ::sx], g["took_gs"])
+    np.testing.assert_allclose(cond.astype(np.float64).mean(axis=(1, 2, 3)), g["cond_image_mean"], atol=1e-7)
+    # the numpy host form the product keeps beside the kernel (no device needed)
+    from syn3r_amd import orchestrator as O
+    m2, c2, _ = O.fuse_uncertainty(cond_ori, gs, soft, 72, 128)
+    np.testing.assert_allclose(m2.numpy(), g["masks"], atol=2e-6)
+    assert np.array_equal(np.all(np.stack(c2) == gs, axis=-1)[:, ::sy, ::sx], g["took_gs"])
+
+
 def test_sigma_schedule_matches_reference(golden_dir):
     g = np.load(golden_dir / "sched_sigmas.npz")
     s = GI.karras_sigmas(100)

@@ -159,6 +159,27 @@ def test_nearby_consistency_vs_cpu_oracle():
         assert np.mean(d > 2e-3) < 5e-3, float(np.mean(d > 2e-3))
 
 
+def test_uncertainty_fusion_vs_reference_golden(golden_dir):
+    """O5 pinned: `syn3r_fuse_uncertainty` against the reference's own statements (model/diffusionGS.py:821-867) executed on four
+    seeded 576 x 1024 frames (tests/golden/orch_fusion.npz, oracle/gen_golden.py orch_fusion): pooled masks to 1e-5 (fp32 kernel
+    against the reference's float64 means), condition images exact wherever the uncertainty is not within 1e-5 of the 0.5 threshold."""
+    from oracle import golden_inputs as GI
+    from syn3r_amd import orchestrator as O
+    c = GI.orch_fusion_case()
+    g = np.load(golden_dir / "orch_fusion.npz")
+    sy, sx = GI.ORCH_NEARBY_STRIDE
+    dev = torch.device("cuda", 0)
+    cond_ori, gs, soft = np.stack(c["cond_images_ori"]), np.stack(c["pseudo_images"][1:-1]), np.stack(c["soft_masks_reproj_ori"])
+    m, cimg, u = O.fuse_uncertainty_device(torch.tensor(cond_ori, device=dev), gs, torch.tensor(soft, device=dev), h=72, w=128)
+    np.testing.assert_allclose(m.cpu().numpy(), g["masks"], atol=1e-5)
+    cs = cimg.cpu().numpy()[:, ::sy, ::sx]
+    took = np.all(cs == gs[:, ::sy, ::sx], axis=-1)
+    assert np.mean(took != g["took_gs"]) < 1e-4, float(np.mean(took != g["took_gs"]))
+    same = took == g["took_gs"]
+    np.testing.assert_allclose(cs[same], g["cond_image"][same], atol=1e-6)
+    np.testing.assert_allclose(cimg.double().mean(dim=(1, 2, 3)).cpu().numpy(), g["cond_image_mean"], atol=1e-5)
+
+
 def test_nearby_consistency_vs_reference_golden(golden_dir):
     """O4 pinned: the HIP path against the REFERENCE's own consistency_check_from_nearby_images_bw
     (model/diffusionGS.py:1300-1361) run on five seeded 576 x 1024 frames (tests/golden/orch_nearby.npz, written by
