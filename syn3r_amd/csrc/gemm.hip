@@ -287,12 +287,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, float4v (&acc
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.0f ? v[e] : (_Float16)0.0f;
         }
-#ifdef SYN3R_EXP_NOSTORE
-        if ((float)v[0] != 12345.678f) continue;
-#endif
-#ifdef SYN3R_EXP_SMALLSTORE    // every store instruction issued, but into a 1 MB window (cache resident): request side only
-        { *(half8*)(p.out + (((long long)(gm0 + row) * 640 + gn0 + ch * 8) & 0x7fff8)) = v; continue; }
-#endif
         if (p.out_tiled) {
             OUT_STORE((half8*)(p.out + tiled_off(m, n, p.N)), v);
         } else if (n + 8 <= p.N) {
@@ -697,9 +691,6 @@ __device__ __forceinline__ void lean_store(const GemmParams& p, float4v (*acc)[T
     constexpr int NQ = NI * 16 * (WN / 8) / 64;   // 10 (NI = 4) or 5 (NI = 2) chunks of 16 bytes per lane
     auto put = [&](int m, int n, const half8& v) {
         if (!(full || (m < p.M && n < N))) return;
-#ifdef Z_EXP_NOSTORE        // timing experiment (wrong results): the epilogue without its global stores
-        if ((float)v[0] != 12345.678f) return;
-#endif
         if (p.out_tiled) OUT_STORE((half8*)(p.out + tiled_off(m, n, N)), v);
         else OUT_STORE((half8*)(p.out + (long long)m * p.ldc + n), v);
     };
@@ -849,14 +840,6 @@ __global__ void __launch_bounds__(512, 2) k_gemm_widep(GemmParams p) {
     // slot 1 and slot 0 is free for the next tile's stage 0, while slot 1 plus the 16 KB behind the ring are exactly
     // the 90,112 bytes the epilogue stages the accumulators through.  Odd counts issue after the epilogue.
     const bool xpf = (nkt & 1) == 0;
-#ifdef SYN3R_EXP_DESYNC   // experiment: start the blocks in 4 phases a quarter of a tile time apart (output bursts spread out)
-    if (t_len >= 4 * t_stride) {
-        const unsigned phase = (blockIdx.x / 8) & 3;
-        const unsigned long long delay = (unsigned long long)phase * ((unsigned long long)nkt * 3300ull + 20000ull) / 4ull;
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(16);
-    }
-#endif
 #ifdef SYN3R_TIMING     // tools/wide_timing.py: s_memtime ticks of one block's tile phases + both clocks around the tile loop
     unsigned long long tph[3] = {0, 0, 0}, tkt[2] = {0, 0}, tgate = 0, ntile = 0, t_a = __builtin_amdgcn_s_memtime();
     const unsigned long long t_begin = t_a, r_begin = __builtin_amdgcn_s_memrealtime();

@@ -270,28 +270,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
     // piece IDX of the stage the cursor points at: 0-3 = A, 4-8 = B
     auto piece = [&](auto IDX) {
         constexpr int idx = decltype(IDX)::value;
-#ifdef Z_EXP_NODMA          // timing experiment (wrong results): the main loop without its DMA stream
-        if (c_tl != 0xffffffffu) return;
-#endif
-#ifdef Z_EXP_DMAHOT         // timing experiment (wrong results): every piece re-reads ONE cache-resident KiB (issue + LDS write only)
-        if (c_tl != 0xffffffffu) {
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.W + (size_t)voff_b), (lds_void_t*)(smem_raw + c_slot + (wv * 9 + idx) * 1024), 16, 0, 0);
-            return;
-        }
-#endif
         char* st = smem_raw + c_slot;
-#ifdef Z_EXP_HALFISSUE      // timing experiment (M % 256 == 0 shapes): wavefronts 0-3 issue their SIMD partners' pieces too, 4-7 none
-        if (wv >= 4) return;
-        if constexpr (idx < 4) {
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase + (size_t)(oa[idx] + voff_a)), (lds_void_t*)(st + (wv * 4 + idx) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase + (size_t)(oa[idx] + 256u * (unsigned)p.lda + voff_a)), (lds_void_t*)(st + ((wv + 4) * 4 + idx) * 1024), 16, 0, 0);
-        } else {
-            constexpr int j = idx - 4;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.W + (size_t)(ob[j] + voff_b)), (lds_void_t*)(st + W_A_BYTES + (wv * 5 + j) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.W + (size_t)(ob[j] + 320u * (unsigned)p.K + voff_b)), (lds_void_t*)(st + W_A_BYTES + ((wv + 4) * 5 + j) * 1024), 16, 0, 0);
-        }
-        return;
-#endif
         if constexpr (idx < 4 && MODE == MODE_CONV2D) {
             const unsigned mk = tap_mask << (6 * idx);
             const bool ok = (cv_flags & mk) == mk;
@@ -361,21 +340,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
     auto group_piece = [&](auto QC) {
         constexpr int q = decltype(QC)::value;
         constexpr int order[9] = {0, 4, 1, 5, 2, 6, 3, 7, 8};     // A and B pieces alternate
-#ifdef Z_EXP_DEPHASE        // timing experiment (wrong results; build with -DZ_EXP_NOVMWAIT): wavefronts 4-7 issue their pieces in groups 8-16
-        if constexpr (q < 9) { if (wv < 4) piece(std::integral_constant<int, order[q < 9 ? q : 0]>{}); }
-        if constexpr (q >= 8 && q < 17) { if (wv >= 4) piece(std::integral_constant<int, order[(q >= 8 && q < 17) ? q - 8 : 0]>{}); }
-        if constexpr (q == 16) cursor_end();
-#elif defined(Z_BUNCH)      // the nine pieces in the first three groups (three each) instead of one per group
-        if constexpr (q < 3) {
-            piece(std::integral_constant<int, order[q < 3 ? 3 * q : 0]>{});
-            piece(std::integral_constant<int, order[q < 3 ? 3 * q + 1 : 0]>{});
-            piece(std::integral_constant<int, order[q < 3 ? 3 * q + 2 : 0]>{});
-        }
-        if constexpr (q == 2) cursor_end();
-#else
         if constexpr (q < 9) piece(std::integral_constant<int, order[q < 9 ? q : 0]>{});
         if constexpr (q == 8) cursor_end();
-#endif
     };
 #define Z_YOUNGER(q) ((19 - (q) < LA ? 19 - (q) : LA) + ((NAF == 2 && (q) >= 7 && (q) < 7 + LA && (q) != 10) ? 4 : 0))
 // (group 10 also needs the A reads of k-half 1: with two register sets they were issued at group 7 and the allowed count is the
@@ -383,15 +349,6 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
 // Group 0, one set: the A reads follow group 19's MFMAs, with two weight reads behind them.)
 #define Z_NWAIT(q) (NAF == 1 ? ((q) == 10 ? 1 : ((q) == 0 ? 2 : Z_YOUNGER(q))) \
                              : ((q) == 10 ? (LA < 4 ? LA : ((10 + LA < 19 ? 10 + LA : 19) - (7 + LA) + 1)) : Z_YOUNGER(q)))
-#ifdef Z_PIECE_AFTER        // the group's DMA piece behind its MFMAs instead of in front of its reads
-#define Z_GROUP(q) do { \
-        if constexpr (NAF == 2 && (q) == 7) z_read_a<1, NAF>(af, ra); \
-        if constexpr ((q) + LA <= 19) z_read_b<((q) + LA <= 19 ? (q) + LA : 0), RB>(bf, rb); \
-        z_wait<(q), RB, Z_NWAIT(q), NAF>(af, bf); \
-        z_mma<(q), RB, NAF>(acc, af, bf); \
-        if constexpr (NAF == 1 && (q) == 9) z_read_a<1, NAF>(af, ra); \
-        group_piece(ZQ(q)); } while (0)
-#else
 #define Z_GROUP(q) do { \
         group_piece(ZQ(q)); \
         if constexpr (NAF == 2 && (q) == 7) z_read_a<1, NAF>(af, ra); \
@@ -399,7 +356,6 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
         z_wait<(q), RB, Z_NWAIT(q), NAF>(af, bf); \
         z_mma<(q), RB, NAF>(acc, af, bf); \
         if constexpr (NAF == 1 && (q) == 9) z_read_a<1, NAF>(af, ra); } while (0)
-#endif
 #define ZQ(q) std::integral_constant<int, q>{}
 
 #ifdef SYN3R_TIMING         // tools/z_timing.py: s_memtime ticks per segment of the k-tile loop, summed per wavefront of one block
@@ -448,9 +404,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[17 % RB]), "+v"(bf[18 % RB]), "+v"(bf[19 % RB]));
             z_mma<17, RB, NAF>(acc, af, bf);
             ZSTAMP(2);
-#ifndef Z_EXP_NOVMWAIT      // timing experiment (wrong results): what the wait for the next stage's DMA costs
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             ZSTAMP(3);
             __builtin_amdgcn_s_barrier();
             ZSTAMP(4);
@@ -488,9 +442,6 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
         // through the k-loop in registers the accumulators do not leave.
         int le = lane;
         asm volatile("" : "+v"(le));
-#ifdef Z_EXP_NOEPI          // timing experiment (wrong results): no epilogue at all
-        if (p.M > 0) { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][3][4])); __builtin_amdgcn_s_barrier(); continue; }
-#endif
         char* const epi = smem_raw + (rslot ? 0 : W_STAGE);
         const int gm0 = m0 + wm * WM;
         if (p.geglu_D > 0) {
