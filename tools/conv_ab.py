@@ -1,5 +1,8 @@
 """3x3 / temporal convolutions of the UNet in isolation on the 160-column tile (SYN3R_CONV_Z=0) against the 256 x 320 tile
-(SYN3R_CONV_Z=1), one subprocess per setting (developer tool)."""
+(SYN3R_CONV_Z=1), one subprocess per setting (developer tool).
+NOTE (round 5): the library's dispatch switches (SYN3R_GEMM_Z, SYN3R_GEMM_WIDE, SYN3R_CONV_Z, SYN3R_Z_BAND, SYN3R_TCONV_ORDER, ...) are
+compiled in only with -DSYN3R_TUNING: build the variant first (`tools/build_variant.sh tune -DSYN3R_TUNING`) and point
+SYN3R_LIB_OVERRIDE at it; the shipped library ignores the environment."""
 import os, subprocess, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]

@@ -1,6 +1,9 @@
 """Per-shape comparison of the dense contraction kernels inside a real UNet unit (developer tool):
 python tools/gemm_ab.py [VAR [A [B]]]  -> runs the unit with VAR=A and VAR=B ("-" = unset) in two subprocesses;
-default: SYN3R_GEMM_WIDE=0 against unset."""
+default: SYN3R_GEMM_WIDE=0 against unset.
+NOTE (round 5): the library's dispatch switches (SYN3R_GEMM_Z, SYN3R_GEMM_WIDE, SYN3R_CONV_Z, SYN3R_Z_BAND, SYN3R_TCONV_ORDER, ...) are
+compiled in only with -DSYN3R_TUNING: build the variant first (`tools/build_variant.sh tune -DSYN3R_TUNING`) and point
+SYN3R_LIB_OVERRIDE at it; the shipped library ignores the environment."""
 import os, re, subprocess, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
