@@ -14,7 +14,7 @@ from __future__ import annotations
 import json
 from pathlib import Path
 from types import SimpleNamespace
-from typing import Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -48,20 +48,29 @@ def resize_with_antialiasing(x: torch.Tensor, size: Tuple[int, int]) -> torch.Te
     return Fn.interpolate(y, size=size, mode="bicubic", align_corners=True)
 
 
-def clip_pixel_values(image, mean: Sequence[float] = CLIP_MEAN, std: Sequence[float] = CLIP_STD) -> torch.Tensor:
-    """The reference's `_encode_image` preprocessing of one image (PIL, HWC numpy in [0, 255] or [0, 1], or a CHW / NCHW tensor
-    in [0, 1]) -> [1, 3, 224, 224] float32 CLIP input."""
+def clip_pixel_values(image, mean: Sequence[float] = CLIP_MEAN, std: Sequence[float] = CLIP_STD,
+                      value_range: Optional[float] = None) -> torch.Tensor:
+    """The reference's `_encode_image` preprocessing of one image -> [1, 3, 224, 224] float32 CLIP input.
+    PIL / uint8 HWC arrays are [0, 255] (VaeImageProcessor.pil_to_numpy); float HWC arrays and CHW / NCHW tensors are [0, 1]
+    unless `value_range` says otherwise (255.0 for a float image in [0, 255]: the range is an argument, never guessed from
+    the data - a dark [0, 255] image has no large value to guess from)."""
+    if value_range is not None and value_range not in (1.0, 255.0):
+        raise ValueError(f"value_range must be 1.0 or 255.0, got {value_range!r}")
     if isinstance(image, torch.Tensor):
         x = image.detach().float().cpu()
         if x.dim() == 3:
             x = x[None]
+        if value_range == 255.0:
+            x = x / 255.0
     else:
         a = np.asarray(image)
         if a.dtype == np.uint8:
+            if value_range == 1.0:
+                raise ValueError("a uint8 image is [0, 255]")
             a = a.astype(np.float32) / 255.0                      # VaeImageProcessor.pil_to_numpy
         else:
             a = a.astype(np.float32)
-            if a.max() > 1.5:
+            if value_range == 255.0:
                 a = a / 255.0
         x = torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1)[None]
     x = x * 2.0 - 1.0

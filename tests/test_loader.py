@@ -24,6 +24,17 @@ def test_clip_preprocessing_equals_reference(golden_dir):
         f = GI.clip_image(h, w).astype(np.float32) / 255.0
         np.testing.assert_allclose(clip_pixel_values(f).numpy(), px, atol=1e-6)
         np.testing.assert_allclose(clip_pixel_values(torch.from_numpy(f).permute(2, 0, 1)).numpy(), px, atol=1e-6)
+        # the range of a float image is an ARGUMENT (a dark [0, 255] float image has nothing to guess it from)
+        f255 = GI.clip_image(h, w).astype(np.float32)
+        np.testing.assert_allclose(clip_pixel_values(f255, value_range=255.0).numpy(), px, atol=1e-6)
+        dark = (f255 / 255.0).clip(0, 1.4)                     # all values <= 1.4: still read as [0, 255] when told so
+        np.testing.assert_allclose(clip_pixel_values(dark, value_range=255.0).numpy(),
+                                   clip_pixel_values(dark / 255.0).numpy(), atol=1e-6)
+    import pytest
+    with pytest.raises(ValueError):
+        clip_pixel_values(GI.clip_image(32, 32), value_range=1.0)
+    with pytest.raises(ValueError):
+        clip_pixel_values(GI.clip_image(32, 32), value_range=2.0)
 
 
 def test_loader_pieces_on_a_tiny_checkpoint(tmp_path):
