@@ -133,14 +133,41 @@ __global__ void __launch_bounds__(kThreads) k_activate_bwd(int N, const float* _
 // ---------------------------------------------------------------------------------------------
 // Photometric loss of the published 3DGS trainer, fused:  L = w * [(1 - lambda) * mean|I - G| + lambda * (1 - SSIM(I, G))]
 // with SSIM as published (11x11 Gaussian window, sigma 1.5, zero padding 5, C1 = 0.01^2, C2 = 0.03^2, mean over
-// all channels and pixels).  Forward: one pass over 16x16 tiles with a 5-pixel halo staged in LDS, separable
-// window (horizontal then vertical) on the five moments; it also stores the three per-pixel derivative maps
-// (d ssim / d mu1 [total], / d sigma1^2, / d sigma12) the backward needs.  Backward: the same separable window
-// on those three maps, combined with the L1 sign term, one write of the image gradient.
-constexpr int kWin = 11, kHalo = 5, kTile = 16, kReg = kTile + 2 * kHalo;   // 26
+// all channels and pixels).  Forward: one pass over 32x32 tiles, separable window (horizontal then vertical) on the five
+// moments; it also stores the three per-pixel derivative maps (d ssim / d mu1 [total], / d sigma1^2, / d sigma12) the
+// backward needs.  Backward: the same separable window on those three maps, combined with the L1 sign term, one write of
+// the image gradient.
+// Round 5 form (the 16x16-tile, one-output-per-thread kernels ran 96 + 67 us at 1080p, half of it vector issue): a thread
+// owns FOUR adjacent outputs in each pass - a row run in the horizontal pass, whose 14 inputs come straight from global
+// memory as aligned 16-byte loads (no staging tile, one barrier less), a column run in the vertical pass - so the inputs'
+// squares and products are formed once per input instead of once per tap, and the moments travel in pairs on packed fp32
+// FMAs: (mu1, mu2) and (E[p^2], E[q^2]) are one v_pk_fma_f32 per tap each, E[pq] a v_fma_f32 (3 instructions per tap and
+// output where the unpacked, uncontracted form issued 10).  The taps of an output are accumulated in ascending order.
+constexpr int kWin = 11, kHalo = 5, kTile = 32, kReg = kTile + 2 * kHalo;   // 42
+constexpr int kRun = 4, kSpan = kRun + kWin - 1;   // 4 outputs per thread and pass, 14 inputs
+constexpr int kLead = 8 - kHalo;                   // a row run is loaded from 8 columns left of its first output: 16-byte aligned
+constexpr int kPhotoItems = kReg * (kTile / kRun);   // 336 horizontal items per tile
+constexpr int kPhotoThreads = 256;                 // the vertical pass' 32 columns x 8 row runs (384 threads = one round of horizontal items: +17 % forward)
 struct SsimWindow { float g[kWin]; };
+// Tile of block b: blocks are dealt to the 8 XCDs round-robin, so XCD x takes the x-th contiguous eighth of the row-major tile list -
+// neighbouring tiles (which share 10 of 42 halo rows and 16 of 48 loaded columns) meet in one L2 instead of being fetched by two.
+struct PhotoTile { int c, x0, y0; unsigned id; };
+__device__ __forceinline__ PhotoTile photo_tile(int gx, int gy) {
+    const unsigned nblk = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8, k = bid / 8;
+    const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    PhotoTile o;
+    o.id = t;
+    o.c = (int)(t / (unsigned)(gx * gy));
+    const unsigned rem = t - (unsigned)o.c * (unsigned)(gx * gy);
+    o.y0 = (int)(rem / (unsigned)gx) * kTile;
+    o.x0 = (int)(rem % (unsigned)gx) * kTile;
+    return o;
+}
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-__device__ __forceinline__ float block_sum_256(float v, float* red) {
+__device__ __forceinline__ float block_sum_photo(float v, float* red) {
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -149,66 +176,130 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return t;
 }
 
-__global__ void __launch_bounds__(256) k_photo_fwd(const float* __restrict__ img, const float* __restrict__ gt, int H,
-                                                   int W, SsimWindow win, float* __restrict__ maps,
+// 20 consecutive values of image row y from column x (x % 4 == 0; zero outside the image).  vec: W % 4 == 0 and the plane is
+// 16-byte aligned, so a group of four is inside the image or outside it as a whole.
+__device__ __forceinline__ void photo_load20(float (&v)[20], const float* __restrict__ plane, int y, int x, int H, int W, bool vec) {
+    const bool row = y >= 0 && y < H;
+    const float* src = plane + (size_t)(row ? y : 0) * W;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int xq = x + 4 * q;
+        if (vec) {
+            const float4 t = (row && xq >= 0 && xq < W) ? *(const float4*)(src + xq) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = (row && xq + e >= 0 && xq + e < W) ? src[xq + e] : 0.0f;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kPhotoThreads) k_photo_fwd(const float* __restrict__ img, const float* __restrict__ gt, int H,
+                                                   int W, int C, SsimWindow win, int vec, float* __restrict__ maps,
                                                    float* __restrict__ partial) {
-    __shared__ float s1[kReg][kReg + 1], s2[kReg][kReg + 1];
-    __shared__ float hor[5][kReg][kTile];
-    __shared__ float red[4];
-    const int c = blockIdx.z, x0 = blockIdx.x * kTile, y0 = blockIdx.y * kTile;
+    __shared__ __attribute__((aligned(16))) f2 hA[kReg][kTile], hB[kReg][kTile];   // (mu1, mu2), (E[p^2], E[q^2]) after the horizontal pass
+    __shared__ __attribute__((aligned(16))) float hC[kReg][kTile];                 // E[pq]
+    __shared__ float red[kPhotoThreads / 64];
+    const PhotoTile tl_ = photo_tile((W + kTile - 1) / kTile, (H + kTile - 1) / kTile);
+    const int c = tl_.c, x0 = tl_.x0, y0 = tl_.y0;
     const size_t plane = (size_t)H * W;
     const float* a = img + c * plane;
     const float* b = gt + c * plane;
-    for (int i = threadIdx.x; i < kReg * kReg; i += 256) {
-        int ry = i / kReg, rx = i - ry * kReg;
-        int y = y0 + ry - kHalo, x = x0 + rx - kHalo;
-        bool in = y >= 0 && y < H && x >= 0 && x < W;
-        s1[ry][rx] = in ? a[(size_t)y * W + x] : 0.0f;
-        s2[ry][rx] = in ? b[(size_t)y * W + x] : 0.0f;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kReg * kTile; i += 256) {
-        int ry = i / kTile, tx = i - ry * kTile;
-        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    float l1_sum = 0.f;
+    // horizontal pass: item = (halo row, run of 4 columns)
+    for (int i = threadIdx.x; i < kPhotoItems; i += kPhotoThreads) {
+        const int ry = i / (kTile / kRun), tx = (i - ry * (kTile / kRun)) * kRun;
+        const int y = y0 + ry - kHalo;
+        float p[20], q[20];
+        photo_load20(p, a, y, x0 + tx - 8, H, W, vec != 0);
+        photo_load20(q, b, y, x0 + tx - 8, H, W, vec != 0);
+        f2 pq[kSpan], sq[kSpan];
+        float pr[kSpan];
+#pragma unroll
+        for (int t = 0; t < kSpan; ++t) {
+            pq[t] = (f2){p[kLead + t], q[kLead + t]};
+            sq[t] = pq[t] * pq[t];
+            pr[t] = pq[t].x * pq[t].y;
+        }
+        f2 mA[kRun], mB[kRun];
+        float mC[kRun];
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) { mA[j] = (f2){0.f, 0.f}; mB[j] = (f2){0.f, 0.f}; mC[j] = 0.f; }
 #pragma unroll
         for (int k = 0; k < kWin; ++k) {
-            float p = s1[ry][tx + k], q = s2[ry][tx + k], w = win.g[k];
-            m1 += w * p; m2 += w * q; e11 += w * p * p; e22 += w * q * q; e12 += w * p * q;
+            const f2 w2 = (f2){win.g[k], win.g[k]};
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) {
+                mA[j] = fma2(w2, pq[j + k], mA[j]);
+                mB[j] = fma2(w2, sq[j + k], mB[j]);
+                mC[j] = __builtin_fmaf(win.g[k], pr[j + k], mC[j]);
+            }
         }
-        hor[0][ry][tx] = m1; hor[1][ry][tx] = m2; hor[2][ry][tx] = e11; hor[3][ry][tx] = e22; hor[4][ry][tx] = e12;
+        *(float4*)&hA[ry][tx] = make_float4(mA[0].x, mA[0].y, mA[1].x, mA[1].y);
+        *(float4*)&hA[ry][tx + 2] = make_float4(mA[2].x, mA[2].y, mA[3].x, mA[3].y);
+        *(float4*)&hB[ry][tx] = make_float4(mB[0].x, mB[0].y, mB[1].x, mB[1].y);
+        *(float4*)&hB[ry][tx + 2] = make_float4(mB[2].x, mB[2].y, mB[3].x, mB[3].y);
+        *(float4*)&hC[ry][tx] = make_float4(mC[0], mC[1], mC[2], mC[3]);
+        if (ry >= kHalo && ry < kHalo + kTile && y < H) {      // an output row: its L1 terms (the run's own pixels are inputs kHalo .. kHalo + 3)
+#pragma unroll
+            for (int j = 0; j < kRun; ++j)
+                if (x0 + tx + j < W) l1_sum += fabsf(pq[kHalo + j].x - pq[kHalo + j].y);
+        }
     }
     __syncthreads();
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int x = x0 + tx, y = y0 + ty;
-    float ssim = 0.f, l1 = 0.f;
-    if (x < W && y < H) {
-        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    // vertical pass: thread = (column, run of 4 rows)
+    const int tx = threadIdx.x & (kTile - 1), ty = (threadIdx.x >> 5) * kRun;
+    const int x = x0 + tx;
+    f2 mA[kRun], mB[kRun];
+    float mC[kRun];
+    {
+        f2 vA[kSpan], vB[kSpan];
+        float vC[kSpan];
+#pragma unroll
+        for (int t = 0; t < kSpan; ++t) { vA[t] = hA[ty + t][tx]; vB[t] = hB[ty + t][tx]; vC[t] = hC[ty + t][tx]; }
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) { mA[j] = (f2){0.f, 0.f}; mB[j] = (f2){0.f, 0.f}; mC[j] = 0.f; }
 #pragma unroll
         for (int k = 0; k < kWin; ++k) {
-            float w = win.g[k];
-            mu1 += w * hor[0][ty + k][tx]; mu2 += w * hor[1][ty + k][tx]; e11 += w * hor[2][ty + k][tx];
-            e22 += w * hor[3][ty + k][tx]; e12 += w * hor[4][ty + k][tx];
+            const f2 w2 = (f2){win.g[k], win.g[k]};
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) {
+                mA[j] = fma2(w2, vA[j + k], mA[j]);
+                mB[j] = fma2(w2, vB[j + k], mB[j]);
+                mC[j] = __builtin_fmaf(win.g[k], vC[j + k], mC[j]);
+            }
         }
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-        const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-        const float sg1 = e11 - mu1s, sg2 = e22 - mu2s, sg12 = e12 - mu12;
-        const float A = 2.f * mu12 + C1, B = 2.f * sg12 + C2, Cc = mu1s + mu2s + C1, D = sg1 + sg2 + C2;
-        const float inv = 1.0f / (Cc * D);
-        ssim = A * B * inv;
-        // partial derivatives of the map value (gt is constant)
-        const float d_sg1 = -ssim / D;                 // d/d sigma1^2
-        const float d_sg12 = 2.f * A * inv;            // d/d sigma12
-        const float d_mu1 = (2.f * mu2 * B * Cc - 2.f * mu1 * A * B) * inv / Cc    // explicit
-                            - 2.f * mu1 * d_sg1 - mu2 * d_sg12;                      // through sigma1^2, sigma12
-        const size_t o = (size_t)c * plane + (size_t)y * W + x;
-        const size_t n = (size_t)gridDim.z * plane;
-        maps[o] = d_mu1; maps[n + o] = d_sg1; maps[2 * n + o] = d_sg12;
-        l1 = fabsf(s1[ty + kHalo][tx + kHalo] - s2[ty + kHalo][tx + kHalo]);
     }
-    const float ts = block_sum_256(ssim, red);
-    const float tl = block_sum_256(l1, red);
+    float ssim_sum = 0.f;
+    const size_t n = (size_t)C * plane;
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+        const int y = y0 + ty + j;
+        if (x < W && y < H) {
+            const float mu1 = mA[j].x, mu2 = mA[j].y, e11 = mB[j].x, e22 = mB[j].y, e12 = mC[j];
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+            const float sg1 = e11 - mu1s, sg2 = e22 - mu2s, sg12 = e12 - mu12;
+            const float A = 2.f * mu12 + C1, B = 2.f * sg12 + C2, Cc = mu1s + mu2s + C1, D = sg1 + sg2 + C2;
+            // Cc >= C1, D >= C2 - rounding: both positive and far from the denormals; v_rcp_f32 is a 1-ulp reciprocal
+            // (an IEEE division is ~10 instructions, three of them were a third of this pass)
+            const float invC = __builtin_amdgcn_rcpf(Cc), invD = __builtin_amdgcn_rcpf(D);
+            const float inv = invC * invD;
+            const float ssim = A * B * inv;
+            // partial derivatives of the map value (gt is constant)
+            const float d_sg1 = -ssim * invD;              // d/d sigma1^2
+            const float d_sg12 = 2.f * A * inv;            // d/d sigma12
+            const float d_mu1 = (2.f * mu2 * B * Cc - 2.f * mu1 * A * B) * inv * invC    // explicit
+                                - 2.f * mu1 * d_sg1 - mu2 * d_sg12;                      // through sigma1^2, sigma12
+            const size_t o = (size_t)c * plane + (size_t)y * W + x;
+            maps[o] = d_mu1; maps[n + o] = d_sg1; maps[2 * n + o] = d_sg12;
+            ssim_sum += ssim;
+        }
+    }
+    const float ts = block_sum_photo(ssim_sum, red);
+    const float tl = block_sum_photo(l1_sum, red);
     if (threadIdx.x == 0) {
-        const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const size_t bid = tl_.id;
         partial[2 * bid] = tl;
         partial[2 * bid + 1] = ts;
     }
@@ -231,50 +322,82 @@ __global__ void __launch_bounds__(256) k_photo_final(const float* __restrict__ p
     }
 }
 
-__global__ void __launch_bounds__(256) k_photo_bwd(const float* __restrict__ img, const float* __restrict__ gt, int H,
-                                                   int W, SsimWindow win, const float* __restrict__ maps, float c_l1,
+__global__ void __launch_bounds__(kPhotoThreads) k_photo_bwd(const float* __restrict__ img, const float* __restrict__ gt, int H,
+                                                   int W, int C, SsimWindow win, int vec, const float* __restrict__ maps, float c_l1,
                                                    float c_ssim, const float* __restrict__ go,
                                                    float* __restrict__ grad) {
-    __shared__ float sm[3][kReg][kReg + 1];
-    __shared__ float hor[3][kReg][kTile];
-    const int c = blockIdx.z, x0 = blockIdx.x * kTile, y0 = blockIdx.y * kTile;
-    const size_t plane = (size_t)H * W, n = (size_t)gridDim.z * plane;
+    __shared__ __attribute__((aligned(16))) f2 hA[kReg][kTile];      // windowed (d_mu1, d_sigma1^2) after the horizontal pass
+    __shared__ __attribute__((aligned(16))) float hC[kReg][kTile];   // windowed d_sigma12
+    const PhotoTile tl_ = photo_tile((W + kTile - 1) / kTile, (H + kTile - 1) / kTile);
+    const int c = tl_.c, x0 = tl_.x0, y0 = tl_.y0;
+    const size_t plane = (size_t)H * W, n = (size_t)C * plane;
     const float* m0 = maps + c * plane;
-    for (int i = threadIdx.x; i < kReg * kReg; i += 256) {
-        int ry = i / kReg, rx = i - ry * kReg;
-        int y = y0 + ry - kHalo, x = x0 + rx - kHalo;
-        bool in = y >= 0 && y < H && x >= 0 && x < W;
-        size_t o = (size_t)y * W + x;
-        sm[0][ry][rx] = in ? m0[o] : 0.0f;
-        sm[1][ry][rx] = in ? m0[n + o] : 0.0f;
-        sm[2][ry][rx] = in ? m0[2 * n + o] : 0.0f;
+    // the vertical pass' own pixels (column tx, rows ty .. ty + 3), requested before the horizontal pass
+    const int vtx = threadIdx.x & (kTile - 1), vty = (threadIdx.x >> 5) * kRun;
+    float pv[kRun], qv[kRun];
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+        const bool in = x0 + vtx < W && y0 + vty + j < H;
+        const size_t o = (size_t)c * plane + (size_t)(y0 + vty + j) * W + x0 + vtx;
+        pv[j] = in ? img[o] : 0.0f;
+        qv[j] = in ? gt[o] : 0.0f;
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kReg * kTile; i += 256) {
-        int ry = i / kTile, tx = i - ry * kTile;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = threadIdx.x; i < kPhotoItems; i += kPhotoThreads) {
+        const int ry = i / (kTile / kRun), tx = (i - ry * (kTile / kRun)) * kRun;
+        const int y = y0 + ry - kHalo;
+        float u0[20], u1[20], u2[20];
+        photo_load20(u0, m0, y, x0 + tx - 8, H, W, vec != 0);
+        photo_load20(u1, m0 + n, y, x0 + tx - 8, H, W, vec != 0);
+        photo_load20(u2, m0 + 2 * n, y, x0 + tx - 8, H, W, vec != 0);
+        f2 mA[kRun];
+        float mC[kRun];
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) { mA[j] = (f2){0.f, 0.f}; mC[j] = 0.f; }
 #pragma unroll
         for (int k = 0; k < kWin; ++k) {
-            float w = win.g[k];
-            a0 += w * sm[0][ry][tx + k]; a1 += w * sm[1][ry][tx + k]; a2 += w * sm[2][ry][tx + k];
+            const f2 w2 = (f2){win.g[k], win.g[k]};
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) {
+                mA[j] = fma2(w2, (f2){u0[kLead + j + k], u1[kLead + j + k]}, mA[j]);
+                mC[j] = __builtin_fmaf(win.g[k], u2[kLead + j + k], mC[j]);
+            }
         }
-        hor[0][ry][tx] = a0; hor[1][ry][tx] = a1; hor[2][ry][tx] = a2;
+        *(float4*)&hA[ry][tx] = make_float4(mA[0].x, mA[0].y, mA[1].x, mA[1].y);
+        *(float4*)&hA[ry][tx + 2] = make_float4(mA[2].x, mA[2].y, mA[3].x, mA[3].y);
+        *(float4*)&hC[ry][tx] = make_float4(mC[0], mC[1], mC[2], mC[3]);
     }
     __syncthreads();
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= W || y >= H) return;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    const int tx = vtx, ty = vty;
+    const int x = x0 + tx;
+    f2 gA[kRun];
+    float gC[kRun];
+    {
+        f2 vA[kSpan];
+        float vC[kSpan];
 #pragma unroll
-    for (int k = 0; k < kWin; ++k) {
-        float w = win.g[k];
-        g0 += w * hor[0][ty + k][tx]; g1 += w * hor[1][ty + k][tx]; g2 += w * hor[2][ty + k][tx];
+        for (int t = 0; t < kSpan; ++t) { vA[t] = hA[ty + t][tx]; vC[t] = hC[ty + t][tx]; }
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) { gA[j] = (f2){0.f, 0.f}; gC[j] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < kWin; ++k) {
+            const f2 w2 = (f2){win.g[k], win.g[k]};
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) {
+                gA[j] = fma2(w2, vA[j + k], gA[j]);
+                gC[j] = __builtin_fmaf(win.g[k], vC[j + k], gC[j]);
+            }
+        }
     }
-    const size_t o = (size_t)c * plane + (size_t)y * W + x;
-    const float p = img[o], q = gt[o], d = p - q;
     const float up = go ? *go : 1.0f;
-    const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-    grad[o] = up * (c_l1 * sgn - c_ssim * (g0 + 2.0f * p * g1 + q * g2));
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+        const int y = y0 + ty + j;
+        if (x >= W || y >= H) continue;
+        const size_t o = (size_t)c * plane + (size_t)y * W + x;
+        const float p = pv[j], q = qv[j], d = p - q;
+        const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+        grad[o] = up * (c_l1 * sgn - c_ssim * (gA[j].x + 2.0f * p * gA[j].y + q * gC[j]));
+    }
 }
 
 int l1_blocks(long long n) {
@@ -403,10 +526,13 @@ extern "C" int syn3r_photo_loss(const float* image, const float* target, int C, 
     const size_t n = (size_t)C * H * W;
     float* maps = (float*)ws;
     float* partial = maps + 3 * n;
-    const dim3 grid((W + kTile - 1) / kTile, (H + kTile - 1) / kTile, C);
-    SYN3R_LAUNCH(k_photo_fwd, grid, dim3(256), 0, stream, image, target, H, W, make_window(), maps, partial);
+    const long long tiles = (long long)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile) * C;
+    SYN3R_REQUIRE(tiles < (1ll << 31), "photo_loss: %lld tiles exceed the grid limit", tiles);
+    const dim3 grid((unsigned)tiles);
+    const int vec = W % 4 == 0 && (((uintptr_t)image | (uintptr_t)target) & 15) == 0;      // aligned 16-byte row runs
+    SYN3R_LAUNCH(k_photo_fwd, grid, dim3(kPhotoThreads), 0, stream, image, target, H, W, C, make_window(), vec, maps, partial);
     SYN3R_LAUNCH(k_photo_final, dim3(1), dim3(256), 0, stream, (const float*)partial,
-                 (long long)grid.x * grid.y * grid.z, 1.0 / (double)n, lambda_dssim, weight, loss3);
+                 (long long)grid.x, 1.0 / (double)n, lambda_dssim, weight, loss3);
     SYN3R_LAUNCH_CHECK("photo_loss launch");
     return SYN3R_OK;
 }
@@ -418,8 +544,11 @@ extern "C" int syn3r_photo_loss_backward(const float* image, const float* target
     SYN3R_REQUIRE(C > 0 && C <= 65535 && SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W), "photo_loss_backward: bad sizes");
     SYN3R_REQUIRE(image && target && ws && grad_image, "photo_loss_backward: null pointer");
     const double n = (double)C * H * W;
-    const dim3 grid((W + kTile - 1) / kTile, (H + kTile - 1) / kTile, C);
-    SYN3R_LAUNCH(k_photo_bwd, grid, dim3(256), 0, stream, image, target, H, W, make_window(), (const float*)ws,
+    const long long tiles = (long long)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile) * C;
+    SYN3R_REQUIRE(tiles < (1ll << 31), "photo_loss: %lld tiles exceed the grid limit", tiles);
+    const dim3 grid((unsigned)tiles);
+    const int vec = W % 4 == 0 && ((uintptr_t)ws & 15) == 0;
+    SYN3R_LAUNCH(k_photo_bwd, grid, dim3(kPhotoThreads), 0, stream, image, target, H, W, C, make_window(), vec, (const float*)ws,
                  (float)((double)weight * (1.0 - (double)lambda_dssim) / n), (float)((double)weight * (double)lambda_dssim / n),
                  grad_loss, grad_image);
     SYN3R_LAUNCH_CHECK("photo_loss_backward launch");

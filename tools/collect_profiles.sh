@@ -41,6 +41,7 @@ if [ -f "$OUT/fetch/p_counter_collection.csv" ] && [ -f "$OUT/write/p_counter_co
 fi
 # per-shape / per-kernel breakdowns of the same build (developer tools; failures here do not fail the collection)
 ( timeout -k 10 100 python3 "$R/tools/raster_breakdown.py" 2>/dev/null | grep -v amdgpu.ids > "$OUT/raster_breakdown.txt" ) || true
+( timeout -k 10 150 python3 "$R/tools/trainer_breakdown.py" 20 2>/dev/null | grep -v amdgpu.ids > "$OUT/trainer_breakdown.txt" ) || true
 ( timeout -k 10 200 python3 "$R/tools/merge_units.py" 25 2>/dev/null | grep -v amdgpu.ids > "$OUT/merge_units.txt" ) || true
 ( timeout -k 10 100 python3 "$R/tools/norm_bench.py" 2>/dev/null | grep -v amdgpu.ids > "$OUT/norm_bench.txt" ) || true
 ( timeout -k 10 100 python3 "$R/tools/lpips_bench.py" 2>/dev/null | grep -v amdgpu.ids > "$OUT/lpips_bench.txt" ) || true
