@@ -74,7 +74,7 @@ struct GemmParams {
     // Two-source A (k_gemm_widep only): columns [0, K1) of a row come from A (stride lda), columns [K1, K) from A2
     // (stride lda2) - the channel concatenation [A | A2] the up blocks' shortcut projection reads is never written.
     const __half* A2; long long lda2; int K1;     // A2 = null: one source
-    // k_ffn320 only: the residual operand is residual + res_add[row / res_add_rpv] (an fp16 tensor add, rounded as such)
+    // k_ffn320r only: the residual operand is residual + res_add[row / res_add_rpv] (an fp16 tensor add, rounded as such)
     const __half* res_add; int res_add_rpv;
     // VGG-style activation options of the GENERAL epilogue (gemm_epilogue; the convolution kernels use it):
     int band;                             // persistent 256 x 320 kernels: tile columns per band of the tile order (band_width())
