@@ -38,7 +38,7 @@ static_assert(sizeof(Splat) == 48, "Splat must be 48 bytes");
 
 // Geometry state carved from the caller's buffer (all arrays 256-byte aligned).
 struct GeomState {
-    unsigned* header;        // [0] = number of (Gaussian, tile) pairs, [1] = 1 if a render ran out of pair capacity
+    unsigned* header;        // [0] = number of (Gaussian, tile) pairs, [1] = 1 if a render ran out of pair capacity, [2] = entries of the super-tile lists
     float* depths;           // [N]
     float* means2D;          // [N,2]
     float* cov3D;            // [N,6]
@@ -57,10 +57,14 @@ struct GeomState {
     void* scan_scratch;
 };
 
+constexpr size_t kBinCounters = 65536;          // (chunk, super-tile) counters of the hierarchical binning
+constexpr size_t kMaxSuperSlots = 1024;         // ... followed by the super-tile list starts (at most 512 + 1)
 struct ImageState {
     uint2* ranges;           // [tiles] (start, end) into the sorted pair list
     unsigned* n_contrib;     // [H*W] index (1-based, within the tile list) of the last contributor
     float* final_T;          // [H*W]
+    unsigned* tile_counts;   // [tiles][4] list length per tile and quarter of its super-tile's list (hierarchical binning)
+    unsigned* bin_counters;  // [kBinCounters + kMaxSuperSlots] per (chunk, super-tile) counts, then the list starts
 };
 
 struct BinningState {

@@ -64,7 +64,7 @@ GeomState carve_geom(void* buf, int N) {
 size_t image_bytes(int H, int W) {
     size_t tiles = (size_t)((W + kTileX - 1) / kTileX) * ((H + kTileY - 1) / kTileY);
     size_t px = (size_t)H * W;
-    return align256(tiles * 8) + align256(px * 4) + align256(px * 4);
+    return align256(tiles * 8) + align256(px * 4) + align256(px * 4) + align256(tiles * 16) + align256((kBinCounters + kMaxSuperSlots) * 4);
 }
 
 ImageState carve_image(void* buf, int H, int W) {
@@ -74,7 +74,9 @@ ImageState carve_image(void* buf, int H, int W) {
     ImageState s;
     s.ranges = (uint2*)p; p += align256(tiles * 8);
     s.n_contrib = (unsigned*)p; p += align256(px * 4);
-    s.final_T = (float*)p;
+    s.final_T = (float*)p; p += align256(px * 4);
+    s.tile_counts = (unsigned*)p; p += align256(tiles * 16);
+    s.bin_counters = (unsigned*)p;
     return s;
 }
 
@@ -331,6 +333,387 @@ __global__ void __launch_bounds__(256) k_tile_ranges(long long P_cap, const unsi
     if (i == P - 1) ranges[cur].y = (unsigned)P;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Hierarchical binning (round 5): the per-tile lists WITHOUT a pair sort.
+// The published pipeline duplicates every Gaussian into (tile, depth) keys and sorts them; this build already emitted the pairs
+// in depth order and stably sorted them by tile id (two 7-bit passes over 2.6 M pairs: 130 of the 950 us of a 1080p iteration).
+// A stable sort of a depth-ordered list by tile id IS a per-tile filter of that list, so the lists are built by filtering -
+//   super-tiles of 8 x 8 tiles (128 x 128 pixels: 135 at 1080p);
+//   k_super_count / k_super_write   the depth-ordered Gaussians in chunks: per (super-tile, chunk) the number of Gaussians whose
+//                                   tile rectangle meets the super-tile (one LDS atomic per Gaussian and super-tile), scanned
+//                                   super-tile-major, then written in order (wave ballots give the rank inside a wavefront,
+//                                   an LDS table the wavefronts' order inside the chunk): per super-tile the ids in depth order
+//                                   + the rectangle clipped to the super-tile (4 x 4 bits);
+//   k_tile_count / k_tile_write     one WAVEFRONT per tile walks its super-tile's list (coalesced, 2 B per entry) and keeps the
+//                                   entries whose rectangle holds the tile: count, one single-block scan over the tiles
+//                                   (k_tile_offsets: ranges, pair count, overflow flag), write in order.
+// Same lists, entry for entry (tests/test_raster_gpu.py compares them with the oracle's sort); six launches instead of fifteen and
+// no pair ever moved twice.  Shapes it does not take (more than 512 super-tiles: images beyond ~4K) keep the sort.
+constexpr int kSuper = 8;                 // tiles per super-tile side
+constexpr int kBinThreads = 512;          // Gaussians per round of a binning block (391 blocks at 200 000: every CU has one)
+constexpr int kOffThreads = 1024;         // k_tile_offsets: one block
+constexpr int kMaxSuper = 512;
+
+// exclusive scan of one value per thread over a 1024-thread block (sort.hip's block_exclusive_scan, local to this file)
+__device__ __forceinline__ unsigned block_scan_1024(unsigned v, unsigned* smem /*[17]*/, unsigned& total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) smem[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+        const unsigned s0 = lane < 16 ? smem[lane] : 0u;
+        unsigned si = s0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const unsigned t = __shfl_up(si, o, 64);
+            if (lane >= o) si += t;
+        }
+        if (lane < 16) smem[lane] = si - s0;
+        if (lane == 15) smem[16] = si;
+    }
+    __syncthreads();
+    const unsigned res = incl - v + smem[wv];
+    total = smem[16];
+    __syncthreads();
+    return res;
+}
+
+struct BinPlan { int sgx, sgy, nsuper, rounds, nchunks; bool ok; };
+inline BinPlan bin_plan(int N, int gx, int gy) {
+    BinPlan b;
+    b.sgx = (gx + kSuper - 1) / kSuper; b.sgy = (gy + kSuper - 1) / kSuper;
+    b.nsuper = b.sgx * b.sgy;
+    b.ok = b.nsuper <= kMaxSuper;
+    const int max_chunks = b.ok ? (int)(kBinCounters / (size_t)b.nsuper) : 1;
+    const int units = (N + kBinThreads - 1) / kBinThreads;
+    b.rounds = (units + max_chunks - 1) / max_chunks;
+    if (b.rounds < 1) b.rounds = 1;
+    b.nchunks = (units + b.rounds - 1) / b.rounds;
+    return b;
+}
+
+// does this shape take the hierarchical binning?  (SYN3R_BIN_HIER=0 in tuning builds: the pair sort, for A/B runs)
+inline bool hier_binning(int N, int gx, int gy) {
+    static const int on = tune_env("SYN3R_BIN_HIER", 1);
+    return on != 0 && bin_plan(N, gx, gy).ok;
+}
+
+// the tile rectangle of the Gaussian at depth position i (empty for culled ones) and its super-tile rectangle
+struct BinRect { int x0, y0, x1, y1; unsigned id; };
+__device__ __forceinline__ BinRect bin_rect(int i, int N, const unsigned* __restrict__ order, const float* __restrict__ means2D,
+                                            const int* __restrict__ radii, int gx, int gy) {
+    BinRect r; r.x0 = r.y0 = r.x1 = r.y1 = 0; r.id = 0u;
+    if (i < N) {
+        r.id = order[i];
+        const int rad = radii[r.id];
+        if (rad > 0) tile_rect(means2D[2 * (size_t)r.id], means2D[2 * (size_t)r.id + 1], rad, gx, gy, r.x0, r.y0, r.x1, r.y1);
+    }
+    return r;
+}
+
+__global__ void __launch_bounds__(kBinThreads) k_super_count(int N, const unsigned* __restrict__ order,
+                                                             const float* __restrict__ means2D, const int* __restrict__ radii,
+                                                             int gx, int gy, int sgx, int nsuper, int rounds, int nchunks,
+                                                             unsigned* __restrict__ counters) {
+    __shared__ unsigned tot[kMaxSuper];
+    for (int s = threadIdx.x; s < nsuper; s += kBinThreads) tot[s] = 0u;
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        const int i = (blockIdx.x * rounds + r) * kBinThreads + threadIdx.x;
+        const BinRect q = bin_rect(i, N, order, means2D, radii, gx, gy);
+        if (q.x1 > q.x0 && q.y1 > q.y0) {
+            const int sx0 = q.x0 / kSuper, sx1 = (q.x1 + kSuper - 1) / kSuper, sy0 = q.y0 / kSuper, sy1 = (q.y1 + kSuper - 1) / kSuper;
+            for (int sy = sy0; sy < sy1; ++sy)
+                for (int sx = sx0; sx < sx1; ++sx) atomicAdd(&tot[sy * sgx + sx], 1u);
+        }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < nsuper; s += kBinThreads) counters[(size_t)blockIdx.x * nsuper + s] = tot[s];   // chunk-major: k_super_write reads it coalesced
+}
+
+// `soff` = exclusive scan of the counters (super-tile-major); writes, per super-tile and in depth order, the Gaussian id and
+// its tile rectangle clipped to the super-tile (x0 | x1 << 4 | y0 << 8 | y1 << 12, each 0..8).
+// A round's entries (about 1.5 per Gaussian) are first laid out in LDS in (super-tile, rank) order - the order of their global
+// positions - and then stored by all 1 024 threads: a wavefront that stored its own hits would issue two stores per ranked
+// super-tile with one or two lanes active (35 us of single-lane stores at 200 000 Gaussians).
+constexpr int kBinStage = 3072;           // staged entries per round; a round with more writes straight from the ranking loop
+__global__ void __launch_bounds__(kBinThreads) k_super_write(int N, const unsigned* __restrict__ order,
+                                                             const float* __restrict__ means2D, const int* __restrict__ radii,
+                                                             int gx, int gy, int sgx, int nsuper, int rounds, int nchunks,
+                                                             const unsigned* __restrict__ counters, unsigned* __restrict__ sstart,
+                                                             unsigned cap, unsigned* __restrict__ sid, unsigned short* __restrict__ srect,
+                                                             unsigned* __restrict__ header) {
+    constexpr int NW = kBinThreads / 64;
+    __shared__ unsigned run[kMaxSuper];            // next free position of (super-tile, this chunk)
+    __shared__ unsigned rbase[kMaxSuper];          // ... at the start of the round
+    __shared__ unsigned lstart[kMaxSuper];         // first staging slot of the super-tile's entries of the round
+    __shared__ unsigned cw[kMaxSuper * NW];        // per round: count of wavefront w, then its starting position
+    __shared__ unsigned long long touched[NW][kMaxSuper / 64];   // super-tiles with an entry from wavefront w this round
+    __shared__ unsigned short sxy[kMaxSuper];      // (sx | sy << 8) of a super-tile: no division in the ranking loop
+    __shared__ unsigned st_pos[kBinStage], st_src[kBinStage];   // staged entry: global position, owner thread | super-tile << 10
+    __shared__ unsigned q_id[kBinThreads];
+    __shared__ unsigned q_rect[kBinThreads];                    // the owner's tile rectangle: x0 | x1 << 8 | y0 << 16 | y1 << 24 (tile grids up to 255: else unstaged)
+    __shared__ unsigned s_total;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int nwords = (nsuper + 63) / 64;
+    const bool small_grid = gx <= 255 && gy <= 255;
+    // Where this chunk's entries of every super-tile start: the (chunk, super-tile) counts are not scanned by a launch of their own -
+    // every block sums the columns (4 partial sums per super-tile, coalesced over the super-tiles; the table is a few hundred KB
+    // of L2 reads per block), a wavefront scans the totals, block 0 publishes the list starts for the tile kernels.
+    {
+        const int PARTS = max(1, min(8, kBinThreads / nsuper));  // (super-tile, part) items: one per thread, one pass
+        unsigned* part_tot = st_pos;                             // [nsuper * PARTS] (the staging arrays are free here)
+        unsigned* part_pre = st_src;
+        const int per = (nchunks + PARTS - 1) / PARTS;
+        for (int w = threadIdx.x; w < nsuper * PARTS; w += kBinThreads) {
+            const int s_ = w % nsuper, part = w / nsuper;
+            const int c0 = part * per, c1 = min(nchunks, c0 + per);
+            unsigned tot = 0, pre = 0;
+            constexpr int UN = 32;
+            for (int cb = c0; cb < c1; cb += UN) {
+                unsigned c[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) c[u] = cb + u < c1 ? counters[(size_t)(cb + u) * nsuper + s_] : 0u;
+#pragma unroll
+                for (int u = 0; u < UN; ++u) { tot += c[u]; pre += cb + u < (int)blockIdx.x ? c[u] : 0u; }
+            }
+            part_tot[w] = tot; part_pre[w] = pre;
+        }
+        __syncthreads();
+        for (int s_ = threadIdx.x; s_ < nsuper; s_ += kBinThreads) {
+            unsigned tot = 0, pre = 0;
+            for (int k = 0; k < PARTS; ++k) { tot += part_tot[k * nsuper + s_]; pre += part_pre[k * nsuper + s_]; }
+            lstart[s_] = tot; rbase[s_] = pre;
+            sxy[s_] = (unsigned short)((s_ % sgx) | ((s_ / sgx) << 8));
+        }
+        __syncthreads();
+        if (wv == 0) {
+            constexpr int PER = kMaxSuper / 64;
+            unsigned c[PER], sum = 0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) { const int s_ = lane * PER + k; c[k] = s_ < nsuper ? lstart[s_] : 0u; sum += c[k]; }
+            unsigned incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            unsigned ex = incl - sum;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int s_ = lane * PER + k;
+                if (s_ < nsuper) {
+                    run[s_] = ex + rbase[s_];
+                    if (blockIdx.x == 0) sstart[s_] = ex;
+                }
+                ex += c[k];
+            }
+            if (blockIdx.x == 0 && lane == 63) { sstart[nsuper] = incl; header[2] = incl; }
+        }
+        __syncthreads();
+    }
+    auto clip = [](int x0, int x1, int y0, int y1, int sx, int sy) {
+        const int bx = sx * kSuper, by = sy * kSuper;
+        const int rx0 = max(x0 - bx, 0), rx1 = min(x1 - bx, kSuper), ry0 = max(y0 - by, 0), ry1 = min(y1 - by, kSuper);
+        return (unsigned short)(rx0 | (rx1 << 4) | (ry0 << 8) | (ry1 << 12));
+    };
+    for (int r = 0; r < rounds; ++r) {
+        for (int k = threadIdx.x; k < nsuper * NW; k += kBinThreads) cw[k] = 0u;
+        __syncthreads();
+        const int i = (blockIdx.x * rounds + r) * kBinThreads + threadIdx.x;
+        const BinRect q = bin_rect(i, N, order, means2D, radii, gx, gy);
+        const bool any = q.x1 > q.x0 && q.y1 > q.y0;
+        const int sx0 = q.x0 / kSuper, sx1 = (q.x1 + kSuper - 1) / kSuper, sy0 = q.y0 / kSuper, sy1 = (q.y1 + kSuper - 1) / kSuper;
+        const unsigned wx = any ? (unsigned)(sx1 - sx0) : 0u, wy = any ? (unsigned)(sy1 - sy0) : 0u;
+        q_id[threadIdx.x] = q.id;
+        q_rect[threadIdx.x] = (unsigned)q.x0 | ((unsigned)q.x1 << 8) | ((unsigned)q.y0 << 16) | ((unsigned)q.y1 << 24);
+        // a: every wavefront's count per super-tile (one LDS atomic per Gaussian and super-tile)
+        if (any)
+            for (int sy = sy0; sy < sy1; ++sy)
+                for (int sx = sx0; sx < sx1; ++sx) atomicAdd(&cw[(sy * sgx + sx) * NW + wv], 1u);
+        __syncthreads();
+        for (int w = 0; w < nwords; ++w) {                       // which super-tiles this wavefront has to rank
+            const int s_ = w * 64 + lane;
+            const unsigned long long m = __ballot(s_ < nsuper && cw[s_ * NW + wv] != 0u);
+            if (lane == 0) touched[wv][w] = m;
+        }
+        // b: wavefront order inside the round
+        for (int s_ = threadIdx.x; s_ < nsuper; s_ += kBinThreads) {
+            unsigned pos = run[s_];
+            rbase[s_] = pos;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const unsigned c = cw[s_ * NW + w]; cw[s_ * NW + w] = pos; pos += c; }
+            lstart[s_] = pos - run[s_];                          // the round's count, scanned below
+            run[s_] = pos;
+        }
+        __syncthreads();
+        if (wv == 0) {                                           // exclusive scan of the round's counts over the super-tiles
+            constexpr int PER = kMaxSuper / 64;
+            unsigned c[PER], sum = 0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) { const int s_ = lane * PER + k; c[k] = s_ < nsuper ? lstart[s_] : 0u; sum += c[k]; }
+            unsigned incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            unsigned ex = incl - sum;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) { const int s_ = lane * PER + k; if (s_ < nsuper) lstart[s_] = ex - rbase[s_]; ex += c[k]; }   // slot = lstart + position
+            if (lane == 63) s_total = incl;
+        }
+        __syncthreads();
+        const unsigned total = s_total;
+        const bool staged = small_grid && total <= (unsigned)kBinStage;   // block-uniform
+        // c: rank in lane (= depth) order inside the wavefront.  The loop runs once per super-tile the wavefront touches (~70 of
+        // 135 for 64 Gaussians in depth order) on every wavefront of the SIMD: it is kept to the test, the rank and two LDS stores;
+        // the clipped rectangle is formed by the flush below, one entry per thread.
+        for (int w = 0; w < nwords; ++w) {
+            unsigned long long todo = touched[wv][w];            // wave-uniform
+            while (todo) {
+                const int s_ = w * 64 + (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int sx = sxy[s_] & 255, sy = sxy[s_] >> 8;
+                const bool hit = (unsigned)(sx - sx0) < wx && (unsigned)(sy - sy0) < wy;
+                const unsigned long long m = __ballot(hit);
+                if (hit) {
+                    const unsigned o = cw[s_ * NW + wv] + (unsigned)__popcll(m & lt);
+                    if (staged) {
+                        const unsigned li = lstart[s_] + o;
+                        st_pos[li] = o; st_src[li] = threadIdx.x | ((unsigned)s_ << 10);
+                    } else if (o < cap) {
+                        sid[o] = q.id; srect[o] = clip(q.x0, q.x1, q.y0, q.y1, sx, sy);
+                    } else {
+                        header[1] = 1u;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (staged)
+            for (unsigned j = threadIdx.x; j < total; j += kBinThreads) {
+                const unsigned o = st_pos[j], src = st_src[j], t = src & 1023u, s_ = src >> 10;
+                if (o < cap) {
+                    const unsigned qr = q_rect[t];
+                    sid[o] = q_id[t];
+                    srect[o] = clip((int)(qr & 255u), (int)((qr >> 8) & 255u), (int)((qr >> 16) & 255u), (int)(qr >> 24), sxy[s_] & 255, sxy[s_] >> 8);
+                } else {
+                    header[1] = 1u;
+                }
+            }
+        __syncthreads();
+    }
+}
+
+// the list of super-tile s: [sstart[s], sstart[s + 1]) clipped to the capacity
+__device__ __forceinline__ void super_range(int s, const unsigned* __restrict__ sstart, unsigned cap, unsigned& b, unsigned& e) {
+    b = min(sstart[s], cap); e = min(sstart[s + 1], cap);
+}
+
+__device__ __forceinline__ bool rect_has(unsigned r, int rx, int ry) {
+    return rx >= (int)(r & 15u) && rx < (int)((r >> 4) & 15u) && ry >= (int)((r >> 8) & 15u) && ry < (int)(r >> 12);
+}
+
+constexpr int kBinUnroll = 8;
+// A block per tile, its four wavefronts a quarter of the super-tile's list each (the longest list sets the kernel's time: a
+// wavefront per tile left the tiles of the busiest super-tile walking ~8 000 entries while the rest of the chip had finished).
+__device__ __forceinline__ void tile_quarter(unsigned b, unsigned e, int q, unsigned& qb, unsigned& qe) {
+    const unsigned len = (e - b + 3u) / 4u;
+    qb = min(e, b + (unsigned)q * len); qe = min(e, qb + len);
+}
+
+__global__ void __launch_bounds__(256) k_tile_count(int gx, int tiles, int sgx, const unsigned* __restrict__ sstart, unsigned cap,
+                                                    const unsigned short* __restrict__ srect, unsigned* __restrict__ tcount) {
+    const int t = blockIdx.x, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx = t % gx, ty = t / gx;
+    unsigned b, e;
+    super_range((ty / kSuper) * sgx + tx / kSuper, sstart, cap, b, e);
+    tile_quarter(b, e, q, b, e);
+    const int rx = tx % kSuper, ry = ty % kSuper;
+    unsigned cnt = 0;
+    for (unsigned i0 = b; i0 < e; i0 += 64 * kBinUnroll) {       // kBinUnroll chunks of 64 entries requested before any is tested
+        unsigned short r[kBinUnroll];
+#pragma unroll
+        for (int u = 0; u < kBinUnroll; ++u) {
+            const unsigned i = i0 + u * 64 + lane;
+            r[u] = i < e ? srect[i] : (unsigned short)0;          // 0: an empty rectangle
+        }
+#pragma unroll
+        for (int u = 0; u < kBinUnroll; ++u) cnt += rect_has(r[u], rx, ry) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) tcount[4 * t + q] = cnt;
+}
+
+// ranges[t] = (start, end) of tile t's list, clipped to the capacity; header[0] = the pair count, header[1] = 1 if it (or the
+// super-tile lists) did not fit.  One block, any tile count.
+__global__ void __launch_bounds__(kOffThreads) k_tile_offsets(int tiles, const unsigned* __restrict__ tcount, unsigned cap,
+                                                              uint2* __restrict__ ranges, unsigned* __restrict__ header) {
+    __shared__ unsigned smem[17];
+    constexpr int PER = 8;                                       // consecutive tiles per thread: 8 192 tiles per round
+    unsigned carry = 0;
+    for (int start = 0; start < tiles; start += kOffThreads * PER) {
+        const int t0 = start + threadIdx.x * PER;
+        unsigned c[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            c[k] = 0u;
+            if (t0 + k < tiles) { const uint4 q4 = ((const uint4*)tcount)[t0 + k]; c[k] = (q4.x + q4.y) + (q4.z + q4.w); }
+            sum += c[k];
+        }
+        unsigned total;
+        unsigned ex = block_scan_1024(sum, smem, total) + carry;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            // an empty tile is (0, 0), as k_tile_ranges leaves it
+            if (t0 + k < tiles) ranges[t0 + k] = c[k] ? make_uint2(min(ex, cap), min(ex + c[k], cap)) : make_uint2(0u, 0u);
+            ex += c[k];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        header[0] = carry;
+        if (carry > cap || header[2] > cap) header[1] = 1u;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_tile_write(int gx, int tiles, int sgx, const unsigned* __restrict__ sstart, unsigned cap,
+                                                    const unsigned* __restrict__ sid, const unsigned short* __restrict__ srect,
+                                                    const uint2* __restrict__ ranges, const unsigned* __restrict__ tcount,
+                                                    unsigned* __restrict__ point_list) {
+    const int t = blockIdx.x, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx = t % gx, ty = t / gx;
+    unsigned b, e;
+    super_range((ty / kSuper) * sgx + tx / kSuper, sstart, cap, b, e);
+    tile_quarter(b, e, q, b, e);
+    const int rx = tx % kSuper, ry = ty % kSuper;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint4 q4 = ((const uint4*)tcount)[t];
+    unsigned pos = ranges[t].x + (q > 0 ? q4.x : 0u) + (q > 1 ? q4.y : 0u) + (q > 2 ? q4.z : 0u);
+    for (unsigned i0 = b; i0 < e; i0 += 64 * kBinUnroll) {       // wave-uniform trip count
+        unsigned short r[kBinUnroll];
+        unsigned id[kBinUnroll];
+#pragma unroll
+        for (int u = 0; u < kBinUnroll; ++u) {
+            const unsigned i = i0 + u * 64 + lane;
+            r[u] = i < e ? srect[i] : (unsigned short)0;
+            id[u] = i < e ? sid[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kBinUnroll; ++u) {
+            const bool hit = rect_has(r[u], rx, ry);
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const unsigned o = pos + (unsigned)__popcll(m & lt);
+                if (o < cap) point_list[o] = id[u];
+            }
+            pos += (unsigned)__popcll(m);
+        }
+    }
+}
+
 // contiguous-chunk-per-XCD remap of a 1-D block id (bijective for any block count)
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8, k = bid / 8;
@@ -529,8 +912,12 @@ extern "C" int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, cons
     rc = argsort_depth_u32(g.dkeys_a, g.order_a, g.dkeys_b, g.order_b, (size_t)N, g.sort_scratch, stream, &in_b);
     if (rc) return rc;
     if ((in_b ? g.order_b : g.order_a) != g.order) { set_error("raster_preprocess: unexpected argsort parity"); return SYN3R_E_INVALID; }
-    rc = exclusive_scan_u32(g.tiles_touched, g.point_offsets, (size_t)N, g.header, g.scan_scratch, stream, g.order);
-    if (rc) return rc;
+    // The hierarchical binning of syn3r_raster_render counts the pairs itself (k_tile_offsets); the scanned tile counts are needed
+    // by the pair-sort path and by a caller who asks for the exact count before sizing the binning buffer.
+    if (!hier_binning(N, cam.grid_x, cam.grid_y) || num_rendered_host) {
+        rc = exclusive_scan_u32(g.tiles_touched, g.point_offsets, (size_t)N, g.header, g.scan_scratch, stream, g.order);
+        if (rc) return rc;
+    }
     SYN3R_LAUNCH_CHECK("raster_preprocess launch");
     if (num_rendered_host) {
         unsigned total = 0;
@@ -568,7 +955,24 @@ extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const i
         if (rc) return rc;
     }
     unsigned* point_list = bn.vals_a;
-    if (P > 0) {
+    if (P > 0 && hier_binning(N, gx, gy)) {
+        const BinPlan bp = bin_plan(N, gx, gy);
+        unsigned* counters = im.bin_counters;
+        unsigned* sid = bn.vals_b;
+        unsigned short* srect = (unsigned short*)bn.keys_a;
+        unsigned* sstart = counters + kBinCounters;              // [nsuper + 1] list starts
+        SYN3R_LAUNCH(k_super_count, dim3(bp.nchunks), dim3(kBinThreads), 0, stream, N, g.order, g.means2D, radii, gx, gy, bp.sgx,
+                     bp.nsuper, bp.rounds, bp.nchunks, counters);
+        SYN3R_LAUNCH(k_super_write, dim3(bp.nchunks), dim3(kBinThreads), 0, stream, N, g.order, g.means2D, radii, gx, gy, bp.sgx,
+                     bp.nsuper, bp.rounds, bp.nchunks, (const unsigned*)counters, sstart, (unsigned)P, sid, srect, g.header);
+        SYN3R_LAUNCH(k_tile_count, dim3((unsigned)tiles), dim3(256), 0, stream, gx, (int)tiles, bp.sgx,
+                     (const unsigned*)sstart, (unsigned)P, (const unsigned short*)srect, im.tile_counts);
+        SYN3R_LAUNCH(k_tile_offsets, dim3(1), dim3(kOffThreads), 0, stream, (int)tiles, (const unsigned*)im.tile_counts, (unsigned)P,
+                     im.ranges, g.header);
+        SYN3R_LAUNCH(k_tile_write, dim3((unsigned)tiles), dim3(256), 0, stream, gx, (int)tiles, bp.sgx,
+                     (const unsigned*)sstart, (unsigned)P, (const unsigned*)sid, (const unsigned short*)srect,
+                     (const uint2*)im.ranges, (const unsigned*)im.tile_counts, point_list);
+    } else if (P > 0) {
         // P is the pair CAPACITY of the binning buffer; the live count is read from the geometry header on
         // the device, so the caller may pass an estimate and skip the device->host read of the exact count
         unsigned* tk_a = (unsigned*)bn.keys_a;

@@ -111,35 +111,36 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_final(const unsigned* __r
     }
 }
 
-// n <= kScanSmallMax (one sort pass's digit table when it is small): a single 1024-thread block, 16 consecutive
-// elements per thread with 16-byte loads and stores - one launch instead of three.
-constexpr int kSmallItems = 16;
-constexpr size_t kScanSmallMax = (size_t)kScanThreads * kSmallItems;
+// n <= kScanThreads * ITEMS (a sort pass's digit table, the rasteriser's binning counters): a single 1024-thread block, ITEMS
+// consecutive elements per thread with 16-byte loads and stores - one launch instead of three.
+constexpr int kSmallItems = 16, kMidItems = 64;
+constexpr size_t kScanSmallMax = (size_t)kScanThreads * kSmallItems, kScanMidMax = (size_t)kScanThreads * kMidItems;
+template <int ITEMS>
 __global__ void __launch_bounds__(kScanThreads) k_scan_small(const unsigned* __restrict__ in, size_t n,
                                                             unsigned* __restrict__ out,
                                                             unsigned* __restrict__ total_out) {
     __shared__ unsigned smem[17];
-    const size_t base = (size_t)threadIdx.x * kSmallItems;
-    unsigned v[kSmallItems];
+    const size_t base = (size_t)threadIdx.x * ITEMS;
+    unsigned v[ITEMS];
     unsigned s = 0;
-    const bool full = base + kSmallItems <= n;
+    const bool full = base + ITEMS <= n;
     if (full) {
         const uint4* src = (const uint4*)(in + base);
 #pragma unroll
-        for (int k = 0; k < kSmallItems / 4; ++k) {
+        for (int k = 0; k < ITEMS / 4; ++k) {
             uint4 q = src[k];
             v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < kSmallItems; ++k) v[k] = (base + k < n) ? in[base + k] : 0;
+        for (int k = 0; k < ITEMS; ++k) v[k] = (base + k < n) ? in[base + k] : 0;
     }
 #pragma unroll
-    for (int k = 0; k < kSmallItems; ++k) s += v[k];
+    for (int k = 0; k < ITEMS; ++k) s += v[k];
     unsigned total;
     unsigned ex = block_exclusive_scan(s, smem, total);
 #pragma unroll
-    for (int k = 0; k < kSmallItems; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         unsigned t = v[k];
         v[k] = ex;
         ex += t;
@@ -147,10 +148,10 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_small(const unsigned* __r
     if (full) {
         uint4* dst = (uint4*)(out + base);
 #pragma unroll
-        for (int k = 0; k < kSmallItems / 4; ++k) dst[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        for (int k = 0; k < ITEMS / 4; ++k) dst[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
     } else {
 #pragma unroll
-        for (int k = 0; k < kSmallItems; ++k)
+        for (int k = 0; k < ITEMS; ++k)
             if (base + k < n) out[base + k] = v[k];
     }
     if (threadIdx.x == 0 && total_out) *total_out = total;
@@ -168,8 +169,9 @@ int exclusive_scan_u32(const unsigned* in, unsigned* out, size_t n, unsigned* to
         if (total_out) return check_hip(hipMemsetAsync(total_out, 0, 4, stream), "memset");
         return SYN3R_OK;
     }
-    if (!perm && n <= kScanSmallMax && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0) {
-        SYN3R_LAUNCH(k_scan_small, dim3(1), dim3(kScanThreads), 0, stream, in, n, out, total_out);
+    if (!perm && n <= kScanMidMax && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0) {
+        if (n <= kScanSmallMax) SYN3R_LAUNCH(k_scan_small<kSmallItems>, dim3(1), dim3(kScanThreads), 0, stream, in, n, out, total_out);
+        else SYN3R_LAUNCH(k_scan_small<kMidItems>, dim3(1), dim3(kScanThreads), 0, stream, in, n, out, total_out);
         return SYN3R_OK;
     }
     size_t chunks = (n + kScanChunk - 1) / kScanChunk;
@@ -223,7 +225,8 @@ __global__ void __launch_bounds__(kSortThreads) k_hist(const K* __restrict__ key
 // FUSED (small sorts: at most kFusedMaxBlocks blocks, one thread per digit): `bases` is the RAW table of k_hist (block-major) -
 // every block forms its own bases from it (a row sum and a prefix per digit, then a block scan over the digits: the table is a
 // few hundred KB of L2 reads in total), so a pass needs no scan launch: the depth argsort of 200 000 Gaussians (49 blocks on
-// 256 CUs, launch-latency bound) is 8 launches instead of 12.  (Also counting the NEXT pass's digits while writing out - integer
+// 256 CUs, launch-latency bound) is 8 launches instead of 12.  (Blocks of 1 024 keys instead of 4 096 - four ranking rounds, 196
+// blocks - were measured too: 15 instead of 16 us per scatter launch whatever the prologue's unroll; not kept.)  (Also counting the NEXT pass's digits while writing out - integer
 // atomics into that pass's table, 5 launches - was built and measured: depth keys share their upper digits, so a pass's atomics
 // all land on a few dozen counters and serialise, 1.5 ms per iteration instead of 0.09.)
 template <typename K, int BITS, bool FUSED = false>
@@ -240,12 +243,13 @@ __global__ void __launch_bounds__(kSortThreads) k_scatter(const K* __restrict__ 
         __shared__ unsigned ssm[17];
         const unsigned* col = bases + threadIdx.x;        // block-major table: entry (block b, digit d) at b * BINS + d
         unsigned tot = 0, pre = 0;
-        for (unsigned b0 = 0; b0 < nblocks; b0 += 8) {
-            unsigned c[8];
+        constexpr int UN = 16;                             // loads in flight per thread: the loop is L2 latency, not bandwidth
+        for (unsigned b0 = 0; b0 < nblocks; b0 += UN) {
+            unsigned c[UN];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) c[u] = b0 + u < nblocks ? col[(size_t)(b0 + u) * BINS] : 0u;
+            for (int u = 0; u < UN; ++u) c[u] = b0 + u < nblocks ? col[(size_t)(b0 + u) * BINS] : 0u;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UN; ++u) {
                 pre += b0 + u < blockIdx.x ? c[u] : 0u;
                 tot += c[u];
             }

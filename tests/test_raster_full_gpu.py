@@ -88,15 +88,14 @@ def test_forward_and_backward_match_oracle_at_benchmark_size(mode, golden, gpu):
     print(f"200k/1080p {mode}: PSNR {psnr:.1f} dB, max |dRGB| {float(dc.max()):.2e}")
 
 
-def test_tile_lists_index_for_index_at_benchmark_size(golden, gpu):
-    """north_star: 'bit-exact on tile/sort indices'.  The oracle's float32 preprocess + stable sort of the published
-    (tile << 32 | depth bits) keys, run live, against the HIP binning at P ~ 2.6 M pairs.  A Gaussian whose 3-sigma radius
-    lands on an integer boundary may get a different ceil() from the two fp32 evaluation orders: those (a handful in
-    200 000) are removed from both lists, everything else must agree index for index."""
+def _check_tile_lists(gpu, N, H, W, bg=(0.1, 0.2, 0.3)):
+    """The oracle's float32 preprocess + stable sort of the published (tile << 32 | depth bits) keys, run live, against the
+    HIP binning.  A Gaussian whose 3-sigma radius lands on an integer boundary may get a different ceil() from the two fp32
+    evaluation orders: those (a handful in 200 000) are removed from both lists, everything else must agree index for
+    index."""
     from syn3r_amd.raster import _Rasterize
-    N, H, W = int(golden["N"]), int(golden["H"]), int(golden["W"])
     m, s, q, o, sh = RO.synthetic_gaussians(N, seed=1234, dtype=torch.float32)
-    (color, radii, depth, alpha), _, _ = _render(gpu, m, s, q, o, sh, H, W, tuple(golden["bg"]), False, True)
+    (color, radii, depth, alpha), _, _ = _render(gpu, m, s, q, o, sh, H, W, bg, False, True)
     dbg = _Rasterize.debug_state
     view, proj, campos, tfx, tfy = RO.look_at_camera(H, W, dtype=torch.float32)
     pre = RO.preprocess(m, s, q, o, sh, None, view, proj, campos, tfx, tfy, H, W, 3)
@@ -104,7 +103,7 @@ def test_tile_lists_index_for_index_at_benchmark_size(golden, gpu):
     valid = pre["valid"].numpy()
     hip_r = radii.cpu().numpy()
     odd = np.nonzero(hip_r != pre["radius"].numpy())[0]
-    assert len(odd) < 1e-4 * N, len(odd)
+    assert len(odd) < 1e-4 * N + 2, len(odd)
     # depths agree bit for bit on the Gaussians both sides render
     both = valid & (hip_r > 0)
     np.testing.assert_array_equal(dbg["depths"].cpu().numpy()[both], pre["depth"].numpy()[both])
@@ -124,7 +123,24 @@ def test_tile_lists_index_for_index_at_benchmark_size(golden, gpu):
         b_ids, b_tiles = per_tile(plist, ranges)
         np.testing.assert_array_equal(a_ids, b_ids)          # same Gaussians in the same order ...
         np.testing.assert_array_equal(a_tiles, b_tiles)      # ... in the same tiles
-    print(f"tile lists: P = {dbg['num_rendered']}, {len(odd)} Gaussians with a ceil() tie excluded")
+    print(f"tile lists {N} @ {W}x{H}: P = {dbg['num_rendered']}, {len(odd)} Gaussians with a ceil() tie excluded")
+
+
+def test_tile_lists_index_for_index_at_benchmark_size(golden, gpu):
+    """north_star: 'bit-exact on tile/sort indices' at P ~ 2.6 M pairs."""
+    _check_tile_lists(gpu, int(golden["N"]), int(golden["H"]), int(golden["W"]), tuple(golden["bg"]))
+
+
+@pytest.mark.parametrize("N,H,W,what", [
+    (300_000, 1080, 1920, "two rounds per binning block (more than 65 536 / 135 chunks of 512 Gaussians)"),
+    (60_000, 2160, 3840, "510 super-tiles: eight mask words per wavefront, one column part per thread"),
+    (20_000, 1152, 8192, "576 super-tiles: beyond the hierarchical binning, the pair sort takes it"),
+    (5_000, 100, 260, "ragged image: partial tiles and partial super-tiles on both edges"),
+])
+def test_tile_lists_other_binning_shapes(N, H, W, what, gpu):
+    """The hierarchical binning (csrc/raster_fwd.hip: super-tile lists, then a filter per tile) and its fallback at the shapes
+    that take its other branches; same oracle, same index-for-index bar."""
+    _check_tile_lists(gpu, N, H, W)
 
 
 def _edge_scene(kind, N, H, W):
