@@ -91,11 +91,11 @@ __global__ void __launch_bounds__(kBwdThreads) k_render_bwd(
     int H, int W, int gx, int gy, const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list,
     const Splat* __restrict__ splats, float bg0, float bg1, float bg2, const unsigned* __restrict__ n_contrib,
     const float* __restrict__ final_T, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-    const float* __restrict__ dL_dalpha_out, float* __restrict__ grad_rec) {
+    const float* __restrict__ dL_dalpha_out, float* __restrict__ grad_rec, const unsigned* __restrict__ tile_order) {
     __shared__ float4 sm[kBwdThreads * 3];
     __shared__ unsigned sid[kBwdThreads];
     __shared__ float sacc[kBwdThreads * kGradSlots];   // per-round gradient records: the 2 wavefronts meet here first
-    const unsigned tile = xcd_remap(blockIdx.x, (unsigned)(gx * gy));
+    const unsigned tile = tile_order ? tile_order[blockIdx.x] : xcd_remap(blockIdx.x, (unsigned)(gx * gy));
     const int tx = tile % gx, ty = tile / gx;
     const int wq = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lx = lane & 15, ly = wq * 8 + (lane >> 4);
@@ -493,7 +493,7 @@ extern "C" int syn3r_raster_backward(int N, int sh_degree, int sh_coeffs, long l
     if (P > 0)
         SYN3R_LAUNCH(k_render_bwd, dim3(tiles), dim3(kBwdThreads), 0, stream, H, W, cam.grid_x, cam.grid_y, im.ranges,
                            point_list, g.splats, bg[0], bg[1], bg[2], im.n_contrib, im.final_T, dL_dcolor, dL_ddepth,
-                           dL_dalpha, grad_rec);
+                           dL_dalpha, grad_rec, (const unsigned*)(raster_tiles_ordered(N, cam.grid_x, cam.grid_y) ? im.tile_order : nullptr));
     SYN3R_LAUNCH(k_preprocess_bwd, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
                        scales, rotations, opacities, shs, confidence, scale_modifier, cam, radii, g, grad_rec,
                        dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacities, dL_dshs, dL_dmeans2D, dL_dconfidence);

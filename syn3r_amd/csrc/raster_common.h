@@ -65,6 +65,7 @@ struct ImageState {
     float* final_T;          // [H*W]
     unsigned* tile_counts;   // [tiles][4] list length per tile and quarter of its super-tile's list (hierarchical binning)
     unsigned* bin_counters;  // [kBinCounters + kMaxSuperSlots] per (chunk, super-tile) counts, then the list starts
+    unsigned* tile_order;    // [tiles] tiles by descending list length
 };
 
 struct BinningState {
@@ -92,6 +93,7 @@ int radix_sort_pairs(unsigned long long* keys_a, unsigned* vals_a, unsigned long
                      const unsigned* n_dev = nullptr);
 
 size_t geom_bytes(int N);
+bool raster_tiles_ordered(int N, int gx, int gy);   // did syn3r_raster_render leave ImageState::tile_order for this shape?
 size_t image_bytes(int H, int W);
 size_t binning_bytes(long long P);
 GeomState carve_geom(void* buf, int N);
