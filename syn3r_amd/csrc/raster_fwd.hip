@@ -7,11 +7,11 @@
 // raster_common.h.  PARITY UNPINNED against the CUDA build; pinned against
 // oracle/raster_oracle.py.
 //
-// MI355X mapping: one 16x16 tile = one 256-thread workgroup = 4 wavefronts, a
-// wavefront covers an 8 x 8 quadrant.  Sorted splats are staged through LDS in
-// batches of 256 as 48-byte records (3 x 16-byte loads per lane, broadcast reads
-// in the blend loop).  Tiles are dealt to XCDs in contiguous chunks so that
-// neighbouring tiles (which share splats) hit the same L2.
+// MI355X mapping: one 16x16 tile = one 128-thread workgroup = 2 wavefronts, a wavefront covers a 16 x 8 half with two
+// pixels per lane on packed fp32 arithmetic (k_render below).  Sorted splats are staged through LDS in batches as 48-byte
+// records (3 x 16-byte loads per lane, broadcast reads in the blend loop).  The per-tile lists come from a hierarchical
+// filter of the depth-ordered Gaussians, not from a pair sort, and the blend kernels take the tiles longest list first
+// ("Hierarchical binning" below).
 #include "common.h"
 #include "raster_common.h"
 
@@ -680,7 +680,18 @@ __global__ void __launch_bounds__(kOffThreads) k_tile_offsets(int tiles, const u
     }
     if (tile_order) {        // tiles by descending list length (buckets of 32 entries): the blend kernels take the long ones first
         __syncthreads();
-        if (threadIdx.x == 0) { unsigned run = 0; for (int k = 0; k < 256; ++k) { const unsigned c = bh[k]; bh[k] = run; run += c; } }
+        if (threadIdx.x < 64) {                                   // exclusive scan of the 256 bucket counts: 4 per lane
+            const int l = threadIdx.x;
+            unsigned c[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { c[k] = bh[4 * l + k]; sum += c[k]; }
+            unsigned incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (l >= o) incl += t; }
+            unsigned ex = incl - sum;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { bh[4 * l + k] = ex; ex += c[k]; }
+        }
         __syncthreads();
         for (int t = threadIdx.x; t < tiles; t += kOffThreads) {
             const uint4 q4 = ((const uint4*)tcount)[t];

@@ -547,7 +547,7 @@ int unet_create_impl(const char* weights_dir, const char* variant, syn3r_unet** 
     size_t off = 0;
     for (auto& hp : packs) {
         rc = check_hip(hipMemcpy(m->blob + off, hp.d.data(), hp.d.size() * 2, hipMemcpyHostToDevice), "hipMemcpy(unet weights)");
-        if (rc) { hipFree(m->blob); return rc; }
+        if (rc) { (void)hipFree(m->blob); return rc; }
         m->w[hp.name] = Wt{(__half*)(m->blob + off), hp.rows, hp.cols};
         off += (hp.d.size() * 2 + 255) / 256 * 256;
     }
@@ -569,10 +569,10 @@ extern "C" int syn3r_unet_destroy(syn3r_unet* m) {
         if (!unet_registry().erase(m)) { set_error("unet_destroy: not a live handle"); return SYN3R_E_INVALID; }
     }
     for (auto& kv : m->pos_cache) {
-        if (kv.second.ready) hipEventDestroy(kv.second.ready);
-        hipFree(kv.second.p);
+        if (kv.second.ready) (void)hipEventDestroy(kv.second.ready);
+        (void)hipFree(kv.second.p);
     }
-    if (m->blob) hipFree(m->blob);
+    if (m->blob) (void)hipFree(m->blob);
     delete m;
     return SYN3R_OK;
 }
@@ -884,10 +884,10 @@ struct Run {
                 syn3r_unet::PosEmb pe;
                 pe.p = keep; pe.stream = stream;
                 if (hipEventCreateWithFlags(&pe.ready, hipEventDisableTiming) == hipSuccess) {
-                    if (hipEventRecord(pe.ready, stream) != hipSuccess) { hipEventDestroy(pe.ready); pe.ready = nullptr; }
+                    if (hipEventRecord(pe.ready, stream) != hipSuccess) { (void)hipEventDestroy(pe.ready); pe.ready = nullptr; }
                 } else pe.ready = nullptr;
                 m.pos_cache[key] = pe;
-            } else if (keep) { hipFree(keep); keep = nullptr; }
+            } else if (keep) { (void)hipFree(keep); keep = nullptr; }
         }
         drop(e2);
         return keep;
