@@ -88,13 +88,14 @@ def test_forward_and_backward_match_oracle_at_benchmark_size(mode, golden, gpu):
     print(f"200k/1080p {mode}: PSNR {psnr:.1f} dB, max |dRGB| {float(dc.max()):.2e}")
 
 
-def _check_tile_lists(gpu, N, H, W, bg=(0.1, 0.2, 0.3)):
+def _check_tile_lists(gpu, N, H, W, bg=(0.1, 0.2, 0.3), scale_mult=1.0):
     """The oracle's float32 preprocess + stable sort of the published (tile << 32 | depth bits) keys, run live, against the
     HIP binning.  A Gaussian whose 3-sigma radius lands on an integer boundary may get a different ceil() from the two fp32
     evaluation orders: those (a handful in 200 000) are removed from both lists, everything else must agree index for
     index."""
     from syn3r_amd.raster import _Rasterize
     m, s, q, o, sh = RO.synthetic_gaussians(N, seed=1234, dtype=torch.float32)
+    s = s * scale_mult
     (color, radii, depth, alpha), _, _ = _render(gpu, m, s, q, o, sh, H, W, bg, False, True)
     dbg = _Rasterize.debug_state
     view, proj, campos, tfx, tfy = RO.look_at_camera(H, W, dtype=torch.float32)
@@ -131,16 +132,17 @@ def test_tile_lists_index_for_index_at_benchmark_size(golden, gpu):
     _check_tile_lists(gpu, int(golden["N"]), int(golden["H"]), int(golden["W"]), tuple(golden["bg"]))
 
 
-@pytest.mark.parametrize("N,H,W,what", [
-    (300_000, 1080, 1920, "two rounds per binning block (more than 65 536 / 135 chunks of 512 Gaussians)"),
-    (60_000, 2160, 3840, "510 super-tiles: eight mask words per wavefront, one column part per thread"),
-    (20_000, 1152, 8192, "576 super-tiles: beyond the hierarchical binning, the pair sort takes it"),
-    (5_000, 100, 260, "ragged image: partial tiles and partial super-tiles on both edges"),
+@pytest.mark.parametrize("N,H,W,scale,what", [
+    (300_000, 1080, 1920, 1.0, "two rounds per binning block (more than 65 536 / 135 chunks of 512 Gaussians)"),
+    (60_000, 2160, 3840, 1.0, "510 super-tiles: eight mask words per wavefront, one column part per thread"),
+    (20_000, 1152, 8192, 1.0, "576 super-tiles: beyond the hierarchical binning, the pair sort takes it"),
+    (5_000, 100, 260, 1.0, "ragged image: partial tiles and partial super-tiles on both edges"),
+    (4_000, 1080, 1920, 10.0, "large footprints: more list entries per block round than the LDS staging holds, written from the ranking loop"),
 ])
-def test_tile_lists_other_binning_shapes(N, H, W, what, gpu):
+def test_tile_lists_other_binning_shapes(N, H, W, scale, what, gpu):
     """The hierarchical binning (csrc/raster_fwd.hip: super-tile lists, then a filter per tile) and its fallback at the shapes
     that take its other branches; same oracle, same index-for-index bar."""
-    _check_tile_lists(gpu, N, H, W)
+    _check_tile_lists(gpu, N, H, W, scale_mult=scale)
 
 
 def _edge_scene(kind, N, H, W):
