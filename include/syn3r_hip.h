@@ -216,8 +216,9 @@ size_t syn3r_raster_image_bytes(int H, int W);
 size_t syn3r_raster_binning_bytes(long long P);
 
 /*
- * Stage 1: project every Gaussian, count the tiles it touches, argsort the
- * Gaussians by depth.  radii [N] i32 out.  If num_rendered_host != NULL the
+ * Stage 1: project every Gaussian and count the tiles it touches (shapes that
+ * take stage 2's pair-sort path also argsort the Gaussians by depth here).
+ * radii [N] i32 out.  If num_rendered_host != NULL the
  * number of (Gaussian, tile) pairs P is summed, copied to it and the stream is
  * synchronised (the reference implementation performs the same device->host
  * read to size its binning buffers); with NULL nothing synchronises and stage 2
@@ -233,9 +234,10 @@ int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, const float* me
 /*
  * Stage 2: the per-tile lists of Gaussians in depth order - entry for entry the
  * result of the published "duplicate (tile<<32 | depth) keys, sort, find tile
- * ranges", built here by filtering the depth-ordered Gaussians through 8x8-tile
- * super-tiles and then per tile (csrc/raster_fwd.hip; images with more than 512
- * super-tiles take a pair sort) - then the blend.  P is the pair CAPACITY of
+ * ranges", built here by filtering the Gaussians through super-tiles of 4x4 or
+ * 8x8 tiles (whose short lists are sorted by (depth bits, index) in LDS) and then
+ * per tile (csrc/raster_fwd.hip; images with more than 512 super-tiles take the
+ * argsort + pair sort) - then the blend.  P is the pair CAPACITY of
  * `binning` (an estimate is fine: a list that does not fit sets the overflow
  * flag in the geometry header and is truncated, never written past the buffer).
  * bg host [3].  out_color [3,H,W], out_depth [1,H,W] (sum of alpha*T*z),

@@ -7,6 +7,7 @@
 #include <stddef.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/syn3r_hip.h"
 
 namespace syn3r {
@@ -18,6 +19,20 @@ inline int check_hip(hipError_t e, const char* what) {
         set_error("%s: %s", what, hipGetErrorString(e));
         return SYN3R_E_HIP;
     }
+    return SYN3R_OK;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: remembered per (kernel, device), so a host that
+// drives several GPUs from one process gets the large-LDS attribute on each of them.
+struct DevOnce { std::atomic<unsigned long long> done{0}; };
+inline int set_max_lds(DevOnce& once, const void* fn, int bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;       // devices beyond 63: set on every launch
+    if (bit && (once.done.load(std::memory_order_acquire) & bit)) return SYN3R_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return check_hip(e, what);
+    once.done.fetch_or(bit, std::memory_order_release);
     return SYN3R_OK;
 }
 

@@ -2,19 +2,7 @@
 // Included by gemm.hip inside its anonymous namespace (one translation unit; the kernels share GemmParams, the epilogues and the
 // LDS-DMA typedefs of gemm_common.h / gemm_dma.h).
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: remembered per (kernel, device), so a host that
-// drives several GPUs from one process gets the 160 KB LDS attribute on each of them.
-struct DevOnce { std::atomic<unsigned long long> done{0}; };
-inline int set_max_lds(DevOnce& once, const void* fn, int bytes, const char* what) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;       // devices beyond 63: set on every launch
-    if (bit && (once.done.load(std::memory_order_acquire) & bit)) return SYN3R_OK;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return check_hip(e, what);
-    once.done.fetch_or(bit, std::memory_order_release);
-    return SYN3R_OK;
-}
+// (DevOnce / set_max_lds - the per-device MaxDynamicSharedMemorySize attribute - live in common.h)
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));

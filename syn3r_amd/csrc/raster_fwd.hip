@@ -335,23 +335,27 @@ __global__ void __launch_bounds__(256) k_tile_ranges(long long P_cap, const unsi
 }
 
 // ---------------------------------------------------------------------------------------------
-// Hierarchical binning (round 5): the per-tile lists WITHOUT a pair sort.
-// The published pipeline duplicates every Gaussian into (tile, depth) keys and sorts them; this build already emitted the pairs
-// in depth order and stably sorted them by tile id (two 7-bit passes over 2.6 M pairs: 130 of the 950 us of a 1080p iteration).
-// A stable sort of a depth-ordered list by tile id IS a per-tile filter of that list, so the lists are built by filtering -
-//   super-tiles of 8 x 8 tiles (128 x 128 pixels: 135 at 1080p);
-//   k_super_count / k_super_write   the depth-ordered Gaussians in chunks: per (super-tile, chunk) the number of Gaussians whose
-//                                   tile rectangle meets the super-tile (one LDS atomic per Gaussian and super-tile), scanned
-//                                   super-tile-major, then written in order (wave ballots give the rank inside a wavefront,
-//                                   an LDS table the wavefronts' order inside the chunk): per super-tile the ids in depth order
-//                                   + the rectangle clipped to the super-tile (4 x 4 bits);
-//   k_tile_count / k_tile_write     one WAVEFRONT per tile walks its super-tile's list (coalesced, 2 B per entry) and keeps the
-//                                   entries whose rectangle holds the tile: count, one single-block scan over the tiles
-//                                   (k_tile_offsets: ranges, pair count, overflow flag), write in order.
-// Same lists, entry for entry (tests/test_raster_gpu.py compares them with the oracle's sort); six launches instead of fifteen and
-// no pair ever moved twice.  Shapes it does not take (more than 512 super-tiles: images beyond ~4K) keep the sort.
-constexpr int kSuper = 8;                 // tiles per super-tile side
-constexpr int kBinThreads = 512;          // Gaussians per round of a binning block (391 blocks at 200 000: every CU has one)
+// Hierarchical binning (round 5): the per-tile lists WITHOUT a pair sort and WITHOUT a global depth sort.
+// The published pipeline duplicates every Gaussian into (tile, depth) keys and sorts them; rounds 1-4 of this build argsorted the
+// Gaussians by depth (4 passes, 12 launches of 49 blocks: launch latency), emitted the pairs in that order and stably sorted them by
+// tile id (two 7-bit passes over 2.6 M pairs) - 260 of the 950 us of a 1080p iteration.  A tile's list is the set of Gaussians whose
+// tile rectangle holds the tile, ordered by (depth bits, index); so the lists are built by filtering and ordered where they are short:
+//   super-tiles of 4 x 4 tiles (510 at 1080p; 8 x 8 where that would be more than 512: up to ~4K);
+//   k_super_count / k_super_append  the Gaussians in chunks (index order): per (chunk, super-tile) the number of Gaussians whose
+//                                   rectangle meets the super-tile (one LDS atomic each); every append block sums the count table's
+//                                   columns itself (no scan launch) and appends its (depth bits << 32 | index) keys to the
+//                                   super-tiles' lists, unordered inside the chunk;
+//   k_super_sort                    a block per super-tile sorts its list (1 015 keys on average, 3 201 at most at 200 000 Gaussians)
+//                                   in LDS - a bitonic network on 8-byte keys; longer lists are sorted in LDS-sized pieces and merged
+//                                   through global memory - and leaves, in order, the ids and the rectangles clipped to the
+//                                   super-tile (4 x 4 bits);
+//   k_tile_count / k_tile_write     a block per tile (four wavefronts, a quarter of the super-tile's list each, coalesced, 2 B per
+//                                   entry) keeps the entries whose rectangle holds the tile: count, one single-block scan over the
+//                                   tiles (k_tile_offsets: ranges, pair count, overflow flag, the blend kernels' tile order), write.
+// Same lists as the (tile << 32 | depth) key sort, entry for entry - equal depths in index order, as a stable sort leaves them
+// (tests/test_raster_gpu.py, test_raster_full_gpu.py against the oracle's sort); seven launches where there were twenty-seven.
+// Shapes it does not take (more than 512 super-tiles: images beyond ~4K) keep the argsort and the pair sort.
+constexpr int kBinThreads = 512;          // Gaussians per round of a binning block
 constexpr int kOffThreads = 1024;         // k_tile_offsets: one block
 constexpr int kMaxSuper = 512;
 
@@ -384,11 +388,19 @@ __device__ __forceinline__ unsigned block_scan_1024(unsigned v, unsigned* smem /
     return res;
 }
 
-struct BinPlan { int sgx, sgy, nsuper, rounds, nchunks; bool ok; };
+// Super-tiles of 4 x 4 tiles where that gives at most 512 of them (up to ~1080p: short lists, a block per list sorts ~600 keys),
+// else 8 x 8 (up to ~4K); `ss` = log2 of the side.  The Gaussians go through the count / append kernels in chunks of
+// rounds x 512, as many chunks as keep the (chunk, super-tile) count table within kBinCounters.
+struct BinPlan { int ss, sgx, sgy, nsuper, rounds, nchunks; bool ok; };
 inline BinPlan bin_plan(int N, int gx, int gy) {
     BinPlan b;
-    b.sgx = (gx + kSuper - 1) / kSuper; b.sgy = (gy + kSuper - 1) / kSuper;
-    b.nsuper = b.sgx * b.sgy;
+    for (b.ss = 2; b.ss <= 3; ++b.ss) {
+        const int side = 1 << b.ss;
+        b.sgx = (gx + side - 1) / side; b.sgy = (gy + side - 1) / side;
+        b.nsuper = b.sgx * b.sgy;
+        if (b.nsuper <= kMaxSuper) break;
+    }
+    if (b.ss > 3) b.ss = 3;
     b.ok = b.nsuper <= kMaxSuper;
     const int max_chunks = b.ok ? (int)(kBinCounters / (size_t)b.nsuper) : 1;
     const int units = (N + kBinThreads - 1) / kBinThreads;
@@ -404,73 +416,56 @@ inline bool hier_binning(int N, int gx, int gy) {
     return on != 0 && bin_plan(N, gx, gy).ok;
 }
 
-// the tile rectangle of the Gaussian at depth position i (empty for culled ones) and its super-tile rectangle
-struct BinRect { int x0, y0, x1, y1; unsigned id; };
-__device__ __forceinline__ BinRect bin_rect(int i, int N, const unsigned* __restrict__ order, const float* __restrict__ means2D,
-                                            const int* __restrict__ radii, int gx, int gy) {
-    BinRect r; r.x0 = r.y0 = r.x1 = r.y1 = 0; r.id = 0u;
+// the tile rectangle of Gaussian i (empty for culled ones)
+struct BinRect { int x0, y0, x1, y1; };
+__device__ __forceinline__ BinRect bin_rect(int i, int N, const float* __restrict__ means2D, const int* __restrict__ radii, int gx, int gy) {
+    BinRect r; r.x0 = r.y0 = r.x1 = r.y1 = 0;
     if (i < N) {
-        r.id = order[i];
-        const int rad = radii[r.id];
-        if (rad > 0) tile_rect(means2D[2 * (size_t)r.id], means2D[2 * (size_t)r.id + 1], rad, gx, gy, r.x0, r.y0, r.x1, r.y1);
+        const int rad = radii[i];
+        if (rad > 0) tile_rect(means2D[2 * (size_t)i], means2D[2 * (size_t)i + 1], rad, gx, gy, r.x0, r.y0, r.x1, r.y1);
     }
     return r;
 }
+__device__ __forceinline__ unsigned short clip_rect(const BinRect& q, int sx, int sy, int ss) {   // x0 | x1 << 4 | y0 << 8 | y1 << 12, each 0..8
+    const int bx = sx << ss, by = sy << ss, side = 1 << ss;
+    const int rx0 = max(q.x0 - bx, 0), rx1 = min(q.x1 - bx, side), ry0 = max(q.y0 - by, 0), ry1 = min(q.y1 - by, side);
+    return (unsigned short)(rx0 | (rx1 << 4) | (ry0 << 8) | (ry1 << 12));
+}
 
-__global__ void __launch_bounds__(kBinThreads) k_super_count(int N, const unsigned* __restrict__ order,
-                                                             const float* __restrict__ means2D, const int* __restrict__ radii,
-                                                             int gx, int gy, int sgx, int nsuper, int rounds, int nchunks,
+__global__ void __launch_bounds__(kBinThreads) k_super_count(int N, const float* __restrict__ means2D, const int* __restrict__ radii,
+                                                             int gx, int gy, int ss, int sgx, int nsuper, int rounds, int nchunks,
                                                              unsigned* __restrict__ counters) {
     __shared__ unsigned tot[kMaxSuper];
     for (int s = threadIdx.x; s < nsuper; s += kBinThreads) tot[s] = 0u;
     __syncthreads();
     for (int r = 0; r < rounds; ++r) {
         const int i = (blockIdx.x * rounds + r) * kBinThreads + threadIdx.x;
-        const BinRect q = bin_rect(i, N, order, means2D, radii, gx, gy);
+        const BinRect q = bin_rect(i, N, means2D, radii, gx, gy);
         if (q.x1 > q.x0 && q.y1 > q.y0) {
-            const int sx0 = q.x0 / kSuper, sx1 = (q.x1 + kSuper - 1) / kSuper, sy0 = q.y0 / kSuper, sy1 = (q.y1 + kSuper - 1) / kSuper;
+            const int side1 = (1 << ss) - 1, sx0 = q.x0 >> ss, sx1 = (q.x1 + side1) >> ss, sy0 = q.y0 >> ss, sy1 = (q.y1 + side1) >> ss;
             for (int sy = sy0; sy < sy1; ++sy)
                 for (int sx = sx0; sx < sx1; ++sx) atomicAdd(&tot[sy * sgx + sx], 1u);
         }
     }
     __syncthreads();
-    for (int s = threadIdx.x; s < nsuper; s += kBinThreads) counters[(size_t)blockIdx.x * nsuper + s] = tot[s];   // chunk-major: k_super_write reads it coalesced
+    for (int s = threadIdx.x; s < nsuper; s += kBinThreads) counters[(size_t)blockIdx.x * nsuper + s] = tot[s];   // chunk-major: k_super_append reads it coalesced
 }
 
-// `soff` = exclusive scan of the counters (super-tile-major); writes, per super-tile and in depth order, the Gaussian id and
-// its tile rectangle clipped to the super-tile (x0 | x1 << 4 | y0 << 8 | y1 << 12, each 0..8).
-// A round's entries (about 1.5 per Gaussian) are first laid out in LDS in (super-tile, rank) order - the order of their global
-// positions - and then stored by all 1 024 threads: a wavefront that stored its own hits would issue two stores per ranked
-// super-tile with one or two lanes active (35 us of single-lane stores at 200 000 Gaussians).
-constexpr int kBinStage = 3072;           // staged entries per round; a round with more writes straight from the ranking loop
-__global__ void __launch_bounds__(kBinThreads) k_super_write(int N, const unsigned* __restrict__ order,
-                                                             const float* __restrict__ means2D, const int* __restrict__ radii,
-                                                             int gx, int gy, int sgx, int nsuper, int rounds, int nchunks,
-                                                             const unsigned* __restrict__ counters, unsigned* __restrict__ sstart,
-                                                             unsigned cap, unsigned* __restrict__ sid, unsigned short* __restrict__ srect,
-                                                             unsigned* __restrict__ header) {
-    constexpr int NW = kBinThreads / 64;
+// Appends the keys (depth bits << 32 | index) of this chunk's Gaussians to the lists of the super-tiles their rectangles meet.
+// Where the chunk's entries of a super-tile start: the (chunk, super-tile) counts are not scanned by a launch of their own - every
+// block sums the table's columns (a few parts per super-tile, coalesced over the super-tiles; a few hundred KB of L2 reads per
+// block), a wavefront scans the totals, block 0 publishes the list starts for the kernels that follow.
+__global__ void __launch_bounds__(kBinThreads) k_super_append(int N, const float* __restrict__ depths, const float* __restrict__ means2D,
+                                                              const int* __restrict__ radii, int gx, int gy, int ss, int sgx, int nsuper,
+                                                              int rounds, int nchunks, const unsigned* __restrict__ counters,
+                                                              unsigned* __restrict__ sstart, unsigned cap,
+                                                              unsigned long long* __restrict__ skeys, unsigned* __restrict__ header) {
     __shared__ unsigned run[kMaxSuper];            // next free position of (super-tile, this chunk)
-    __shared__ unsigned rbase[kMaxSuper];          // ... at the start of the round
-    __shared__ unsigned lstart[kMaxSuper];         // first staging slot of the super-tile's entries of the round
-    __shared__ unsigned cw[kMaxSuper * NW];        // per round: count of wavefront w, then its starting position
-    __shared__ unsigned long long touched[NW][kMaxSuper / 64];   // super-tiles with an entry from wavefront w this round
-    __shared__ unsigned short sxy[kMaxSuper];      // (sx | sy << 8) of a super-tile: no division in the ranking loop
-    __shared__ unsigned st_pos[kBinStage], st_src[kBinStage];   // staged entry: global position, owner thread | super-tile << 10
-    __shared__ unsigned q_id[kBinThreads];
-    __shared__ unsigned q_rect[kBinThreads];                    // the owner's tile rectangle: x0 | x1 << 8 | y0 << 16 | y1 << 24 (tile grids up to 255: else unstaged)
-    __shared__ unsigned s_total;
+    __shared__ unsigned tot_s[kMaxSuper], pre_s[kMaxSuper];
+    __shared__ unsigned part_tot[kBinThreads], part_pre[kBinThreads];   // nsuper * PARTS <= kBinThreads
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const int nwords = (nsuper + 63) / 64;
-    const bool small_grid = gx <= 255 && gy <= 255;
-    // Where this chunk's entries of every super-tile start: the (chunk, super-tile) counts are not scanned by a launch of their own -
-    // every block sums the columns (4 partial sums per super-tile, coalesced over the super-tiles; the table is a few hundred KB
-    // of L2 reads per block), a wavefront scans the totals, block 0 publishes the list starts for the tile kernels.
     {
         const int PARTS = max(1, min(8, kBinThreads / nsuper));  // (super-tile, part) items: one per thread, one pass
-        unsigned* part_tot = st_pos;                             // [nsuper * PARTS] (the staging arrays are free here)
-        unsigned* part_pre = st_src;
         const int per = (nchunks + PARTS - 1) / PARTS;
         for (int w = threadIdx.x; w < nsuper * PARTS; w += kBinThreads) {
             const int s_ = w % nsuper, part = w / nsuper;
@@ -490,15 +485,14 @@ __global__ void __launch_bounds__(kBinThreads) k_super_write(int N, const unsign
         for (int s_ = threadIdx.x; s_ < nsuper; s_ += kBinThreads) {
             unsigned tot = 0, pre = 0;
             for (int k = 0; k < PARTS; ++k) { tot += part_tot[k * nsuper + s_]; pre += part_pre[k * nsuper + s_]; }
-            lstart[s_] = tot; rbase[s_] = pre;
-            sxy[s_] = (unsigned short)((s_ % sgx) | ((s_ / sgx) << 8));
+            tot_s[s_] = tot; pre_s[s_] = pre;
         }
         __syncthreads();
         if (wv == 0) {
             constexpr int PER = kMaxSuper / 64;
             unsigned c[PER], sum = 0;
 #pragma unroll
-            for (int k = 0; k < PER; ++k) { const int s_ = lane * PER + k; c[k] = s_ < nsuper ? lstart[s_] : 0u; sum += c[k]; }
+            for (int k = 0; k < PER; ++k) { const int s_ = lane * PER + k; c[k] = s_ < nsuper ? tot_s[s_] : 0u; sum += c[k]; }
             unsigned incl = sum;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -507,7 +501,7 @@ __global__ void __launch_bounds__(kBinThreads) k_super_write(int N, const unsign
             for (int k = 0; k < PER; ++k) {
                 const int s_ = lane * PER + k;
                 if (s_ < nsuper) {
-                    run[s_] = ex + rbase[s_];
+                    run[s_] = ex + pre_s[s_];
                     if (blockIdx.x == 0) sstart[s_] = ex;
                 }
                 ex += c[k];
@@ -516,100 +510,118 @@ __global__ void __launch_bounds__(kBinThreads) k_super_write(int N, const unsign
         }
         __syncthreads();
     }
-    auto clip = [](int x0, int x1, int y0, int y1, int sx, int sy) {
-        const int bx = sx * kSuper, by = sy * kSuper;
-        const int rx0 = max(x0 - bx, 0), rx1 = min(x1 - bx, kSuper), ry0 = max(y0 - by, 0), ry1 = min(y1 - by, kSuper);
-        return (unsigned short)(rx0 | (rx1 << 4) | (ry0 << 8) | (ry1 << 12));
-    };
     for (int r = 0; r < rounds; ++r) {
-        for (int k = threadIdx.x; k < nsuper * NW; k += kBinThreads) cw[k] = 0u;
-        __syncthreads();
         const int i = (blockIdx.x * rounds + r) * kBinThreads + threadIdx.x;
-        const BinRect q = bin_rect(i, N, order, means2D, radii, gx, gy);
-        const bool any = q.x1 > q.x0 && q.y1 > q.y0;
-        const int sx0 = q.x0 / kSuper, sx1 = (q.x1 + kSuper - 1) / kSuper, sy0 = q.y0 / kSuper, sy1 = (q.y1 + kSuper - 1) / kSuper;
-        const unsigned wx = any ? (unsigned)(sx1 - sx0) : 0u, wy = any ? (unsigned)(sy1 - sy0) : 0u;
-        q_id[threadIdx.x] = q.id;
-        q_rect[threadIdx.x] = (unsigned)q.x0 | ((unsigned)q.x1 << 8) | ((unsigned)q.y0 << 16) | ((unsigned)q.y1 << 24);
-        // a: every wavefront's count per super-tile (one LDS atomic per Gaussian and super-tile)
-        if (any)
+        const BinRect q = bin_rect(i, N, means2D, radii, gx, gy);
+        if (q.x1 > q.x0 && q.y1 > q.y0) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(depths[i]) << 32) | (unsigned)i;
+            const int side1 = (1 << ss) - 1, sx0 = q.x0 >> ss, sx1 = (q.x1 + side1) >> ss, sy0 = q.y0 >> ss, sy1 = (q.y1 + side1) >> ss;
             for (int sy = sy0; sy < sy1; ++sy)
-                for (int sx = sx0; sx < sx1; ++sx) atomicAdd(&cw[(sy * sgx + sx) * NW + wv], 1u);
-        __syncthreads();
-        for (int w = 0; w < nwords; ++w) {                       // which super-tiles this wavefront has to rank
-            const int s_ = w * 64 + lane;
-            const unsigned long long m = __ballot(s_ < nsuper && cw[s_ * NW + wv] != 0u);
-            if (lane == 0) touched[wv][w] = m;
-        }
-        // b: wavefront order inside the round
-        for (int s_ = threadIdx.x; s_ < nsuper; s_ += kBinThreads) {
-            unsigned pos = run[s_];
-            rbase[s_] = pos;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) { const unsigned c = cw[s_ * NW + w]; cw[s_ * NW + w] = pos; pos += c; }
-            lstart[s_] = pos - run[s_];                          // the round's count, scanned below
-            run[s_] = pos;
-        }
-        __syncthreads();
-        if (wv == 0) {                                           // exclusive scan of the round's counts over the super-tiles
-            constexpr int PER = kMaxSuper / 64;
-            unsigned c[PER], sum = 0;
-#pragma unroll
-            for (int k = 0; k < PER; ++k) { const int s_ = lane * PER + k; c[k] = s_ < nsuper ? lstart[s_] : 0u; sum += c[k]; }
-            unsigned incl = sum;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-            unsigned ex = incl - sum;
-#pragma unroll
-            for (int k = 0; k < PER; ++k) { const int s_ = lane * PER + k; if (s_ < nsuper) lstart[s_] = ex - rbase[s_]; ex += c[k]; }   // slot = lstart + position
-            if (lane == 63) s_total = incl;
-        }
-        __syncthreads();
-        const unsigned total = s_total;
-        const bool staged = small_grid && total <= (unsigned)kBinStage;   // block-uniform
-        // c: rank in lane (= depth) order inside the wavefront.  The loop runs once per super-tile the wavefront touches (~70 of
-        // 135 for 64 Gaussians in depth order) on every wavefront of the SIMD: it is kept to the test, the rank and two LDS stores;
-        // the clipped rectangle is formed by the flush below, one entry per thread.
-        for (int w = 0; w < nwords; ++w) {
-            unsigned long long todo = touched[wv][w];            // wave-uniform
-            while (todo) {
-                const int s_ = w * 64 + (int)__builtin_ctzll(todo);
-                todo &= todo - 1;
-                const int sx = sxy[s_] & 255, sy = sxy[s_] >> 8;
-                const bool hit = (unsigned)(sx - sx0) < wx && (unsigned)(sy - sy0) < wy;
-                const unsigned long long m = __ballot(hit);
-                if (hit) {
-                    const unsigned o = cw[s_ * NW + wv] + (unsigned)__popcll(m & lt);
-                    if (staged) {
-                        const unsigned li = lstart[s_] + o;
-                        st_pos[li] = o; st_src[li] = threadIdx.x | ((unsigned)s_ << 10);
-                    } else if (o < cap) {
-                        sid[o] = q.id; srect[o] = clip(q.x0, q.x1, q.y0, q.y1, sx, sy);
-                    } else {
-                        header[1] = 1u;
-                    }
+                for (int sx = sx0; sx < sx1; ++sx) {
+                    const unsigned o = atomicAdd(&run[sy * sgx + sx], 1u);
+                    if (o < cap) skeys[o] = key;
+                    else header[1] = 1u;
                 }
-            }
         }
-        __syncthreads();
-        if (staged)
-            for (unsigned j = threadIdx.x; j < total; j += kBinThreads) {
-                const unsigned o = st_pos[j], src = st_src[j], t = src & 1023u, s_ = src >> 10;
-                if (o < cap) {
-                    const unsigned qr = q_rect[t];
-                    sid[o] = q_id[t];
-                    srect[o] = clip((int)(qr & 255u), (int)((qr >> 8) & 255u), (int)((qr >> 16) & 255u), (int)(qr >> 24), sxy[s_] & 255, sxy[s_] >> 8);
-                } else {
-                    header[1] = 1u;
-                }
-            }
-        __syncthreads();
     }
 }
 
 // the list of super-tile s: [sstart[s], sstart[s + 1]) clipped to the capacity
 __device__ __forceinline__ void super_range(int s, const unsigned* __restrict__ sstart, unsigned cap, unsigned& b, unsigned& e) {
     b = min(sstart[s], cap); e = min(sstart[s + 1], cap);
+}
+
+// A block per super-tile: its list of keys into ascending order (depth bits, then index: what a stable sort by depth leaves), then
+// the ids and clipped rectangles of the entries.  Bitonic network in the form whose every comparison puts the smaller key at the
+// lower index (first step of a merge: partner l ^ (k - 1); later steps: l + j), so the virtual +inf padding up to a power of two
+// never moves and any length sorts.  Up to kSortLds keys (every list of the 200 000-Gaussian benchmark: 3 201 at most) the whole
+// network runs in LDS; beyond, LDS-sized pieces are sorted,
+// and for the larger merges the steps whose distance reaches across pieces run on global memory (one block: __syncthreads orders
+// them), the rest again in LDS.
+constexpr int kSortLds = 4096;                    // keys per LDS piece (32 KB: four blocks per CU, every super-tile's block resident at once)
+constexpr int kSuperSortThreads = 512;
+__device__ __forceinline__ void cmpx(unsigned long long& a, unsigned long long& b) { if (a > b) { const unsigned long long t = a; a = b; b = t; } }
+// pair of comparison t in a step of distance j (a power of two): l = t with a zero inserted at bit log2(j), r = l + j
+__device__ __forceinline__ int pair_lo(int t, int j) { return (t << 1) - (t & (j - 1)); }
+// steps of the network on `buf[0, m)` (m a power of two) for merge size k: the first (flip) step if `flip`, then distances j0, j0/2 .. 1
+__device__ __forceinline__ void bitonic_steps(unsigned long long* buf, int m, int k, bool flip, int j0) {
+    if (flip) {
+        const int h = k >> 1;
+        for (int t = threadIdx.x; t < (m >> 1); t += kSuperSortThreads) {
+            const int off = t & (h - 1), l = pair_lo(t, h), r = l - off + (k - 1 - off);
+            cmpx(buf[l], buf[r]);
+        }
+        __syncthreads();
+    }
+    for (int j = j0; j > 0; j >>= 1) {
+        for (int t = threadIdx.x; t < (m >> 1); t += kSuperSortThreads) {
+            const int l = pair_lo(t, j);
+            cmpx(buf[l], buf[l + j]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kSuperSortThreads) k_super_sort(int N, const float* __restrict__ means2D, const int* __restrict__ radii,
+                                                                  int gx, int gy, int ss, int sgx, const unsigned* __restrict__ sstart, unsigned cap,
+                                                                  unsigned long long* __restrict__ skeys, unsigned* __restrict__ sid,
+                                                                  unsigned short* __restrict__ srect) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];   // kSortLds keys
+    const int s_ = blockIdx.x, sx = s_ % sgx, sy = s_ / sgx;
+    unsigned b, e;
+    super_range(s_, sstart, cap, b, e);
+    const int n = (int)(e - b);
+    if (n == 0) return;
+    unsigned long long* gk = skeys + b;
+    const unsigned long long INF = ~0ull;
+    int m = 1;
+    while (m < n) m <<= 1;
+    const unsigned long long* sorted;              // where the sorted keys end up
+    if (m <= kSortLds) {
+        for (int i = threadIdx.x; i < m; i += kSuperSortThreads) sk[i] = i < n ? gk[i] : INF;
+        __syncthreads();
+        for (int k = 2; k <= m; k <<= 1) bitonic_steps(sk, m, k, true, k >> 2);
+        sorted = sk;
+    } else {
+        // pieces of kSortLds keys, each through the whole network in LDS
+        for (int p0 = 0; p0 < n; p0 += kSortLds) {
+            for (int i = threadIdx.x; i < kSortLds; i += kSuperSortThreads) sk[i] = p0 + i < n ? gk[p0 + i] : INF;
+            __syncthreads();
+            for (int k = 2; k <= kSortLds; k <<= 1) bitonic_steps(sk, kSortLds, k, true, k >> 2);
+            for (int i = threadIdx.x; i < kSortLds; i += kSuperSortThreads) if (p0 + i < n) gk[p0 + i] = sk[i];
+            __syncthreads();
+        }
+        // merges across pieces: the steps of distance >= kSortLds on global memory (a partner beyond n is +inf: nothing to do)
+        for (int k = kSortLds << 1; k <= m; k <<= 1) {
+            const int h = k >> 1;
+            for (int t = threadIdx.x; t < (m >> 1); t += kSuperSortThreads) {
+                const int off = t & (h - 1), l = pair_lo(t, h), r = l - off + (k - 1 - off);
+                if (r < n) { unsigned long long a = gk[l], c = gk[r]; if (a > c) { gk[l] = c; gk[r] = a; } }
+            }
+            __syncthreads();
+            for (int j = k >> 2; j >= kSortLds; j >>= 1) {
+                for (int t = threadIdx.x; t < (m >> 1); t += kSuperSortThreads) {
+                    const int l = pair_lo(t, j), r = l + j;
+                    if (r < n) { unsigned long long a = gk[l], c = gk[r]; if (a > c) { gk[l] = c; gk[r] = a; } }
+                }
+                __syncthreads();
+            }
+            for (int p0 = 0; p0 < n; p0 += kSortLds) {            // distances below a piece: in LDS
+                for (int i = threadIdx.x; i < kSortLds; i += kSuperSortThreads) sk[i] = p0 + i < n ? gk[p0 + i] : INF;
+                __syncthreads();
+                bitonic_steps(sk, kSortLds, kSortLds, false, kSortLds >> 1);
+                for (int i = threadIdx.x; i < kSortLds; i += kSuperSortThreads) if (p0 + i < n) gk[p0 + i] = sk[i];
+                __syncthreads();
+            }
+        }
+        sorted = gk;
+    }
+    for (int i = threadIdx.x; i < n; i += kSuperSortThreads) {
+        const unsigned id = (unsigned)sorted[i];
+        const BinRect q = bin_rect((int)id, N, means2D, radii, gx, gy);
+        sid[b + i] = id;
+        srect[b + i] = clip_rect(q, sx, sy, ss);
+    }
 }
 
 __device__ __forceinline__ bool rect_has(unsigned r, int rx, int ry) {
@@ -624,14 +636,14 @@ __device__ __forceinline__ void tile_quarter(unsigned b, unsigned e, int q, unsi
     qb = min(e, b + (unsigned)q * len); qe = min(e, qb + len);
 }
 
-__global__ void __launch_bounds__(256) k_tile_count(int gx, int tiles, int sgx, const unsigned* __restrict__ sstart, unsigned cap,
+__global__ void __launch_bounds__(256) k_tile_count(int gx, int tiles, int ss, int sgx, const unsigned* __restrict__ sstart, unsigned cap,
                                                     const unsigned short* __restrict__ srect, unsigned* __restrict__ tcount) {
     const int t = blockIdx.x, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tx = t % gx, ty = t / gx;
     unsigned b, e;
-    super_range((ty / kSuper) * sgx + tx / kSuper, sstart, cap, b, e);
+    super_range((ty >> ss) * sgx + (tx >> ss), sstart, cap, b, e);
     tile_quarter(b, e, q, b, e);
-    const int rx = tx % kSuper, ry = ty % kSuper;
+    const int rx = tx & ((1 << ss) - 1), ry = ty & ((1 << ss) - 1);
     unsigned cnt = 0;
     for (unsigned i0 = b; i0 < e; i0 += 64 * kBinUnroll) {       // kBinUnroll chunks of 64 entries requested before any is tested
         unsigned short r[kBinUnroll];
@@ -705,16 +717,16 @@ __global__ void __launch_bounds__(kOffThreads) k_tile_offsets(int tiles, const u
     }
 }
 
-__global__ void __launch_bounds__(256) k_tile_write(int gx, int tiles, int sgx, const unsigned* __restrict__ sstart, unsigned cap,
+__global__ void __launch_bounds__(256) k_tile_write(int gx, int tiles, int ss, int sgx, const unsigned* __restrict__ sstart, unsigned cap,
                                                     const unsigned* __restrict__ sid, const unsigned short* __restrict__ srect,
                                                     const uint2* __restrict__ ranges, const unsigned* __restrict__ tcount,
                                                     unsigned* __restrict__ point_list) {
     const int t = blockIdx.x, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tx = t % gx, ty = t / gx;
     unsigned b, e;
-    super_range((ty / kSuper) * sgx + tx / kSuper, sstart, cap, b, e);
+    super_range((ty >> ss) * sgx + (tx >> ss), sstart, cap, b, e);
     tile_quarter(b, e, q, b, e);
-    const int rx = tx % kSuper, ry = ty % kSuper;
+    const int rx = tx & ((1 << ss) - 1), ry = ty & ((1 << ss) - 1);
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint4 q4 = ((const uint4*)tcount)[t];
     unsigned pos = ranges[t].x + (q > 0 ? q4.x : 0u) + (q > 1 ? q4.y : 0u) + (q > 2 ? q4.z : 0u);
@@ -936,17 +948,21 @@ extern "C" int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, cons
     SYN3R_LAUNCH(k_preprocess, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
                        scales, rotations, opacities, shs, confidence, scale_modifier, cam, radii, g);
     int rc = SYN3R_OK;
-    // Gaussians by ascending depth (stable: equal depths keep index order), then the tile counts scanned in
-    // that order: pairs emitted along it and stably sorted by tile id end up ordered exactly like the
-    // published (tile << 32 | depth bits) key sort, for 8 B instead of 72 B of sort traffic per pair
-    int in_b = 0;
-    rc = argsort_depth_u32(g.dkeys_a, g.order_a, g.dkeys_b, g.order_b, (size_t)N, g.sort_scratch, stream, &in_b);
-    if (rc) return rc;
-    if ((in_b ? g.order_b : g.order_a) != g.order) { set_error("raster_preprocess: unexpected argsort parity"); return SYN3R_E_INVALID; }
-    // The hierarchical binning of syn3r_raster_render counts the pairs itself (k_tile_offsets); the scanned tile counts are needed
-    // by the pair-sort path and by a caller who asks for the exact count before sizing the binning buffer.
-    if (!hier_binning(N, cam.grid_x, cam.grid_y) || num_rendered_host) {
+    const bool hier = hier_binning(N, cam.grid_x, cam.grid_y);
+    if (!hier) {
+        // the pair-sort path: Gaussians by ascending depth (stable: equal depths keep index order), then the tile counts scanned in
+        // that order: pairs emitted along it and stably sorted by tile id end up ordered exactly like the
+        // published (tile << 32 | depth bits) key sort, for 8 B instead of 72 B of sort traffic per pair
+        int in_b = 0;
+        rc = argsort_depth_u32(g.dkeys_a, g.order_a, g.dkeys_b, g.order_b, (size_t)N, g.sort_scratch, stream, &in_b);
+        if (rc) return rc;
+        if ((in_b ? g.order_b : g.order_a) != g.order) { set_error("raster_preprocess: unexpected argsort parity"); return SYN3R_E_INVALID; }
         rc = exclusive_scan_u32(g.tiles_touched, g.point_offsets, (size_t)N, g.header, g.scan_scratch, stream, g.order);
+        if (rc) return rc;
+    } else if (num_rendered_host) {
+        // The hierarchical binning of syn3r_raster_render orders and counts on its own (k_super_sort, k_tile_offsets); a caller who
+        // asks for the exact pair count before sizing the binning buffer gets the sum of the tile counts
+        rc = exclusive_scan_u32(g.tiles_touched, g.point_offsets, (size_t)N, g.header, g.scan_scratch, stream);
         if (rc) return rc;
     }
     SYN3R_LAUNCH_CHECK("raster_preprocess launch");
@@ -993,11 +1009,16 @@ extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const i
         unsigned* sid = bn.vals_b;
         unsigned short* srect = (unsigned short*)bn.keys_a;
         unsigned* sstart = counters + kBinCounters;              // [nsuper + 1] list starts
-        SYN3R_LAUNCH(k_super_count, dim3(bp.nchunks), dim3(kBinThreads), 0, stream, N, g.order, g.means2D, radii, gx, gy, bp.sgx,
+        unsigned long long* skeys = bn.keys_b;
+        static DevOnce once;
+        if (int rc2 = set_max_lds(once, (const void*)k_super_sort, kSortLds * 8, "hipFuncSetAttribute(super_sort)")) return rc2;
+        SYN3R_LAUNCH(k_super_count, dim3(bp.nchunks), dim3(kBinThreads), 0, stream, N, (const float*)g.means2D, radii, gx, gy, bp.ss, bp.sgx,
                      bp.nsuper, bp.rounds, bp.nchunks, counters);
-        SYN3R_LAUNCH(k_super_write, dim3(bp.nchunks), dim3(kBinThreads), 0, stream, N, g.order, g.means2D, radii, gx, gy, bp.sgx,
-                     bp.nsuper, bp.rounds, bp.nchunks, (const unsigned*)counters, sstart, (unsigned)P, sid, srect, g.header);
-        SYN3R_LAUNCH(k_tile_count, dim3((unsigned)tiles), dim3(256), 0, stream, gx, (int)tiles, bp.sgx,
+        SYN3R_LAUNCH(k_super_append, dim3(bp.nchunks), dim3(kBinThreads), 0, stream, N, (const float*)g.depths, (const float*)g.means2D, radii,
+                     gx, gy, bp.ss, bp.sgx, bp.nsuper, bp.rounds, bp.nchunks, (const unsigned*)counters, sstart, (unsigned)P, skeys, g.header);
+        SYN3R_LAUNCH(k_super_sort, dim3(bp.nsuper), dim3(kSuperSortThreads), kSortLds * 8, stream, N, (const float*)g.means2D, radii, gx, gy,
+                     bp.ss, bp.sgx, (const unsigned*)sstart, (unsigned)P, skeys, sid, srect);
+        SYN3R_LAUNCH(k_tile_count, dim3((unsigned)tiles), dim3(256), 0, stream, gx, (int)tiles, bp.ss, bp.sgx,
                      (const unsigned*)sstart, (unsigned)P, (const unsigned short*)srect, im.tile_counts);
         // the blend kernels take the tiles longest list first: with one block per tile in image order they ended on the few long
         // tiles of the last dispatch round (k_render 170 -> 130 us, k_render_bwd 463 -> 380 us at 200 000 Gaussians / 1080p;
@@ -1006,7 +1027,7 @@ extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const i
         tile_order = order_env ? im.tile_order : nullptr;
         SYN3R_LAUNCH(k_tile_offsets, dim3(1), dim3(kOffThreads), 0, stream, (int)tiles, (const unsigned*)im.tile_counts, (unsigned)P,
                      im.ranges, g.header, tile_order);
-        SYN3R_LAUNCH(k_tile_write, dim3((unsigned)tiles), dim3(256), 0, stream, gx, (int)tiles, bp.sgx,
+        SYN3R_LAUNCH(k_tile_write, dim3((unsigned)tiles), dim3(256), 0, stream, gx, (int)tiles, bp.ss, bp.sgx,
                      (const unsigned*)sstart, (unsigned)P, (const unsigned*)sid, (const unsigned short*)srect,
                      (const uint2*)im.ranges, (const unsigned*)im.tile_counts, point_list);
     } else if (P > 0) {
