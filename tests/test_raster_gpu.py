@@ -188,6 +188,12 @@ def test_async_pair_count_mode_matches_sync(gpu):
         raster.flush_pair_checks()
         for c, _, d, a in outs:
             assert torch.equal(c, c_sync) and torch.equal(d, d_sync) and torch.equal(a, a_sync)
+        # the same capacity, nothing visible: the binning kernels run on empty lists (no read-back decides to skip them)
+        behind = f(sc["m"]).clone(); behind[:, 2] = -5.0
+        c0, r0, d0, a0 = GaussianRasterizer(st)(behind, None, f(sc["o"]), shs=f(sc["sh"]), scales=f(sc["s"]), rotations=f(sc["q"]))
+        raster.flush_pair_checks()
+        assert (r0 == 0).all() and (a0 == 0).all() and (d0 == 0).all()
+        assert torch.equal(c0, f(sc["bg"])[:, None, None].expand(3, sc["H"], sc["W"]))
         raster._capacity[key] = 16               # force an overflow
         GaussianRasterizer(st)(f(sc["m"]), None, f(sc["o"]), shs=f(sc["sh"]), scales=f(sc["s"]), rotations=f(sc["q"]))
         with pytest.raises(Exception):
