@@ -271,8 +271,11 @@ __device__ __forceinline__ F3 operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b
 __device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
 // SH colour backward: writes dL_dsh (M x 3) and returns dL_dmean through the view direction
-__device__ F3 sh_backward(int D, int M, F3 pos, const float* campos, const float* __restrict__ sh, unsigned clamped,
-                          F3 dL_dRGB, float* __restrict__ dL_dsh) {
+// PRELOAD (M == 16): every coefficient is read into registers before the first output is written, so `dL_dsh` may be the row
+// `sh` itself (k_preprocess_bwd's LDS-staged rows)
+template <bool PRELOAD>
+__device__ __forceinline__ F3 sh_backward(int D, int M, F3 pos, const float* campos, const float* sh, unsigned clamped,
+                                          F3 dL_dRGB, float* dL_dsh) {
     F3 dir_o = f3(pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]);
     float len2 = dot(dir_o, dir_o);
     float inv = 1.0f / sqrtf(len2);
@@ -280,7 +283,12 @@ __device__ F3 sh_backward(int D, int M, F3 pos, const float* campos, const float
     if (clamped & 1u) dL_dRGB.x = 0.0f;
     if (clamped & 2u) dL_dRGB.y = 0.0f;
     if (clamped & 4u) dL_dRGB.z = 0.0f;
-    auto c = [&](int k) { return f3(sh[3 * k], sh[3 * k + 1], sh[3 * k + 2]); };
+    float pre[PRELOAD ? 48 : 1];
+    if constexpr (PRELOAD) {
+#pragma unroll
+        for (int k = 0; k < 48; ++k) pre[k] = sh[k];
+    }
+    auto c = [&](int k) { return PRELOAD ? f3(pre[3 * k], pre[3 * k + 1], pre[3 * k + 2]) : f3(sh[3 * k], sh[3 * k + 1], sh[3 * k + 2]); };
     auto put = [&](int k, float s) {
         dL_dsh[3 * k] = s * dL_dRGB.x; dL_dsh[3 * k + 1] = s * dL_dRGB.y; dL_dsh[3 * k + 2] = s * dL_dRGB.z;
     };
@@ -321,6 +329,11 @@ __device__ F3 sh_backward(int D, int M, F3 pos, const float* campos, const float
     return f3((dL_ddir.x - x * vg) * inv, (dL_ddir.y - y * vg) * inv, (dL_ddir.z - z * vg) * inv);
 }
 
+// STAGED (sh_coeffs == 16, 16-byte aligned tensors): a block's spherical-harmonics rows (256 x 192 B, contiguous in memory) come in
+// and its gradient rows go out through LDS with coalesced 16-byte accesses; a thread reading and writing its own 192-byte row in
+// global memory touches 64 different cache lines per wave instruction (32 of the kernel's 42 us at 200 000 Gaussians).
+constexpr int kShLd = 49;      // LDS row stride (floats): odd, so the 64 rows of a wavefront fall into 64 banks
+template <bool STAGED>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(
     int N, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rots, const float* __restrict__ opacities, const float* __restrict__ shs,
@@ -328,16 +341,31 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
     const float* __restrict__ grad_rec, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drots, float* __restrict__ dL_dopacity, float* __restrict__ dL_dshs,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconf) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    float* osh = dL_dshs + (size_t)i * M * 3;
+    __shared__ float shl[STAGED ? 256 * kShLd : 1];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const size_t blk0 = (size_t)blockIdx.x * 256 * 48;                // first float of the block's rows
+    const int rows = min(256, N - (int)blockIdx.x * 256);
+    if constexpr (STAGED) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int e = (threadIdx.x + 256 * k) * 4, row = e / 48, col = e - row * 48;
+            if (row < rows) {
+                const float4 v4 = *(const float4*)(shs + blk0 + e);
+                float* d = &shl[row * kShLd + col];
+                d[0] = v4.x; d[1] = v4.y; d[2] = v4.z; d[3] = v4.w;
+            }
+        }
+        __syncthreads();
+    }
+    if (i < N) do {
+    float* osh = STAGED ? &shl[threadIdx.x * kShLd] : dL_dshs + (size_t)i * M * 3;
     if (radii[i] <= 0) {
         for (int k = 0; k < 3; ++k) { dL_dmeans3D[3 * i + k] = 0.f; dL_dscales[3 * i + k] = 0.f; dL_dmeans2D[3 * i + k] = 0.f; }
         for (int k = 0; k < 4; ++k) dL_drots[4 * i + k] = 0.f;
         dL_dopacity[i] = 0.f;
         if (dL_dconf) dL_dconf[i] = 0.f;
         for (int k = 0; k < 3 * M; ++k) osh[k] = 0.f;
-        return;
+        break;
     }
     const float* gr = grad_rec + (size_t)i * kGradSlots;
     F3 p = f3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
@@ -410,7 +438,8 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
     dL_dmeans2D[3 * i] = g2x; dL_dmeans2D[3 * i + 1] = g2y; dL_dmeans2D[3 * i + 2] = 0.f;
 
     // ---- colour -> SH and mean
-    F3 dm_sh = sh_backward(D, M, p, cam.campos, shs + (size_t)i * M * 3, g.clamped[i], f3(gr[G_R], gr[G_G], gr[G_B]), osh);
+    F3 dm_sh = sh_backward<STAGED>(D, M, p, cam.campos, STAGED ? (const float*)osh : shs + (size_t)i * M * 3, g.clamped[i],
+                                   f3(gr[G_R], gr[G_G], gr[G_B]), osh);
     dmean = dmean + dm_sh;
     dL_dmeans3D[3 * i] = dmean.x; dL_dmeans3D[3 * i + 1] = dmean.y; dL_dmeans3D[3 * i + 2] = dmean.z;
 
@@ -449,6 +478,18 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
                                  2.f * qy * dR22);
     dL_drots[4 * i + 3] = 2.f * (-2.f * qz * dR00 - qr * dR01 + qx * dR02 + qr * dR10 - 2.f * qz * dR11 + qy * dR12 +
                                  qx * dR20 + qy * dR21);
+    } while (0);
+    if constexpr (STAGED) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int e = (threadIdx.x + 256 * k) * 4, row = e / 48, col = e - row * 48;
+            if (row < rows) {
+                const float* d = &shl[row * kShLd + col];
+                *(float4*)(dL_dshs + blk0 + e) = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -494,7 +535,13 @@ extern "C" int syn3r_raster_backward(int N, int sh_degree, int sh_coeffs, long l
         SYN3R_LAUNCH(k_render_bwd, dim3(tiles), dim3(kBwdThreads), 0, stream, H, W, cam.grid_x, cam.grid_y, im.ranges,
                            point_list, g.splats, bg[0], bg[1], bg[2], im.n_contrib, im.final_T, dL_dcolor, dL_ddepth,
                            dL_dalpha, grad_rec, (const unsigned*)(raster_tiles_ordered(N, cam.grid_x, cam.grid_y) ? im.tile_order : nullptr));
-    SYN3R_LAUNCH(k_preprocess_bwd, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
+    const bool staged = sh_coeffs == 16 && ((((uintptr_t)shs) | ((uintptr_t)dL_dshs)) & 15) == 0;
+    if (staged)
+        SYN3R_LAUNCH(k_preprocess_bwd<true>, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
+                       scales, rotations, opacities, shs, confidence, scale_modifier, cam, radii, g, grad_rec,
+                       dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacities, dL_dshs, dL_dmeans2D, dL_dconfidence);
+    else
+    SYN3R_LAUNCH(k_preprocess_bwd<false>, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
                        scales, rotations, opacities, shs, confidence, scale_modifier, cam, radii, g, grad_rec,
                        dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacities, dL_dshs, dL_dmeans2D, dL_dconfidence);
     SYN3R_LAUNCH_CHECK("raster_backward launch");
