@@ -535,6 +535,13 @@ int syn3r_gaussian_activate_backward(int N, const float* rotations, const float*
                                      const float* d_opacities, float* d_log_scales, float* d_rotations, float* d_opacity_logits,
                                      void* stream);
 
+/* The per-iteration statistics of the published adaptive density control (3DGS section 5.2; GaussianModel.add_densification_stats
+ * as FSGS' loop behind gsTrainer.training() applies it), for the Gaussians the render saw (radii[i] > 0), in one launch and without
+ * the host synchronisations of boolean-mask indexing: grad_accum[i] += |viewspace_grad[i, :2]|_2 (sqrt(gx*gx + gy*gy), fp32),
+ * denom[i] += 1, max_radii[i] = max(max_radii[i], radii[i]).  viewspace_grad [N,3] fp32; radii [N] i32; the rest [N] fp32. */
+int syn3r_densification_stats(int N, const int* radii, const float* viewspace_grad, float* grad_accum, float* denom,
+                              float* max_radii, void* stream);
+
 /* out[i] = mean of the three smallest squared Euclidean distances from point i to the OTHER points of the cloud
  * (points [n,3] fp32, n >= 4): the quantity FSGS' GaussianModel.create_from_pcd takes from `distCUDA2` of the
  * simple-knn CUDA extension to initialise the Gaussian scales (reached from reset_gaussians_from_pcd,

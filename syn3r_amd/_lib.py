@@ -64,6 +64,7 @@ SIGNATURES = {
     "syn3r_sort_pairs": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_i, c_p, c_sz, C.POINTER(c_i), c_p]),
     "syn3r_gaussian_activate": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "syn3r_gaussian_activate_backward": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "syn3r_densification_stats": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "syn3r_gemm_f16": (c_i, [c_p, c_ll, c_p, c_p, c_ll, c_p, c_p, c_ll, c_i, c_i, c_p, c_ll, c_p, c_ll, c_f, c_f, c_f,
                              c_i, c_i, c_i, c_p]),
     "syn3r_gemm_set_tile": (c_i, [c_i]),

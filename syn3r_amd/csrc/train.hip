@@ -130,6 +130,21 @@ __global__ void __launch_bounds__(kThreads) k_activate_bwd(int N, const float* _
     d_logit[i] = d_opacity[i] * s * (1.0f - s);
 }
 
+// GaussianModel.add_densification_stats of the published trainer for the visible Gaussians (radii > 0): torch.norm(grad[:, :2]) is
+// sqrt(gx*gx + gy*gy) in fp32 (this file compiles without fma contraction)
+__global__ void __launch_bounds__(kThreads) k_densify_stats(int N, const int* __restrict__ radii, const float* __restrict__ vgrad,
+                                                           float* __restrict__ accum, float* __restrict__ denom,
+                                                           float* __restrict__ max_radii) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= N) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    const float gx = vgrad[3 * i], gy = vgrad[3 * i + 1];
+    accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.0f;
+    max_radii[i] = fmaxf(max_radii[i], (float)r);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Photometric loss of the published 3DGS trainer, fused:  L = w * [(1 - lambda) * mean|I - G| + lambda * (1 - SSIM(I, G))]
 // with SSIM as published (11x11 Gaussian window, sigma 1.5, zero padding 5, C1 = 0.01^2, C2 = 0.03^2, mean over
@@ -498,6 +513,16 @@ extern "C" int syn3r_gaussian_activate_backward(int N, const float* rotations, c
     SYN3R_LAUNCH(k_activate_bwd, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream_, N, rotations,
                  scales, rotations_n, opacities, d_scales, d_rotations_n, d_opacities, d_log_scales, d_rotations, d_opacity_logits);
     SYN3R_LAUNCH_CHECK("gaussian_activate_backward launch");
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_densification_stats(int N, const int* radii, const float* viewspace_grad, float* grad_accum, float* denom,
+                                         float* max_radii, void* stream_) {
+    SYN3R_REQUIRE(SYN3R_DIM_OK(N), "densification_stats: bad N=%d", N);
+    SYN3R_REQUIRE(radii && viewspace_grad && grad_accum && denom && max_radii, "densification_stats: null pointer");
+    SYN3R_LAUNCH(k_densify_stats, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream_, N, radii,
+                 viewspace_grad, grad_accum, denom, max_radii);
+    SYN3R_LAUNCH_CHECK("densification_stats launch");
     return SYN3R_OK;
 }
 

@@ -138,6 +138,16 @@ class GaussianModel:
         """Accumulate the norm of the screen-space positional gradient of the visible Gaussians (3DGS section 5.2: the
         quantity the clone / split decision thresholds) and their largest screen radius."""
         self.ensure_stats()
+        if (radii is not None and update_filter is None and viewspace_grad.is_cuda and viewspace_grad.dtype == torch.float32
+                and viewspace_grad.is_contiguous() and radii.dtype == torch.int32):
+            # the training loop's case (visible = radii > 0): one HIP launch, no boolean-mask indexing (each of which is a
+            # `nonzero` with a device -> host synchronisation)
+            L.check(L.load().syn3r_densification_stats(int(radii.shape[0]), L.ptr(radii), L.ptr(viewspace_grad),
+                                                       L.ptr(self.xyz_gradient_accum), L.ptr(self.denom), L.ptr(self.max_radii2D),
+                                                       L.stream_ptr(viewspace_grad.device)), "densification_stats")
+            return
+        if update_filter is None:
+            update_filter = radii > 0
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_grad[update_filter, :2], dim=-1, keepdim=True)
         self.denom[update_filter] += 1
         if radii is not None:
@@ -583,7 +593,7 @@ class GSTrainer:
                                                          L.ptr(d_ro), L.ptr(d_op), L.ptr(d_ls), L.ptr(d_rr), L.ptr(d_lg), stream),
                     "gaussian_activate_backward")
             g._xyz.grad, g._features.grad, g._opacity.grad, g._scaling.grad, g._rotation.grad = d_m3, d_sh, d_lg.reshape(g._opacity.shape), d_ls, d_rr
-        out = {"render": color, "depth": depth, "alpha": alpha, "viewspace_grad": d_m2, "visibility_filter": radii > 0 if self.densify else None,
+        out = {"render": color, "depth": depth, "alpha": alpha, "viewspace_grad": d_m2, "visibility_filter": None,      # visible = radii > 0: add_densification_stats takes it from `radii` on the device
                "radii": radii}
         return loss, out
 

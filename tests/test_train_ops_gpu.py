@@ -124,3 +124,23 @@ def test_photometric_loss_full_frame_and_errors(gpu):
     assert float(a.grad.abs().max()) < 1e-6
     with pytest.raises(ValueError):
         photometric_loss(a.detach()[0], a.detach()[0])
+
+
+def test_densification_stats_vs_masked_torch(gpu):
+    """syn3r_densification_stats == the published GaussianModel.add_densification_stats (boolean-mask indexing) bit for bit."""
+    from syn3r_amd import _lib as L
+    g = torch.Generator().manual_seed(11)
+    n = 10_007
+    radii = torch.randint(-2, 40, (n,), generator=g, dtype=torch.int32).to(gpu)
+    vgrad = torch.randn(n, 3, generator=g).to(gpu)
+    accum = torch.rand(n, 1, generator=g).to(gpu); denom = torch.randint(0, 5, (n, 1), generator=g).float().to(gpu)
+    maxr = (torch.rand(n, generator=g) * 30).to(gpu)
+    vis = radii > 0
+    ea, ed, em = accum.clone(), denom.clone(), maxr.clone()
+    ea[vis] += torch.norm(vgrad[vis, :2], dim=-1, keepdim=True)
+    ed[vis] += 1
+    em[vis] = torch.max(em[vis], radii[vis].to(em.dtype))
+    L.check(L.load().syn3r_densification_stats(n, L.ptr(radii), L.ptr(vgrad), L.ptr(accum), L.ptr(denom), L.ptr(maxr),
+                                               L.stream_ptr(gpu)), "densification_stats")
+    assert torch.equal(denom, ed) and torch.equal(maxr, em)
+    assert torch.allclose(accum, ea, rtol=2e-7, atol=0)          # torch.norm may fuse the two products differently: 1 ulp

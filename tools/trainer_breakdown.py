@@ -1,5 +1,5 @@
 """Per-kernel device time of one GSTrainer.train_step (explicit step) at 200 000 Gaussians / 1920x1080 (developer tool).
-usage: python tools/trainer_breakdown.py [iterations]"""
+usage: python tools/trainer_breakdown.py [iterations] [densify]"""
 import sys
 import tempfile
 import time
@@ -9,10 +9,13 @@ import torch
 from syn3r_amd import _lib as L, measure, raster
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+densify = len(sys.argv) > 2 and sys.argv[2] == "densify"          # with the per-iteration densification statistics
 dev = torch.device("cuda", 0)
 with tempfile.TemporaryDirectory() as tmp:
     tr = measure.synthetic_scene(dev, 200_000, 1080, 1920, 2, 1000, tmp)
     tr.training(0, iterations=50, disable_densification=True)          # warm-up: capacities, workspaces
+    tr.densify = densify
+    tr.opt.densify_from_iter = 10 ** 9                               # statistics only: the set of Gaussians stays fixed
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(100):
