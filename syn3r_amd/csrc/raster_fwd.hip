@@ -539,7 +539,7 @@ __device__ __forceinline__ void super_range(int s, const unsigned* __restrict__ 
 // and for the larger merges the steps whose distance reaches across pieces run on global memory (one block: __syncthreads orders
 // them), the rest again in LDS.
 constexpr int kSortLds = 4096;                    // keys per LDS piece (32 KB: four blocks per CU, every super-tile's block resident at once)
-constexpr int kSuperSortThreads = 512;
+constexpr int kSuperSortThreads = 1024;
 __device__ __forceinline__ void cmpx(unsigned long long& a, unsigned long long& b) { if (a > b) { const unsigned long long t = a; a = b; b = t; } }
 // pair of comparison t in a step of distance j (a power of two): l = t with a zero inserted at bit log2(j), r = l + j
 __device__ __forceinline__ int pair_lo(int t, int j) { return (t << 1) - (t & (j - 1)); }
