@@ -543,23 +543,45 @@ constexpr int kSuperSortThreads = 1024;
 __device__ __forceinline__ void cmpx(unsigned long long& a, unsigned long long& b) { if (a > b) { const unsigned long long t = a; a = b; b = t; } }
 // pair of comparison t in a step of distance j (a power of two): l = t with a zero inserted at bit log2(j), r = l + j
 __device__ __forceinline__ int pair_lo(int t, int j) { return (t << 1) - (t & (j - 1)); }
-// steps of the network on `buf[0, m)` (m a power of two) for merge size k: the first (flip) step if `flip`, then distances j0, j0/2 .. 1
-__device__ __forceinline__ void bitonic_steps(unsigned long long* buf, int m, int k, bool flip, int j0) {
-    if (flip) {
-        const int h = k >> 1;
-        for (int t = threadIdx.x; t < (m >> 1); t += kSuperSortThreads) {
-            const int off = t & (h - 1), l = pair_lo(t, h), r = l - off + (k - 1 - off);
-            cmpx(buf[l], buf[r]);
+// The steps of the network on `buf[0, m)` (m a power of two, LDS) are taken TWO per pass: a thread owns the four keys that two
+// consecutive steps connect, exchanges them in registers and stores them - half the barriers and half the LDS round trips of a
+// step per pass (the network is bound by those, not by its comparisons: 78 steps -> 42 passes at 4 096 keys).
+// distances j, j/2, .. 1 of a merge (pairs (l, l + j)), two distances per pass, a last single one if their number is odd
+__device__ __forceinline__ void bitonic_dists(unsigned long long* buf, int m, int j) {
+    for (; j >= 2; j >>= 2) {
+        const int jh = j >> 1;
+        for (int t = threadIdx.x; t < (m >> 2); t += kSuperSortThreads) {
+            const int e0 = pair_lo(pair_lo(t, jh), j);
+            unsigned long long a = buf[e0], b = buf[e0 + jh], c = buf[e0 + j], d = buf[e0 + j + jh];
+            cmpx(a, c); cmpx(b, d);          // distance j
+            cmpx(a, b); cmpx(c, d);          // distance j / 2
+            buf[e0] = a; buf[e0 + jh] = b; buf[e0 + j] = c; buf[e0 + j + jh] = d;
         }
         __syncthreads();
     }
-    for (int j = j0; j > 0; j >>= 1) {
-        for (int t = threadIdx.x; t < (m >> 1); t += kSuperSortThreads) {
-            const int l = pair_lo(t, j);
-            cmpx(buf[l], buf[l + j]);
-        }
+    if (j == 1) {
+        for (int t = threadIdx.x; t < (m >> 1); t += kSuperSortThreads) cmpx(buf[2 * t], buf[2 * t + 1]);
         __syncthreads();
     }
+}
+// all steps of merge size k: the flip step (pairs (l, l ^ (k - 1)) inside blocks of k) together with distance k / 4, then the rest
+__device__ __forceinline__ void bitonic_merge(unsigned long long* buf, int m, int k) {
+    if (k == 2) {
+        for (int t = threadIdx.x; t < (m >> 1); t += kSuperSortThreads) cmpx(buf[2 * t], buf[2 * t + 1]);
+        __syncthreads();
+        return;
+    }
+    const int q = k >> 2;
+    for (int t = threadIdx.x; t < (m >> 2); t += kSuperSortThreads) {
+        const int off = t & (q - 1), blk = (t - off) << 2;           // (t / q) * k
+        const int ia = blk + off, ib = ia + q, ird = blk + (k - 1 - off), irc = ird - q;
+        unsigned long long a = buf[ia], b = buf[ib], c = buf[irc], d = buf[ird];
+        cmpx(a, d); cmpx(b, c);              // flip
+        cmpx(a, b); cmpx(c, d);              // distance k / 4
+        buf[ia] = a; buf[ib] = b; buf[irc] = c; buf[ird] = d;
+    }
+    __syncthreads();
+    bitonic_dists(buf, m, q >> 1);
 }
 
 __global__ void __launch_bounds__(kSuperSortThreads) k_super_sort(int N, const float* __restrict__ means2D, const int* __restrict__ radii,
@@ -580,14 +602,14 @@ __global__ void __launch_bounds__(kSuperSortThreads) k_super_sort(int N, const f
     if (m <= kSortLds) {
         for (int i = threadIdx.x; i < m; i += kSuperSortThreads) sk[i] = i < n ? gk[i] : INF;
         __syncthreads();
-        for (int k = 2; k <= m; k <<= 1) bitonic_steps(sk, m, k, true, k >> 2);
+        for (int k = 2; k <= m; k <<= 1) bitonic_merge(sk, m, k);
         sorted = sk;
     } else {
         // pieces of kSortLds keys, each through the whole network in LDS
         for (int p0 = 0; p0 < n; p0 += kSortLds) {
             for (int i = threadIdx.x; i < kSortLds; i += kSuperSortThreads) sk[i] = p0 + i < n ? gk[p0 + i] : INF;
             __syncthreads();
-            for (int k = 2; k <= kSortLds; k <<= 1) bitonic_steps(sk, kSortLds, k, true, k >> 2);
+            for (int k = 2; k <= kSortLds; k <<= 1) bitonic_merge(sk, kSortLds, k);
             for (int i = threadIdx.x; i < kSortLds; i += kSuperSortThreads) if (p0 + i < n) gk[p0 + i] = sk[i];
             __syncthreads();
         }
@@ -609,7 +631,7 @@ __global__ void __launch_bounds__(kSuperSortThreads) k_super_sort(int N, const f
             for (int p0 = 0; p0 < n; p0 += kSortLds) {            // distances below a piece: in LDS
                 for (int i = threadIdx.x; i < kSortLds; i += kSuperSortThreads) sk[i] = p0 + i < n ? gk[p0 + i] : INF;
                 __syncthreads();
-                bitonic_steps(sk, kSortLds, kSortLds, false, kSortLds >> 1);
+                bitonic_dists(sk, kSortLds, kSortLds >> 1);
                 for (int i = threadIdx.x; i < kSortLds; i += kSuperSortThreads) if (p0 + i < n) gk[p0 + i] = sk[i];
                 __syncthreads();
             }
