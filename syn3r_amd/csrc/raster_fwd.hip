@@ -1026,6 +1026,7 @@ extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const i
     unsigned* point_list = bn.vals_a;
     unsigned* tile_order = nullptr;
     if (P > 0 && hier_binning(N, gx, gy)) {
+        SYN3R_REQUIRE(P < (1ll << 30), "raster_render: pair capacity %lld: the super-tile sort indexes a list with 31-bit integers (2^30 pairs at most)", P);
         const BinPlan bp = bin_plan(N, gx, gy);
         unsigned* counters = im.bin_counters;
         unsigned* sid = bn.vals_b;
