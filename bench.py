@@ -37,9 +37,10 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
 # constants: v_fma_f32 "one wave alone: 4") at the 2.4 GHz maximum clock = 614.4 G wave-instructions / s
 VALU_ISSUE_PEAK_GINST = 256 * 4 * 2.4 / 4.0   # = 614.4 G wave-instructions / s
 # SQ_INSTS_VALU per launch of the blend kernels on the bench scene (200 000 Gaussians, 1920x1080, seed 0), used when the committed
-# PMC summary of THIS build carries none: profiles/r04/pmc/pmc_counters_by_kernel.json (raster_fwd.hip / raster_bwd.hip unchanged since)
-VALU_INSTS_FALLBACK = {"k_render_bwd": (200413989.0, "profiles/r04/pmc/pmc_counters_by_kernel.json (blend kernels unchanged since)"),
-                       "k_render": (69256554.0, "profiles/r04/pmc/pmc_counters_by_kernel.json (blend kernels unchanged since)")}
+# PMC summary of THIS build carries none: profiles/r05/pmc/pmc_counters_by_kernel.json (the same counts as round 4's: the blend
+# loops are unchanged, round 5 changed the order in which the tiles are taken and how their lists are built)
+VALU_INSTS_FALLBACK = {"k_render_bwd": (200413989.0, "profiles/r05/pmc/pmc_counters_by_kernel.json (an earlier build of this round; blend loops unchanged since)"),
+                       "k_render": (69256554.0, "profiles/r05/pmc/pmc_counters_by_kernel.json (an earlier build of this round; blend loops unchanged since)")}
 
 
 def parse():
