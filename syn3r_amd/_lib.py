@@ -10,11 +10,7 @@ from pathlib import Path
 
 import torch
 
-import os as _os
-
 _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libsyn3r_hip.so"
-if _os.environ.get("SYN3R_LIB_OVERRIDE"):          # developer A/B runs against another BUILD of the same library (tools/)
-    _LIB_PATH = Path(_os.environ["SYN3R_LIB_OVERRIDE"]).resolve()
 _lib = None
 
 c_f = C.c_float
@@ -129,6 +125,15 @@ class Syn3rError(RuntimeError):
 
 def lib_path() -> Path:
     return _LIB_PATH
+
+
+def set_library_path(path) -> None:
+    """Developer A/B runs against another BUILD of the same library: an EXPLICIT call (tools/_devlib.py, the `--syn3r-lib`
+    option of tests/conftest.py), before the first load().  The package itself never looks at the environment for this."""
+    global _LIB_PATH
+    if _lib is not None:
+        raise Syn3rError("set_library_path() after the library was loaded")
+    _LIB_PATH = Path(path).resolve()
 
 
 def load():

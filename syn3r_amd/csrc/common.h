@@ -153,25 +153,48 @@ __device__ __forceinline__ float fast_erff(float x) {
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + fast_erff(g * 0.70710678118654752f)); }
 
 // Exact (erf) GELU of TWO values on packed fp32 arithmetic:  gelu(g) = g * Phi(g),  Phi(g) = 1/2 + g * P(g^2)  with P a
-// degree-12 polynomial (Chebyshev fit of (Phi(g) - 1/2) / g on |g| <= 5, evaluated by Horner in t = 2 g^2 / 25 - 1) and g
-// clamped to [-5, 5] inside Phi (beyond it Phi is 0 / 1 to 3e-7).  |error| <= 2.3e-6 on gelu (fp32 Horner, checked
-// against scipy erf over [-7, 7]): 25x below the fp16 rounding step of the gate output it feeds.  No transcendental, no
-// reciprocal: 15 v_pk_fma_f32 / v_pk_mul_f32 per pair, i.e. ~7 issue slots per value against ~26 for gelu_erf.
+// polynomial (fit of (Phi(g) - 1/2) / g on |g| <= G, evaluated by Horner in t = 2 g^2 / G^2 - 1) and g clamped to [-G, G]
+// inside Phi.  No transcendental, no reciprocal: DEG + 3 v_pk_fma_f32 / v_pk_mul_f32 per pair against ~26 issue slots per
+// VALUE for gelu_erf.  The gate is bound by the SIMD's vector EXECUTION (a wave64 v_pk_fma_f32 is four passes of the 32-lane
+// unit: two cycles per value and Horner step, whoever issues it), so its cost is its degree:
+//   SYN3R_GELU_DEG 12  (rounds 2-5)  G = 5    |error| <= 2.3e-6 on gelu, 1.2-1.7 % of the fp16-rounded gate outputs differ by one
+//                                             ulp from the correctly rounded erf form
+//   SYN3R_GELU_DEG 10                G = 4.5  |error| <= 2.6e-5 (at the clamp: gelu(-4.5) = -1.5e-5 -> 0), rms 1.6e-6, 2.9 % one-ulp
+//   SYN3R_GELU_DEG 9                 G = 4.5  |error| <= 3.7e-5, rms 7.6e-6, 8.4 % one-ulp
+//   SYN3R_GELU_DEG 8   (round 6)     G = 4.25 |error| <= 6.3e-5 (8.5e-5 at |g| = 8: 1e-5 relative), rms 1.7e-5, 15.9 % one-ulp
+// (weighted minimax fits, the weight = the tighter of fp16's half-ulp of gelu(+-g) and 1.5e-5; checked against scipy erf over
+// [-8, 8] in fp32 Horner arithmetic; rms over N(0, 1.5) gates, whose fp16 rounding noise is ~1e-4 rms: the lower degrees add
+// 0.01-3 % to the noise the fp16 output carries anyway.  The parity decision rests on the reference fixtures)
+#ifndef SYN3R_GELU_DEG
+#define SYN3R_GELU_DEG 8
+#endif
 typedef float syn3r_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ syn3r_f2 gelu_pk(syn3r_f2 g) {
-    const syn3r_f2 gc = (syn3r_f2){__builtin_amdgcn_fmed3f(g.x, -5.0f, 5.0f), __builtin_amdgcn_fmed3f(g.y, -5.0f, 5.0f)};
-    const syn3r_f2 t = gc * gc * 0.08f - 1.0f;
-    syn3r_f2 a = t * 7.695898276e-04f + -1.685841001e-03f;
-    a = a * t + 1.275028536e-03f;
-    a = a * t + -2.503029935e-03f;
-    a = a * t + 6.874790886e-03f;
-    a = a * t + -1.132975735e-02f;
-    a = a * t + 1.618207803e-02f;
-    a = a * t + -2.320382084e-02f;
-    a = a * t + 3.148886876e-02f;
-    a = a * t + -4.045282865e-02f;
-    a = a * t + 5.151694415e-02f;
-    a = a * t + -7.029583794e-02f;
-    a = a * t + 1.413638313e-01f;
+#if SYN3R_GELU_DEG == 12
+    constexpr float G = 5.0f, SC = 0.08f;
+    constexpr float c[13] = {1.413638313e-01f, -7.029583794e-02f, 5.151694415e-02f, -4.045282865e-02f, 3.148886876e-02f,
+                             -2.320382084e-02f, 1.618207803e-02f, -1.132975735e-02f, 6.874790886e-03f, -2.503029935e-03f,
+                             1.275028536e-03f, -1.685841001e-03f, 7.695898276e-04f};
+#elif SYN3R_GELU_DEG == 10
+    constexpr float G = 4.5f, SC = 0.09876543209876543f;
+    constexpr float c[11] = {1.569051000e-01f, -7.719027244e-02f, 5.468925326e-02f, -4.017315754e-02f, 2.841398309e-02f,
+                             -1.872261455e-02f, 1.095662898e-02f, -5.753943520e-03f, 3.429505493e-03f, -2.064591753e-03f,
+                             6.205179385e-04f};
+#elif SYN3R_GELU_DEG == 9
+    constexpr float G = 4.5f, SC = 0.09876543209876543f;
+    constexpr float c[10] = {1.569051204e-01f, -7.718434032e-02f, 5.468310931e-02f, -4.028949651e-02f, 2.852618328e-02f,
+                             -1.812994075e-02f, 1.038848351e-02f, -6.836305825e-03f, 4.474478846e-03f, -1.427198998e-03f};
+#elif SYN3R_GELU_DEG == 8
+    constexpr float G = 4.25f, SC = 0.11072664359861592f;
+    constexpr float c[9] = {1.659352130e-01f, -8.078260179e-02f, 5.572614317e-02f, -3.908646575e-02f, 2.530956491e-02f,
+                            -1.488701428e-02f, 9.392296479e-03f, -5.790942058e-03f, 1.829005353e-03f};
+#else
+#error "SYN3R_GELU_DEG must be 8, 9, 10 or 12"
+#endif
+    const syn3r_f2 gc = (syn3r_f2){__builtin_amdgcn_fmed3f(g.x, -G, G), __builtin_amdgcn_fmed3f(g.y, -G, G)};
+    const syn3r_f2 t = gc * gc * SC - 1.0f;
+    syn3r_f2 a = t * c[SYN3R_GELU_DEG] + c[SYN3R_GELU_DEG - 1];
+#pragma unroll
+    for (int k = SYN3R_GELU_DEG - 2; k >= 0; --k) a = a * t + c[k];
     return g * (gc * a + 0.5f);
 }

@@ -10,8 +10,16 @@ if str(ROOT) not in sys.path:
 GOLDEN = ROOT / "tests" / "golden"
 
 
+def pytest_addoption(parser):
+    parser.addoption("--syn3r-lib", default=None,
+                     help="developer A/B: run the suite against another BUILD of libsyn3r_hip.so (tools/build_variant.sh)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if config.getoption("--syn3r-lib"):
+        from syn3r_amd import _lib
+        _lib.set_library_path(config.getoption("--syn3r-lib"))
 
 
 @pytest.fixture(scope="session")

@@ -71,7 +71,9 @@ def test_product_does_not_import_oracle():
 def test_library_reads_no_environment():
     """include/syn3r_hip.h: the shipped library has no process-wide switches.  The sources call getenv only inside
     `#ifdef SYN3R_TUNING` (developer builds), the built library does not import it, and the Python host reads the environment
-    only for the developer library override and the torchrun rank variables."""
+    only for the build's compiler flags and the torchrun rank variables - in particular NOT for the path of the library it loads
+    (a stray SYN3R_LIB_OVERRIDE used to swap the whole library; another build is now named by an explicit
+    `_lib.set_library_path()` call from tools/_devlib.py or the `--syn3r-lib` pytest option)."""
     import shutil
     import subprocess
     csrc = ROOT / "syn3r_amd" / "csrc"
@@ -95,7 +97,7 @@ def test_library_reads_no_environment():
     if nm and so.exists():
         out = subprocess.run([nm, "-D", "--undefined-only", str(so)], capture_output=True, text=True, check=True).stdout
         assert "getenv" not in out
-    allowed = {"SYN3R_LIB_OVERRIDE", "SYN3R_EXTRA_HIPCC_FLAGS", "HIPCC", "RANK", "WORLD_SIZE", "LOCAL_RANK"}
+    allowed = {"SYN3R_EXTRA_HIPCC_FLAGS", "HIPCC", "RANK", "WORLD_SIZE", "LOCAL_RANK"}
     for p in (ROOT / "syn3r_amd").rglob("*.py"):
         if p.name == "tuning.py":          # from_env(): called by tools/ only
             continue
@@ -104,3 +106,12 @@ def test_library_reads_no_environment():
     for p in (ROOT / "syn3r_amd").rglob("*.py"):
         if p.name != "tuning.py":
             assert "from_env" not in p.read_text(), p
+        assert "SYN3R_LIB_OVERRIDE" not in p.read_text(), p
+    # and the loader really ignores it
+    import os
+    import subprocess as sp
+    import sys
+    env = dict(os.environ, SYN3R_LIB_OVERRIDE="/nonexistent/libsyn3r_hip.so")
+    r = sp.run([sys.executable, "-c", "from syn3r_amd import _lib; print(_lib.lib_path())"], env=env, cwd=str(ROOT),
+               capture_output=True, text=True, check=True)
+    assert r.stdout.strip() == str(so), r.stdout

@@ -9,6 +9,7 @@ ROOT = Path(__file__).resolve().parents[1]
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path.insert(0, str(ROOT))
     import torch
+    import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
     from syn3r_amd.unet import ops
     dev = torch.device("cuda", 0)
     H = torch.float16

@@ -4,6 +4,7 @@ import json, sys, tempfile
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
+import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
 from syn3r_amd import measure as M
 
 dev = torch.device("cuda", 0)

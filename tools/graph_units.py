@@ -3,6 +3,7 @@ import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
+import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
 from syn3r_amd import tuning; tuning.from_env()      # developer tool: host-graph switches from SYN3R_* variables
 from syn3r_amd.pipeline.svd_step import SvdStepBench
 

@@ -4,6 +4,7 @@ from pathlib import Path
 from types import SimpleNamespace
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np, torch
+import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
 from syn3r_amd import measure as M
 from syn3r_amd.diffusionGS import DiffusionGS
 

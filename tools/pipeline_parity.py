@@ -7,6 +7,7 @@ import numpy as np
 import torch
 from oracle import pipeline_mocks as PM
 from oracle import unet_weights as UW
+import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
 from syn3r_amd.pipeline.svd_2pass import StableVideoDiffusionPipeline
 from syn3r_amd.schedulers.scheduling_euler_discrete import SVD_XT_SCHEDULER_CONFIG, EulerDiscreteScheduler
 from syn3r_amd.unet.model import UNetSpatioTemporalConditionModel

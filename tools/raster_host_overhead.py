@@ -4,6 +4,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 import bench
+import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
 from syn3r_amd import raster
 args = types.SimpleNamespace(gaussians=200000, height=1080, width=1920, seed=1234)
 dev = torch.device("cuda", 0)

@@ -12,6 +12,7 @@ loop = bench.RasterLoop(args, torch.device("cuda", 0))
 for _ in range(n):
     loop.iteration()
 torch.cuda.synchronize()
+import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
 from syn3r_amd import raster
 raster.flush_pair_checks()
 print("ok")

@@ -7,6 +7,7 @@ from types import SimpleNamespace
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
 import torch
+import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
 from syn3r_amd import orchestrator as O
 from syn3r_amd.pipeline.svd_2pass import StableVideoDiffusionPipeline
 from syn3r_amd.schedulers.scheduling_euler_discrete import EulerDiscreteScheduler, SVD_XT_SCHEDULER_CONFIG

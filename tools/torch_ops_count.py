@@ -6,6 +6,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from torch.profiler import profile, ProfilerActivity
 import bench as B
+import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
 from syn3r_amd.pipeline.svd_step import SvdStepBench
 
 dev = torch.device("cuda", 0)

@@ -6,6 +6,7 @@ import time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
+import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
 from syn3r_amd import _lib as L, measure, raster
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20

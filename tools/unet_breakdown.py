@@ -3,10 +3,9 @@ import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
+import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
 from syn3r_amd import _lib as L
 import os
-if os.environ.get("SYN3R_LIB_OVERRIDE"):      # A/B against another build of the library
-    L._LIB_PATH = Path(os.environ["SYN3R_LIB_OVERRIDE"]).resolve()
 from syn3r_amd.pipeline.svd_step import SvdStepBench
 if os.environ.get("SYN3R_SET_TILE"):          # force a contraction kernel family (syn3r_gemm_set_tile), tuning runs
     L.load().syn3r_gemm_set_tile(int(os.environ["SYN3R_SET_TILE"]))

@@ -7,6 +7,7 @@ for kv in sys.argv[2:]:
     k, v = kv.split("=", 1)
     os.environ[k] = v
 import torch
+import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
 from syn3r_amd.pipeline.svd_step import SvdStepBench
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 14
 b = SvdStepBench(F, torch.device("cuda", 0))

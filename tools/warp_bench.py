@@ -5,6 +5,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
 import torch
+import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
 from syn3r_amd import _lib as L
 from syn3r_amd.solver_utils.consistency import consistency_check_with_depth
 from syn3r_amd.solver_utils.forward_warp import forward_warp, inverse_warp, inverse_warp_batch

@@ -7,6 +7,7 @@ import ctypes, os, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
+import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
 from syn3r_amd.unet import ops
 from syn3r_amd import _lib
 dev = torch.device("cuda", 0)
