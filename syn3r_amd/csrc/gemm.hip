@@ -22,6 +22,7 @@
 //   k_lnlin320     LayerNorm + stacked q / k / v projection for C = 320 in one kernel
 //   k_gemm_dma     BM x 160 tile, LDS-DMA 3-stage ring (BM = 256, wavefronts 4-7 staggered; every convolution /
 //                  temporal convolution and the K = 320 residual projections) or 2-stage (BM = 128, small grids)
+//   k_gemm_dmapd   persistent 256 x 160 tile with a deferred, LDS-free epilogue (gemm_dmapd.h): residual projections, 640 <= K <= 1280
 //   k_gemm_skinny  M <= 16 rows (time embedding, folded cross-attention context)
 // This file is the dispatch: the shape rules (launch_dma), the launchers and the C-ABI entry points; the kernel families live in
 // gemm_common.h / gemm_dma.h / gemm_wide.h / gemm_z.h / gemm_dmap.h / gemm_ffn.h, included below into ONE translation unit.
@@ -40,6 +41,7 @@ namespace {
 #include "gemm_wide.h"
 #include "gemm_z.h"
 #include "gemm_dmap.h"
+#include "gemm_dmapd.h"
 #include "gemm_ffn.h"
 
 // grid of the persistent kernels: the CU count of the CURRENT device (queried once per device; SYN3R_PERSISTENT_BLOCKS overrides
@@ -149,6 +151,31 @@ bool widep_admits(const GemmParams& p) {
 // 160-column LDS-DMA kernel of that block height, -320 = the persistent 256 x 320 kernel k_gemm_widep wherever it admits the
 // shape, -322 = the software-pipelined 256 x 320 kernel k_gemm_z (dense, two-source, convolutions).  thread_local: no state shared between host threads.
 
+int launch_dmapd(const GemmParams& p, hipStream_t stream) {
+    constexpr size_t lds = (size_t)3 * (256 * BK * 2 + DMA_B_BYTES);   // 159,744 B
+    static DevOnce once;
+    if (int rc = set_max_lds(once, (const void*)k_gemm_dmapd, (int)lds, "hipFuncSetAttribute(gemm_dmapd)")) return rc;
+    const int tiles = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+    const int blocks = std::min(tiles, persistent_blocks());
+    char name[96];
+    if (trace_on()) {
+        if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_dmapd[M%d,N%d,K%d,e%d]", p.M, p.N, p.K, p.residual != nullptr);
+        else snprintf(name, sizeof(name), "k_gemm_dmapd");
+    }
+    SYN3R_LAUNCH_NAMED(name, k_gemm_dmapd, dim3(blocks), dim3(512), lds, stream, p);
+    SYN3R_LAUNCH_CHECK("gemm_dmapd launch");
+    return SYN3R_OK;
+}
+
+// Does the deferred-epilogue kernel take this contraction?  Dense, row-major output, WHOLE 256 x 160 tiles (no row / column clamps in
+// the kernel: what the UNet launches at full frames), at least four k-tiles (a k-tile carries at most one of the parked tile's four
+// units), a residual only with 16-byte aligned rows, no aux blend.
+bool dmapd_admits(const GemmParams& p) {
+    return p.geglu_D <= 0 && !p.A2 && !p.a_tiled && !p.out_tiled && !p.out_nt && !p.relu && !p.relu_mask && p.ksplit <= 1 && !p.aux &&
+           !p.res_add && p.M % 256 == 0 && p.N % BN == 0 && p.K / BK >= 4 && p.ldc % 8 == 0 && (!p.residual || p.ldr % 8 == 0) &&
+           (!p.rowvec || p.ldrv % 4 == 0);
+}
+
 template <int MODE>
 int launch_dmap(const GemmParams& p, hipStream_t stream) {
     constexpr size_t lds = (size_t)3 * (256 * BK * 2 + DMA_B_BYTES);   // 159,744 B
@@ -234,6 +261,18 @@ int launch_splitk(const GemmParams& p, hipStream_t stream, bool* done) {
 template <int MODE>
 int launch_dma(const GemmParams& p, hipStream_t stream) {
     static const int wide_env = tune_env("SYN3R_GEMM_WIDE", -1);       // -1 = by shape, 0 = never, 1 = always (tuning builds)
+    if constexpr (MODE == MODE_DENSE) {
+        // Round 6: the residual projections with 640 <= K <= 1280 (attn1 / attn2 to_out, proj_out at levels 1-2: [64512,640,640],
+        // [16128,1280,1280]) spend as long in their epilogue as in their k-loop on the 256 x 320 tile; k_gemm_dmapd parks the result
+        // and runs the residual loads / adds / stores inside the next tile's k-loop: -8 % on exactly these shapes inside the unit, same
+        // box (profiles/r05/dmapd_deferred_epilogue.txt; K = 320 +-0 and the projections WITHOUT a residual 0..+7 % slower: they stay;
+        // [16128,1280,1280] without a residual -11 %: taken).  SYN3R_DMAPD_WIDE=0: never; 2: every admissible K <= 1280 shape.
+        static const int ddw_env = tune_env("SYN3R_DMAPD_WIDE", 1);
+        const bool won = p.residual ? (p.K >= 640 && p.K <= 1280 && p.N <= 1280) : (p.K == 1280 && p.N == 1280);
+        if (ddw_env != 0 && g_dma_bm == 0 && (ddw_env == 2 ? p.K <= 1280 : won) && dmapd_admits(p) &&
+            (long long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN) >= 256)
+            return launch_dmapd(p, stream);
+    }
     const bool wide_ok = MODE == MODE_DENSE && widep_admits(p);
     if (g_dma_bm == -320 && wide_ok) return launch_widep(p, stream);                              // syn3r_gemm_set_tile(-320)
     if (g_dma_bm == -322 && wide_ok) return launch_z<MODE_DENSE>(p, stream);                      // syn3r_gemm_set_tile(-322)

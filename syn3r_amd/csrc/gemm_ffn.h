@@ -45,7 +45,9 @@ __device__ __forceinline__ void ln_tile320(char* smem_raw, int tid, int m0, int 
     // LayerNorm of the resident x tile (attention.py:430-453: norm3 in front of ff), so that the normalised activation is never
     // written to / re-read from HBM.  Same arithmetic, same order of additions as k_layernorm<8> (norm.hip): 8 partial sums per
     // row over the 16-byte chunks c, c + 8, ..., combined by the xor tree 4, 2, 1 - here four threads per row hold two of the
-    // eight each.  The tile is five [128 x 64] k-tile images with the chunk index XOR-swizzled by the row.
+    // eight each: sub-lanes part and part + 4 (round 6; rounds 4-5 held 2 part and 2 part + 1, whose four threads per row read the
+    // EVEN chunks of a k-tile in one ds_read_b128 - two of the four rows a 16-lane group covers then share their banks whatever the
+    // row swizzle: the 2-way conflict of profiles/r05/pmc; chunks part / part + 4 put a group's rows on disjoint bank quarters).
     {
         const int r = tid >> 2, part = tid & 3;
         half8 xv[5][2], addv[5][2];
@@ -56,7 +58,7 @@ __device__ __forceinline__ void ln_tile320(char* smem_raw, int tid, int m0, int 
 #pragma unroll
             for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) addv[kt][e] = *(const half8*)(av + (kt * 8 + part * 2 + e) * 8);
+                for (int e = 0; e < 2; ++e) addv[kt][e] = *(const half8*)(av + (kt * 8 + part + 4 * e) * 8);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -65,7 +67,7 @@ __device__ __forceinline__ void ln_tile320(char* smem_raw, int tid, int m0, int 
         for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
             for (int e = 0; e < 2; ++e)
-                xv[kt][e] = *(const half8*)(smem_raw + kt * 16384 + r * 128 + (((part * 2 + e) ^ (r & 7)) << 4));
+                xv[kt][e] = *(const half8*)(smem_raw + kt * 16384 + r * 128 + (((part + 4 * e) ^ (r & 7)) << 4));
         if (add) {       // norm_in of the temporal block normalises hidden + frame-position embedding (attention.py:500-507)
 #pragma unroll
             for (int kt = 0; kt < 5; ++kt)
@@ -76,10 +78,11 @@ __device__ __forceinline__ void ln_tile320(char* smem_raw, int tid, int m0, int 
         for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
             for (int i = 0; i < 8; ++i) { sa += (float)xv[kt][0][i]; sb += (float)xv[kt][1][i]; }
-        sa += __shfl_xor(sa, 2, 64); sb += __shfl_xor(sb, 2, 64);
-        sa += __shfl_xor(sa, 1, 64); sb += __shfl_xor(sb, 1, 64);
+        float s = sa + sb;                                   // xor 4: sub-lanes part and part + 4 live in this thread
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
         // cf = 320 as a run-time value: the same division k_layernorm compiles to
-        const float mean = (sa + sb) / cf;
+        const float mean = s / cf;
         float qa = 0.f, qb = 0.f;
         {
 #pragma clang fp contract(off)      // k_layernorm's squares are a packed multiply followed by adds, not an fma: the same bits here
@@ -92,19 +95,20 @@ __device__ __forceinline__ void ln_tile320(char* smem_raw, int tid, int m0, int 
                     qa += da2; qb += db2;
                 }
         }
-        qa += __shfl_xor(qa, 2, 64); qb += __shfl_xor(qb, 2, 64);
-        qa += __shfl_xor(qa, 1, 64); qb += __shfl_xor(qb, 1, 64);
-        const float rstd = rsqrtf((qa + qb) / cf + ln_eps);
+        float qq = qa + qb;
+        qq += __shfl_xor(qq, 2, 64);
+        qq += __shfl_xor(qq, 1, 64);
+        const float rstd = rsqrtf(qq / cf + ln_eps);
 #pragma unroll
         for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int cv = kt * 8 + part * 2 + e;
+                const int cv = kt * 8 + part + 4 * e;
                 const half8 g = *(const half8*)(ln_g + cv * 8), b = *(const half8*)(ln_b + cv * 8);
                 half8 o;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = (_Float16)(((float)xv[kt][e][i] - mean) * rstd * (float)g[i] + (float)b[i]);
-                *(half8*)(smem_raw + kt * 16384 + r * 128 + (((part * 2 + e) ^ (r & 7)) << 4)) = o;
+                *(half8*)(smem_raw + kt * 16384 + r * 128 + (((part + 4 * e) ^ (r & 7)) << 4)) = o;
             }
         __syncthreads();
     }
@@ -545,7 +549,19 @@ __global__ void __launch_bounds__(512, 2) k_lnlin320(LnLinParams p) {
     const unsigned x_row = lds0 + (unsigned)((wm * 64 + fr) * 128);                       // + kt * 16384 + i * 2048 + sw
     const unsigned w_row = (unsigned)((wn * 80 + fr) * 64) + (unsigned)((fq ^ h_swz(fr)) << 4);   // inside a slot, + j * 1024
     const unsigned st_base = lds0 + Q_ST + (unsigned)(wv * Q_ST_WAVE);
-    const unsigned st_wr = st_base + (unsigned)(fr * (WN * 2) + fq * 8);                  // + j * 32
+    // Staging writes (round 6): a 16-lane group of a ds_write_b64 is 16 rows of ONE column position; at the 160-byte row pitch they
+    // fall on four bank pairs - the 4-way conflict that was 12.3 M of this kernel's 38.3 M LDS cycles (profiles/r05/pmc).  Row r
+    // keeps its ten 16-byte chunks ROTATED by r positions ((chunk + r) mod 10): eight bank groups per 16 rows, 2-way (an 8-byte
+    // store cannot do better at a 16-byte-aligned pitch); the read-back takes whole rows as before and un-rotates the column.
+    unsigned st_wr[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) st_wr[j] = st_base + (unsigned)(fr * (WN * 2) + ((j * 2 + (fq >> 1) + fr) % 10) * 16 + (fq & 1) * 8);
+    int st_col[3];                       // column (halfs) of the chunk this lane reads back in round it: position q = lane + 64 it
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int q = lane + it * 64, row = q / (WN / 8), chp = q - row * (WN / 8);
+        st_col[it] = ((chp + 20 - row) % 10) * 8;
+    }
     typedef _Float16 half4e __attribute__((ext_vector_type(4)));
 
     int cslot = 0, g = 0;
@@ -610,7 +626,7 @@ __global__ void __launch_bounds__(512, 2) k_lnlin320(LnLinParams p) {
                 half4e o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (_Float16)acc[i][j][r];
-                DS_WRITE64(st_wr + (unsigned)(j * 32), o);
+                DS_WRITE64(st_wr[j], o);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -623,9 +639,9 @@ __global__ void __launch_bounds__(512, 2) k_lnlin320(LnLinParams p) {
 #pragma unroll
             for (int it = 0; it < 3; ++it) {
                 const int q = lane + it * 64;
-                const int row = q / (WN / 8), ch = q - row * (WN / 8);
+                const int row = q / (WN / 8);
                 const int m = m0 + wm * WM + i * 16 + row;
-                if (q < 16 * (WN / 8) && m < p.M) *(half8*)(orow + (long long)m * p.ldc + ch * 8) = v[it];
+                if (q < 16 * (WN / 8) && m < p.M) *(half8*)(orow + (long long)m * p.ldc + st_col[it]) = v[it];
             }
         }
     }
