@@ -459,6 +459,30 @@ int syn3r_groupnorm_f16(const void* x, void* y, int samples, int rows, int C, co
 int syn3r_groupnorm_2src_f16(const void* x1, int C1, const void* x2, int C2, void* y, int samples, int rows,
                              const void* gamma, const void* beta, float eps, int silu, void* workspace,
                              size_t workspace_bytes, void* stream);
+/*
+ * GroupNorm statistics out of the PRODUCER's epilogue (round 6).  Every GroupNorm input of the UNet is the output of a
+ * contraction (resnet.py:272,286,574,588: conv1 + temb -> norm2, conv2 + shortcut -> the temporal norm1, the AlphaBlender
+ * output -> the next norm1; transformer_temporal.py:235), whose epilogue holds the values in registers: the statistics
+ * pass over the activation (one full extra read) is not launched.
+ *
+ * syn3r_gemm_set_gn_partials(buf, bytes): the NEXT contraction the calling thread launches through syn3r_gemm_f16 /
+ * syn3r_gemm_2src_f16 / syn3r_conv2d3x3_f16 / syn3r_tconv3_f16 also writes, for its [M, N] fp16 output as stored,
+ *     buf[((m / 32) * 2 + q) * (N / 10) + n / 10]   (float; q = 0: sum of x, q = 1: sum of x^2)
+ * over rows [32 rb, 32 rb + 32) and columns [10 u, 10 u + 10) - if M % 32 == 0, N % 80 == 0, bytes >=
+ * syn3r_gn_partials_bytes(M, N) and the kernel chosen for the shape has the lean epilogue (the persistent 256-row
+ * kernels).  The request is consumed by that one call (thread_local, like the split-K workspace; nothing is shared between
+ * host threads).  syn3r_gemm_gn_partials_written() tells whether the calling thread's LAST contraction wrote them; if not,
+ * the consumer runs syn3r_groupnorm_f16 as before.  Fixed summation order: bitwise reproducible run to run.
+ *
+ * syn3r_groupnorm_pre_f16: syn3r_groupnorm_f16 / _2src_f16 (x2 = NULL, C2 = 0: one source) with the statistics folded from
+ * such partial sums (part1 for x1, part2 for x2).  rows % 32 == 0, (C1 + C2) / 32 and C1 multiples of 10.  Same workspace.
+ */
+size_t syn3r_gn_partials_bytes(int M, int N);
+int syn3r_gemm_set_gn_partials(void* partials, size_t bytes);
+int syn3r_gemm_gn_partials_written(void);
+int syn3r_groupnorm_pre_f16(const void* x1, int C1, const void* part1, const void* x2, int C2, const void* part2, void* y,
+                            int samples, int rows, const void* gamma, const void* beta, float eps, int silu,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * LayerNorm over C of [M, C] fp16.  If addvec != NULL, addvec[m / rows_per_vec, :] is added first

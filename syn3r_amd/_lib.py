@@ -84,6 +84,10 @@ SIGNATURES = {
     "syn3r_groupnorm_workspace_bytes": (c_sz, [c_i, c_i]),
     "syn3r_groupnorm_f16": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_p, c_sz, c_p]),
     "syn3r_groupnorm_2src_f16": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_f, c_i, c_p, c_sz, c_p]),
+    "syn3r_groupnorm_pre_f16": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_f, c_i, c_p, c_sz, c_p]),
+    "syn3r_gn_partials_bytes": (c_sz, [c_i, c_i]),
+    "syn3r_gemm_set_gn_partials": (c_i, [c_p, c_sz]),
+    "syn3r_gemm_gn_partials_written": (c_i, []),
     "syn3r_gemm_2src_supported": (c_i, [c_i, c_i, c_i, c_i, c_ll, c_ll]),
     "syn3r_gemm_2src_f16": (c_i, [c_p, c_ll, c_i, c_p, c_ll, c_i, c_p, c_p, c_ll, c_p, c_i, c_i, c_p]),
     "syn3r_layernorm_f16": (c_i, [c_p, c_p, c_p, c_p, c_i, c_ll, c_i, c_p, c_p, c_f, c_p]),

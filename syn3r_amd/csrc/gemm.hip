@@ -62,6 +62,23 @@ int persistent_blocks() {
     return n;
 }
 
+// GroupNorm partial sums (GemmParams::gn_part) of the CALLING THREAD's next contraction (syn3r_gemm_set_gn_partials): the entry
+// points move the pending buffer into the launch's parameters (gn_take), the launchers of the kernels with the lean epilogue
+// report that they wrote it (syn3r_gemm_gn_partials_written); every other kernel leaves it untouched and the caller runs the
+// statistics pass.
+thread_local void* g_gn_pending = nullptr;
+thread_local size_t g_gn_pending_bytes = 0;
+thread_local bool g_gn_written = false;
+size_t gn_partials_bytes(long long M, long long N) { return (size_t)(M / 32) * 2 * (size_t)(N / 10) * sizeof(float); }
+void gn_take(GemmParams& p) {
+    g_gn_written = false;
+    void* buf = g_gn_pending;
+    const size_t bytes = g_gn_pending_bytes;
+    g_gn_pending = nullptr; g_gn_pending_bytes = 0;
+    if (!buf || p.M % 32 != 0 || p.N % 80 != 0 || p.geglu_D > 0 || p.out_tiled || bytes < gn_partials_bytes(p.M, p.N)) return;
+    p.gn_part = (float*)buf; p.gn_units = p.N / 10;
+}
+
 // Tile columns per band of the persistent 256 x 320 kernels' tile order (bands of `band` tile columns, row-major inside a band: the
 // 32 tiles an XCD holds at a time are ~32 / band rows x band columns).  A narrower band re-reads A more often from beyond the L2
 // (once per band) but keeps the band's weight panel (band x 320 x K x 2 B) well inside the 4 MB L2.  Measured
@@ -91,6 +108,7 @@ int launch_widep(const GemmParams& p, hipStream_t stream) {
     q.band = band_width(p);
     SYN3R_LAUNCH_NAMED(name, k_gemm_widep, dim3(blocks), dim3(512), lds, stream, q);
     SYN3R_LAUNCH_CHECK("gemm_widep launch");
+    g_gn_written = p.gn_part != nullptr;
     return SYN3R_OK;
 }
 
@@ -111,13 +129,14 @@ int launch_z(const GemmParams& p, hipStream_t stream) {
         else snprintf(name, sizeof(name), "k_gemm_z<%d>", MODE);
     }
     if constexpr (MODE == MODE_DENSE) {
-        if (p.A2) { SYN3R_LAUNCH_NAMED(name, (k_gemm_z<true, MODE_DENSE>), dim3(blocks), dim3(512), Z_LDS, stream, p_); SYN3R_LAUNCH_CHECK("gemm_z launch"); return SYN3R_OK; }
+        if (p.A2) { SYN3R_LAUNCH_NAMED(name, (k_gemm_z<true, MODE_DENSE>), dim3(blocks), dim3(512), Z_LDS, stream, p_); SYN3R_LAUNCH_CHECK("gemm_z launch"); g_gn_written = p.gn_part != nullptr; return SYN3R_OK; }
     }
     if constexpr (MODE == MODE_CONV2D) {
-        if (p.ups) { SYN3R_LAUNCH_NAMED(name, (k_gemm_z<false, MODE_CONV2D, true>), dim3(blocks), dim3(512), Z_LDS, stream, p_); SYN3R_LAUNCH_CHECK("gemm_z launch"); return SYN3R_OK; }
+        if (p.ups) { SYN3R_LAUNCH_NAMED(name, (k_gemm_z<false, MODE_CONV2D, true>), dim3(blocks), dim3(512), Z_LDS, stream, p_); SYN3R_LAUNCH_CHECK("gemm_z launch"); g_gn_written = p.gn_part != nullptr; return SYN3R_OK; }
     }
     SYN3R_LAUNCH_NAMED(name, (k_gemm_z<false, MODE>), dim3(blocks), dim3(512), Z_LDS, stream, p_);
     SYN3R_LAUNCH_CHECK("gemm_z launch");
+    g_gn_written = p.gn_part != nullptr;
     return SYN3R_OK;
 }
 
@@ -197,6 +216,7 @@ int launch_dmap(const GemmParams& p, hipStream_t stream) {
     }
     SYN3R_LAUNCH_NAMED(name, (k_gemm_dmap<MODE>), dim3(blocks), dim3(512), lds, stream, q);
     SYN3R_LAUNCH_CHECK("gemm_dmap launch");
+    g_gn_written = p.gn_part != nullptr;
     return SYN3R_OK;
 }
 
@@ -269,7 +289,9 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
         // [16128,1280,1280] without a residual -11 %: taken).  SYN3R_DMAPD_WIDE=0: never; 2: every admissible K <= 1280 shape.
         static const int ddw_env = tune_env("SYN3R_DMAPD_WIDE", 1);
         const bool won = p.residual ? (p.K >= 640 && p.K <= 1280 && p.N <= 1280) : (p.K == 1280 && p.N == 1280);
-        if (ddw_env != 0 && g_dma_bm == 0 && (ddw_env == 2 ? p.K <= 1280 : won) && dmapd_admits(p) &&
+        // (a launch asked for GroupNorm partial sums - proj_out, 5 of these 15 launches per level - keeps the lean epilogue, which
+        // writes them: the statistics pass it saves costs more than the deferred epilogue gains)
+        if (ddw_env != 0 && g_dma_bm == 0 && !p.gn_part && (ddw_env == 2 ? p.K <= 1280 : won) && dmapd_admits(p) &&
             (long long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN) >= 256)
             return launch_dmapd(p, stream);
     }
@@ -356,6 +378,21 @@ extern "C" int syn3r_gemm_set_splitk_workspace(void* workspace, size_t bytes) {
     return SYN3R_OK;
 }
 
+extern "C" size_t syn3r_gn_partials_bytes(int M, int N) {
+    if (!SYN3R_DIM_OK(M) || !SYN3R_DIM_OK(N) || M % 32 != 0 || N % 80 != 0) return 0;
+    return gn_partials_bytes(M, N);
+}
+
+extern "C" int syn3r_gemm_set_gn_partials(void* partials, size_t bytes) {
+    SYN3R_REQUIRE((partials == nullptr) == (bytes == 0), "gemm_set_gn_partials: pointer and size must both be given or both be zero");
+    SYN3R_REQUIRE(((uintptr_t)partials % 16) == 0, "gemm_set_gn_partials: the buffer must be 16-byte aligned");
+    g_gn_pending = partials;
+    g_gn_pending_bytes = bytes;
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_gemm_gn_partials_written(void) { return g_gn_written ? 1 : 0; }
+
 extern "C" int syn3r_gemm_set_tile(int bm) {
     SYN3R_REQUIRE(bm == 0 || bm == -128 || bm == -256 || bm == -320 || bm == -322, "gemm_set_tile: bm must be 0, -128, -256, -320 or -322");
     g_dma_bm = (bm == -128 || bm == -256) ? -bm : bm;        // this thread's launches only (thread_local)
@@ -435,6 +472,7 @@ extern "C" int syn3r_gemm_f16(const void* A, long long lda, const void* W, void*
     p.rv_group = rv_group_rows;
     p.residual = (const __half*)residual; p.ldr = ldr; p.aux = (const __half*)aux; p.ldaux = ldaux;
     p.s_acc = s_acc; p.s_res = s_res; p.s_aux = s_aux; p.M = M; p.N = N; p.K = K;
+    gn_take(p);
     int rc = check_common(p, "gemm_f16");
     if (rc) return rc;
     SYN3R_REQUIRE(lda % 8 == 0 && lda >= K, "gemm_f16: lda=%lld must be >= K and a multiple of 8", lda);
@@ -450,6 +488,7 @@ extern "C" int syn3r_gemm_2src_f16(const void* A1, long long lda1, int K1, const
     p.A = (const __half*)A1; p.lda = lda1; p.A2 = (const __half*)A2; p.lda2 = lda2; p.K1 = K1;
     p.W = (const __half*)W; p.out = (__half*)out; p.ldc = ldc; p.bias = (const __half*)bias;
     p.s_acc = 1.0f; p.s_res = 1.0f; p.s_aux = 1.0f; p.M = M; p.N = N; p.K = K1 + K2;
+    gn_take(p);
     int rc = check_common(p, "gemm_2src_f16");
     if (rc) return rc;
     SYN3R_REQUIRE(lda1 % 8 == 0 && lda1 >= K1 && lda2 % 8 == 0 && lda2 >= K2 && ((uintptr_t)A2 % 16) == 0, "gemm_2src: bad strides / alignment");
@@ -614,6 +653,7 @@ extern "C" int syn3r_conv2d3x3_f16(const void* X, const void* W, void* out, long
     long long M = (long long)NB * p.Ho * p.Wo;
     SYN3R_REQUIRE(M < (1ll << 31), "conv2d3x3: too many output pixels");
     p.M = (int)M; p.N = Cout; p.K = 9 * Cin;
+    gn_take(p);
     int rc = check_common(p, "conv2d3x3");
     if (rc) return rc;
     return launch<MODE_CONV2D>(p, (hipStream_t)stream);
@@ -652,6 +692,7 @@ extern "C" int syn3r_tconv3_f16(const void* X, const void* W, void* out, long lo
     long long M = (long long)B * F * HW;
     SYN3R_REQUIRE(M < (1ll << 31), "tconv3: too many rows");
     p.M = (int)M; p.N = Cout; p.K = 3 * Cin;
+    gn_take(p);
     int rc = check_common(p, "tconv3");
     if (rc) return rc;
     return launch<MODE_TCONV>(p, (hipStream_t)stream);

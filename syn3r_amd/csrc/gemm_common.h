@@ -72,6 +72,12 @@ struct GemmParams {
     int ksplit; float* split_ws;
     int relu;                             // result = max(result, 0)
     const __half* relu_mask;              // [M][ldc]: result zeroed where mask <= 0 (ReLU backward: grad * (activation > 0))
+    // GroupNorm partial sums of the OUTPUT (round 6; the lean epilogue of the persistent kernels, gn_tile_stats in gemm_wide.h):
+    // gn_part[((m / 32) * 2 + q) * gn_units + n / 10], q = 0: sum of x, q = 1: sum of x^2 over rows [32 rb, 32 rb + 32) and columns
+    // [10 u, 10 u + 10) of the fp16 results as stored.  Every GroupNorm(32) of the UNet has 10, 20, 30, 40, 60 or 80 channels per
+    // group (C = 320 .. 2560), so any consumer folds whole units; the statistics pass over the activation (k_gn_stats) is not
+    // launched (resnet.py:272,286,574,588, transformer_temporal.py:235).  null: not written.  Needs M % 32 == 0 and N % 80 == 0.
+    float* gn_part; int gn_units;
 };
 
 // element offset of (row m, column d) in the A-tiled layout of a matrix with D columns

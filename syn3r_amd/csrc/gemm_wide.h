@@ -39,6 +39,56 @@ __device__ unsigned long long g_wide_timing[64];
 // 64-row tile, 11,264 B of staging; NI = 2: half of it, 5,632 B): (+bias +row vector) * s_acc -> fp16 through the
 // wavefront's own LDS staging area `st` -> row-contiguous 16-byte stores (+ s_res * residual + s_aux * aux), row-major or
 // A-tiled.  N is the logical column count (a multiple of 8, so a 16-byte chunk is inside the matrix or outside it as a whole).
+// GroupNorm partial sums of a wavefront's staged output tile (GemmParams::gn_part): NI x 16 rows x 80 columns of FINAL fp16 values
+// in `st` (row stride EPI_LD).  A lane takes one row (NI = 4: row = lane; NI = 2: row = lane & 31 and the column half lane >> 5) and
+// reads it as 16-byte chunks (row stride 176 B: the 16 lanes of a read pass land on 16 different 16-byte bank groups), sums pairs of
+// neighbouring columns with v_dot2c_f32_f16 (x . (1, 1) and x . x: fp16 products are exact in fp32) into the 10-column unit the pair
+// belongs to (compile-time: pair p of the 40 pairs of a row is unit p / 5), then the 32 lanes of a half are folded: one
+// v_permlane16_swap + add per unit leaves the sums of x on the even 16-lane rows and the sums of x^2 on the odd ones, four DPP
+// row rotations finish each.  Fixed order throughout: bitwise reproducible.  ~140 (NI = 4) / ~70 vector instructions per call.
+template <int NI>
+__device__ __forceinline__ void gn_tile_stats(const GemmParams& p, const __half* st, int lane, int gm0, int gn0, int N) {
+    typedef _Float16 half2e __attribute__((ext_vector_type(2)));
+    constexpr int NU = NI == 4 ? 8 : 4, NC = NI == 4 ? 10 : 5;
+    const int row = NI == 4 ? lane : (lane & 31);
+    const int half_ = NI == 4 ? 0 : (lane >> 5);
+    float s[NU], q[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) { s[u] = 0.f; q[u] = 0.f; }
+    const half2e one = {(_Float16)1.0f, (_Float16)1.0f};
+    const __half* src = st + row * EPI_LD + half_ * 40;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const half8 v = *(const half8*)(src + c * 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const half2e pr = {v[2 * k], v[2 * k + 1]};
+            s[(4 * c + k) / 5] = __builtin_amdgcn_fdot2(pr, one, s[(4 * c + k) / 5], false);
+            q[(4 * c + k) / 5] = __builtin_amdgcn_fdot2(pr, pr, q[(4 * c + k) / 5], false);
+        }
+    }
+    float w[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {        // odd 16-lane rows of s <-> even rows of q: even rows own the sums, odd rows the sums of squares
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(s[u]), __float_as_int(q[u]), false, false);
+        w[u] = __int_as_float(r[0]) + __int_as_float(r[1]);
+        w[u] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w[u]), 0x128 /* row_ror:8 */, 0xF, 0xF, false));
+        w[u] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w[u]), 0x124 /* row_ror:4 */, 0xF, 0xF, false));
+        w[u] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w[u]), 0x122 /* row_ror:2 */, 0xF, 0xF, false));
+        w[u] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w[u]), 0x121 /* row_ror:1 */, 0xF, 0xF, false));
+    }
+    if ((lane & 15) == 0) {
+        const int rowp = lane >> 4;                                   // 0 / 2: sums, 1 / 3: sums of squares; 2, 3: the upper 32 lanes
+        const int m = gm0 + (NI == 4 ? 32 * (rowp >> 1) : 0);
+        const int n = gn0 + (NI == 4 ? 0 : 40 * (rowp >> 1));
+        if (m < p.M && n < N) {
+            float* dst = p.gn_part + ((size_t)(m >> 5) * 2 + (rowp & 1)) * (size_t)p.gn_units + n / 10;
+#pragma unroll
+            for (int u = 0; u < NU; u += 4) *(float4v*)(dst + u) = (float4v){w[u], w[u + 1], w[u + 2], w[u + 3]};
+        }
+    }
+}
+
 template <int NI>
 __device__ __forceinline__ void lean_store(const GemmParams& p, float4v (*acc)[TN], __half* st, int lane, int gm0,
                                            int gn0, int N, const __half* bias, const __half* residual, const __half* aux, bool full) {
@@ -110,6 +160,7 @@ __device__ __forceinline__ void lean_store(const GemmParams& p, float4v (*acc)[T
                     f += p.s_aux * (float)ax[it][e];
                     v[e] = (_Float16)f;
                 }
+                if (p.gn_part) *(half8*)(st + row * EPI_LD + ch * 8) = v;      // the statistics pass reads the values as stored
                 put(gm0 + row, gn0 + ch * 8, v);
             }
         }
@@ -128,6 +179,7 @@ __device__ __forceinline__ void lean_store(const GemmParams& p, float4v (*acc)[T
             half8 v = *(const half8*)(st + row * EPI_LD + ch * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] + p.s_res * (float)res[it][e]);
+            if (p.gn_part) *(half8*)(st + row * EPI_LD + ch * 8) = v;          // the statistics pass reads the values as stored
             put(gm0 + row, gn0 + ch * 8, v);
         }
     } else {
@@ -139,6 +191,10 @@ __device__ __forceinline__ void lean_store(const GemmParams& p, float4v (*acc)[T
         }
     }
     __builtin_amdgcn_wave_barrier();
+    if (p.gn_part) {                      // (wave-uniform)
+        gn_tile_stats<NI>(p, st, lane, gm0, gn0, N);
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 __device__ __forceinline__ void widep_store(const GemmParams& p, float4v (&acc)[TM][TN], char* epi, int lane, int wv, int gm0,

@@ -99,6 +99,42 @@ __global__ void __launch_bounds__(1024) k_gn_finalize(const float* __restrict__ 
     }
 }
 
+// (mean, rstd) per (sample, group) from the partial sums the PRODUCER of the activation left behind (GemmParams::gn_part, the lean
+// epilogue of the persistent contraction kernels; round 6): part[((m / 32) * 2 + q) * U + n / 10] over 32-row blocks and 10-column
+// units.  Two-source input: units [0, U1) come from part1, the rest from part2 (a group may straddle the two tensors: 1280 + 640
+// channels are groups of 60).  One block per (group, sample); thread t folds items t, t + 256, ... of the group's
+// (row block, unit) list in order, then a fixed tree: bitwise reproducible.  No pass over the activation.
+__global__ void __launch_bounds__(256) k_gn_finalize_parts(const float* __restrict__ part1, int U1, const float* __restrict__ part2, int U2,
+                                                           int rb_per_sample, int upg, float inv_n, float eps, float* __restrict__ mr) {
+    const int g = blockIdx.x, sample = blockIdx.y;
+    const int items = rb_per_sample * upg;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < items; i += 256) {
+        const int rbl = i / upg, u = g * upg + (i - rbl * upg);
+        const size_t rb = (size_t)sample * rb_per_sample + rbl;
+        const float* P = u < U1 ? part1 + rb * 2 * (size_t)U1 + u : part2 + rb * 2 * (size_t)U2 + (u - U1);
+        const int U = u < U1 ? U1 : U2;
+        s1 += P[0];
+        s2 += P[U];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_down(s1, o, 64);
+        s2 += __shfl_down(s2, o, 64);
+    }
+    __shared__ float red[8];
+    if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = s1; red[(threadIdx.x >> 6) * 2 + 1] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s1 = (red[0] + red[2]) + (red[4] + red[6]);
+        s2 = (red[1] + red[3]) + (red[5] + red[7]);
+        const float mean = s1 * inv_n;
+        const float var = fmaxf(s2 * inv_n - mean * mean, 0.0f);
+        mr[((size_t)sample * 32 + g) * 2] = mean;
+        mr[((size_t)sample * 32 + g) * 2 + 1] = rsqrtf(var + eps);
+    }
+}
+
 template <bool SILU>
 __global__ void k_gn_apply(const __half* __restrict__ x, const __half* __restrict__ x2, int C1, __half* __restrict__ y, int R,
                            int C, int rows_per_block,
@@ -250,7 +286,8 @@ extern "C" size_t syn3r_groupnorm_workspace_bytes(int samples, int rows) {
 
 namespace {
 int groupnorm_launch(const void* x, const void* x2, int C1, void* y, int samples, int rows, int C, const void* gamma,
-                     const void* beta, float eps, int silu, void* workspace, size_t workspace_bytes, void* stream_) {
+                     const void* beta, float eps, int silu, void* workspace, size_t workspace_bytes, void* stream_,
+                     const float* part1 = nullptr, const float* part2 = nullptr) {
     SYN3R_REQUIRE(x && y && gamma && beta, "groupnorm: null tensor");
     SYN3R_REQUIRE(SYN3R_DIM_OK(samples) && SYN3R_DIM_OK(rows) && SYN3R_DIM_OK(C) && C % 32 == 0 && C % 8 == 0, "groupnorm: bad sizes samples=%d rows=%d C=%d",
                   samples, rows, C);
@@ -269,10 +306,18 @@ int groupnorm_launch(const void* x, const void* x2, int C1, void* y, int samples
     size_t lds = (size_t)threads * 16 * sizeof(float);
     float* partial = (float*)workspace;
     float* meanrstd = partial + (size_t)samples * chunks * 64;
-    SYN3R_LAUNCH(k_gn_stats, grid, dim3(threads), lds, stream, (const __half*)x, (const __half*)x2, C1, rows, C, rows_per_block,
-                 partial);
-    SYN3R_LAUNCH(k_gn_finalize, dim3(samples), dim3(1024), 0, stream, (const float*)partial, chunks,
-                 1.0f / ((float)rows * (float)(C / 32)), eps, meanrstd);
+    if (part1) {          // the producers' partial sums: no statistics pass
+        const int cpg = C / 32;
+        SYN3R_REQUIRE(rows % 32 == 0 && cpg % 10 == 0 && C1 % 10 == 0 && (!x2 || part2), "groupnorm_pre: needs rows %% 32 == 0 and whole 10-channel units (rows=%d C=%d C1=%d)", rows, C, C1);
+        SYN3R_REQUIRE(((uintptr_t)part1 | (uintptr_t)part2) % 4 == 0, "groupnorm_pre: misaligned partial sums");
+        SYN3R_LAUNCH(k_gn_finalize_parts, dim3(32, samples), dim3(256), 0, stream, part1, C1 / 10, part2, (C - C1) / 10, rows / 32, cpg / 10,
+                     1.0f / ((float)rows * (float)cpg), eps, meanrstd);
+    } else {
+        SYN3R_LAUNCH(k_gn_stats, grid, dim3(threads), lds, stream, (const __half*)x, (const __half*)x2, C1, rows, C, rows_per_block,
+                     partial);
+        SYN3R_LAUNCH(k_gn_finalize, dim3(samples), dim3(1024), 0, stream, (const float*)partial, chunks,
+                     1.0f / ((float)rows * (float)(C / 32)), eps, meanrstd);
+    }
     if (silu)
         SYN3R_LAUNCH(k_gn_apply<true>, grid, dim3(threads), 0, stream, (const __half*)x, (const __half*)x2, C1, (__half*)y, rows,
                      C, rows_per_block, (const float*)meanrstd, (const __half*)gamma, (const __half*)beta, eps);
@@ -295,6 +340,15 @@ extern "C" int syn3r_groupnorm_2src_f16(const void* x1, int C1, const void* x2, 
                                         size_t workspace_bytes, void* stream_) {
     SYN3R_REQUIRE(x2 != nullptr && SYN3R_DIM_OK(C1) && SYN3R_DIM_OK(C2), "groupnorm_2src: second source missing or bad widths C1=%d C2=%d", C1, C2);
     return groupnorm_launch(x1, x2, C1, y, samples, rows, C1 + C2, gamma, beta, eps, silu, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int syn3r_groupnorm_pre_f16(const void* x1, int C1, const void* part1, const void* x2, int C2, const void* part2, void* y,
+                                       int samples, int rows, const void* gamma, const void* beta, float eps, int silu,
+                                       void* workspace, size_t workspace_bytes, void* stream_) {
+    SYN3R_REQUIRE(part1 != nullptr && SYN3R_DIM_OK(C1) && (x2 == nullptr ? C2 == 0 : (SYN3R_DIM_OK(C2) && part2 != nullptr)),
+                  "groupnorm_pre: partial sums missing or bad widths C1=%d C2=%d", C1, C2);
+    return groupnorm_launch(x1, x2, C1, y, samples, rows, C1 + C2, gamma, beta, eps, silu, workspace, workspace_bytes, stream_,
+                            (const float*)part1, (const float*)part2);
 }
 
 extern "C" int syn3r_layernorm_f16(const void* x, void* y, void* xsum, const void* addvec, int rows_per_vec,

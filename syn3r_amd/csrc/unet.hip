@@ -621,7 +621,9 @@ struct Arena {
     }
 };
 
-struct T { __half* p = nullptr; long long rows = 0; int cols = 0; };     // an activation [rows, cols] in the arena
+// an activation [rows, cols] in the arena; gnp: the GroupNorm partial sums its producer was asked for (syn3r_gemm_set_gn_partials),
+// gn_ok: the kernel that ran wrote them
+struct T { __half* p = nullptr; long long rows = 0; int cols = 0; float* gnp = nullptr; bool gn_ok = false; };
 
 struct Epi {                                                              // the fused epilogue of syn3r_gemm_f16 and friends
     const __half* rowvec = nullptr; long long ldrv = 0; int rows_per_vec = 0, rv_group = 0;
@@ -655,23 +657,41 @@ struct Run {
         if (!t.p) { set_error("unet_forward: workspace too small (needs syn3r_unet_workspace_bytes)"); rc = SYN3R_E_WORKSPACE; }
         return t;
     }
-    void drop(T& t) { ar.release(t.p); t.p = nullptr; }
+    void drop(T& t) { ar.release(t.p); t.p = nullptr; ar.release(t.gnp); t.gnp = nullptr; t.gn_ok = false; }
+    // GroupNorm statistics from the producer's epilogue (model.py: gn_stats=TUNE["gn_epilogue"]): the buffer is part of the
+    // allocation sequence whenever the shape can carry partial sums (dry runs see the same sequence); whether the kernel chosen
+    // for the shape wrote them is known after the launch
+    void gn_begin(T& out, bool want) {
+        static const int gn_env = tune_env("SYN3R_GN_EPILOGUE", 1);
+        const size_t nb = (want && gn_env != 0 && out.rows <= SYN3R_DIM_MAX) ? syn3r_gn_partials_bytes((int)out.rows, out.cols) : 0;
+        if (!nb || !ok()) return;
+        out.gnp = (float*)ar.alloc(nb);
+        if (!out.gnp) { set_error("unet_forward: workspace too small (needs syn3r_unet_workspace_bytes)"); rc = SYN3R_E_WORKSPACE; return; }
+        if (go()) chk(syn3r_gemm_set_gn_partials(out.gnp, nb));
+    }
+    void gn_end(T& out) {
+        if (!out.gnp || !go()) return;
+        out.gn_ok = syn3r_gemm_gn_partials_written() != 0;
+        if (!out.gn_ok) syn3r_gemm_set_gn_partials(nullptr, 0);
+    }
     void chk(int r) { if (r && !rc) rc = r; }
     bool go() const { return ok() && !dry; }
 
     // ---- operators (ops.py)
-    T linear(const T& x, long long ldx, int K, const std::string& wname, const char* bias_name, const Epi& e = Epi()) {
+    T linear(const T& x, long long ldx, int K, const std::string& wname, const char* bias_name, const Epi& e = Epi(), bool gn = false) {
         const Wt* wt = W(wname);
         const __half* b = bias_name ? Wp(bias_name) : nullptr;
         T out = make(x.rows, wt ? (int)wt->rows : 0);
+        gn_begin(out, gn);
         if (go())
             chk(syn3r_gemm_f16(x.p, ldx, wt->p, out.p, out.cols, b, e.rowvec, e.ldrv, e.rows_per_vec, e.rv_group,
                                e.residual ? e.residual->p : nullptr, e.residual ? e.residual->cols : 0, e.aux ? e.aux->p : nullptr,
                                e.aux ? e.aux->cols : 0, e.s_acc, e.s_res, e.s_aux, (int)x.rows, out.cols, K, stream));
+        gn_end(out);
         return out;
     }
-    T linear(const T& x, const std::string& wname, const std::string& bname, const Epi& e = Epi()) {
-        return linear(x, x.cols, x.cols, wname, bname.empty() ? nullptr : bname.c_str(), e);
+    T linear(const T& x, const std::string& wname, const std::string& bname, const Epi& e = Epi(), bool gn = false) {
+        return linear(x, x.cols, x.cols, wname, bname.empty() ? nullptr : bname.c_str(), e, gn);
     }
     T linear_cat(const T& x1, const T& x2, const std::string& wname, const std::string& bname) {
         const Wt* wt = W(wname);
@@ -691,7 +711,7 @@ struct Run {
         return out;
     }
     T conv3x3(const T& x, int NB, int Hi, int Wi, int Cin, const std::string& wname, const std::string& bname, int stride, bool ups,
-              const Epi& e, int* Ho_ = nullptr, int* Wo_ = nullptr) {
+              const Epi& e, int* Ho_ = nullptr, int* Wo_ = nullptr, bool gn = true) {
         const Wt* wt = W(wname);
         const int Cout = wt ? (int)wt->rows : 0;
         const int Hg = ups ? 2 * Hi : Hi, Wg = ups ? 2 * Wi : Wi;
@@ -699,18 +719,22 @@ struct Run {
         if (Ho_) *Ho_ = Ho;
         if (Wo_) *Wo_ = Wo;
         T out = make((long long)NB * Ho * Wo, Cout);
+        gn_begin(out, gn);
         if (go())
             chk(syn3r_conv2d3x3_f16(x.p, wt->p, out.p, Cout, Wp(bname), e.rowvec, e.ldrv, e.rows_per_vec, e.residual ? e.residual->p : nullptr,
                                     e.residual ? Cout : 0, e.s_acc, e.s_res, NB, Hi, Wi, Cin, Cout, stride, ups ? 1 : 0, 1, stream));
+        gn_end(out);
         return out;
     }
     T tconv3(const T& x, const std::string& wname, const std::string& bname, int HW, const Epi& e) {
         const Wt* wt = W(wname);
         const int Cout = wt ? (int)wt->rows : 0;
         T out = make(x.rows, Cout);
+        gn_begin(out, true);                     // (every temporal convolution's output is a GroupNorm input, model.py:_resblock)
         if (go())
             chk(syn3r_tconv3_f16(x.p, wt->p, out.p, Cout, Wp(bname), e.rowvec, e.ldrv, e.rows_per_vec, e.residual ? e.residual->p : nullptr,
                                  e.residual ? Cout : 0, e.s_acc, e.s_res, B, F, HW, x.cols, Cout, stream));
+        gn_end(out);
         return out;
     }
     T groupnorm(const T& x, const std::string& pre, int samples, float eps, bool silu, const T* x2 = nullptr) {
@@ -719,7 +743,11 @@ struct Run {
         T out = make(x.rows, x.cols + (x2 ? x2->cols : 0));
         void* ws = ok() ? ar.alloc(wsb) : nullptr;
         if (ok() && !ws) { set_error("unet_forward: workspace too small (needs syn3r_unet_workspace_bytes)"); rc = SYN3R_E_WORKSPACE; }
-        if (go()) {
+        const int Ct = x.cols + (x2 ? x2->cols : 0);
+        if (go() && x.gn_ok && (!x2 || x2->gn_ok) && rows % 32 == 0 && Ct % 320 == 0 && x.cols % 10 == 0) {      // ops.py:groupnorm, the same rule
+            chk(syn3r_groupnorm_pre_f16(x.p, x.cols, x.gnp, x2 ? x2->p : nullptr, x2 ? x2->cols : 0, x2 ? x2->gnp : nullptr, out.p, samples, rows,
+                                        Wp(pre + ".weight"), Wp(pre + ".bias"), eps, silu, ws, wsb, stream));
+        } else if (go()) {
             if (x2) chk(syn3r_groupnorm_2src_f16(x.p, x.cols, x2->p, x2->cols, out.p, samples, rows, Wp(pre + ".weight"), Wp(pre + ".bias"), eps, silu, ws, wsb, stream));
             else chk(syn3r_groupnorm_f16(x.p, out.p, samples, rows, x.cols, Wp(pre + ".weight"), Wp(pre + ".bias"), eps, silu, ws, wsb, stream));
         }
@@ -961,7 +989,7 @@ struct Run {
         drop(tt);
         drop(hs);
         Epi eo; eo.residual = &x;
-        T out = linear(mix, pre + ".proj_out.weight", pre + ".proj_out.bias", eo);
+        T out = linear(mix, pre + ".proj_out.weight", pre + ".proj_out.bias", eo, true);
         drop(mix);
         return out;
     }
@@ -1073,7 +1101,7 @@ struct Run {
         // 6. out (:481-486)
         T gn = groupnorm(x, "conv_norm_out", B * F, 1e-5f, true);
         drop(x);
-        T y = conv3x3(gn, B * F, h, w, c0, "conv_out.weight", "conv_out.bias", 1, false, Epi());
+        T y = conv3x3(gn, B * F, h, w, c0, "conv_out.weight", "conv_out.bias", 1, false, Epi(), nullptr, nullptr, false);
         drop(gn);
         if (go()) { const long long n = (long long)B * F * m.out_ch * h * w; hipLaunchKernelGGL(k_nhwc_to_nchw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, y.p, out, B * F, m.out_ch, h * w, y.cols); }
         drop(y);

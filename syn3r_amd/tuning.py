@@ -19,11 +19,12 @@ FLAGS = {
     "unet_graph": False,    # replay captured UNet launch sequences (hipGraph)
     "two_streams": True,    # independent launch sequences of a two-pass step on their own HIP streams
     "merge_passes": True,   # both passes of a step in one stack of UNet launches
+    "gn_epilogue": True,    # GroupNorm statistics from the producing contraction's epilogue (no k_gn_stats pass)
 }
 
 _ENV = {"ff_fused": "SYN3R_FF_FUSED", "ff_ln": "SYN3R_FF_LN", "ff_tiled": "SYN3R_FF_TILED", "ln_qkv": "SYN3R_LN_QKV",
         "splitk": "SYN3R_SPLITK", "unet_cat": "SYN3R_UNET_CAT", "unet_graph": "SYN3R_UNET_GRAPH",
-        "two_streams": "SYN3R_TWO_STREAMS", "merge_passes": "SYN3R_MERGE_PASSES"}
+        "two_streams": "SYN3R_TWO_STREAMS", "merge_passes": "SYN3R_MERGE_PASSES", "gn_epilogue": "SYN3R_GN_EPILOGUE"}
 
 
 def from_env() -> dict:

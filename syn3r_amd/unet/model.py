@@ -365,8 +365,11 @@ class UNetSpatioTemporalConditionModel:
         a0, a1 = self._temb_slices[s + ".time_emb_proj"]
         tp_s = st["temb_all"][:, a0:a1]                                   # [B, cout], a column slice of the stacked projection
         hcur = ops.groupnorm(x, W(s + ".norm1.weight"), W(s + ".norm1.bias"), B * F, 1e-5, True, x2=x2)
+        # (every contraction whose output a GroupNorm reads next leaves the statistics' partial sums behind: ops.groupnorm
+        # then runs without its pass over the activation, TUNE["gn_epilogue"])
         hcur = ops.conv3x3(hcur.view(B * F, h, w_, cin), W(s + ".conv1.weight"), W(s + ".conv1.bias"),
-                           rowvec=tp_s, rows_per_vec=F * HW).view(-1, cout)
+                           rowvec=tp_s, rows_per_vec=F * HW, gn_stats=TUNE["gn_epilogue"])
+        hcur = ops.keep_gn(hcur.view(-1, cout), hcur)
         hcur = ops.groupnorm(hcur, W(s + ".norm2.weight"), W(s + ".norm2.bias"), B * F, 1e-5, True)
         skip = x
         if x2 is not None:                 # (a concatenated input is always wider than the output: the shortcut exists)
@@ -374,17 +377,18 @@ class UNetSpatioTemporalConditionModel:
         elif cin != cout:
             skip = ops.linear(x, W(s + ".conv_shortcut.weight"), W(s + ".conv_shortcut.bias"))
         xs = ops.conv3x3(hcur.view(B * F, h, w_, cout), W(s + ".conv2.weight"), W(s + ".conv2.bias"),
-                         residual=skip).view(-1, cout)
+                         residual=skip, gn_stats=TUNE["gn_epilogue"])
+        xs = ops.keep_gn(xs.view(-1, cout), xs)
         # TemporalResnetBlock (resnet.py:613-636) + AlphaBlender (:789-802)
         a0, a1 = self._temb_slices[t + ".time_emb_proj"]
         tp_t = st["temb_all"][:, a0:a1]
         hcur = ops.groupnorm(xs, W(t + ".norm1.weight"), W(t + ".norm1.bias"), B, 1e-5, True)
-        hcur = ops.tconv3(hcur, W(t + ".conv1.weight"), W(t + ".conv1.bias"), B, F, HW, rowvec=tp_t, rows_per_vec=F * HW)
+        hcur = ops.tconv3(hcur, W(t + ".conv1.weight"), W(t + ".conv1.bias"), B, F, HW, rowvec=tp_t, rows_per_vec=F * HW, gn_stats=TUNE["gn_epilogue"])
         hcur = ops.groupnorm(hcur, W(t + ".norm2.weight"), W(t + ".norm2.bias"), B, 1e-5, True)
         a, om = self._blend_scales(pre + ".time_mixer.mix_factor")
         # alpha*xs + (1-alpha)*(xs + conv2)  ==  (alpha + (1-alpha))*xs + (1-alpha)*conv2
         return ops.tconv3(hcur, W(t + ".conv2.weight"), W(t + ".conv2.bias"), B, F, HW, residual=xs, s_acc=om,
-                          s_res=a + om)
+                          s_res=a + om, gn_stats=TUNE["gn_epilogue"])
 
     def _cross_vec(self, pre: str, ehs: torch.Tensor, cache: Optional[dict] = None) -> torch.Tensor:
         """attn2 with a single key: to_out(to_v(ctx)) per batch item -> [B, C].  A function of the context alone: the
@@ -482,7 +486,7 @@ class UNetSpatioTemporalConditionModel:
         a, om = self._blend_scales(pre + ".time_mixer.mix_factor")
         # alpha*hs + (1-alpha)*(ff(norm3(tt)) + tt)
         mix = self._ff(t + ".ff", tt, norm=t + ".norm3", residual=tt, aux=hs, s_acc=om, s_res=om, s_aux=a)
-        return ops.linear(mix, W(pre + ".proj_out.weight"), W(pre + ".proj_out.bias"), residual=x)
+        return ops.linear(mix, W(pre + ".proj_out.weight"), W(pre + ".proj_out.bias"), residual=x, gn_stats=TUNE["gn_epilogue"])
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -550,7 +554,8 @@ class UNetSpatioTemporalConditionModel:
         # 2. conv_in on NHWC with channels padded to 64 (:428)
         x = sample.to(H).flatten(0, 1).permute(0, 2, 3, 1)
         x = Fn.pad(x, (0, 64 - Cin % 64 if Cin % 64 else 0)).contiguous()
-        x = ops.conv3x3(x, W("conv_in.weight"), W("conv_in.bias")).view(-1, boc[0])
+        x = ops.conv3x3(x, W("conv_in.weight"), W("conv_in.bias"), gn_stats=TUNE["gn_epilogue"])
+        x = ops.keep_gn(x.view(-1, boc[0]), x)
         skips = [(x, boc[0])]
         # 3. down (:432-449)
         for blk in self.down_plan:
@@ -563,9 +568,9 @@ class UNetSpatioTemporalConditionModel:
             if blk["down"]:
                 ch = blk["ch"]
                 x = ops.conv3x3(x.view(B * F, st["h"], st["w"], ch), W(f"down_blocks.{i}.downsamplers.0.conv.weight"),
-                                W(f"down_blocks.{i}.downsamplers.0.conv.bias"), stride=2)
+                                W(f"down_blocks.{i}.downsamplers.0.conv.bias"), stride=2, gn_stats=TUNE["gn_epilogue"])
                 st["h"], st["w"] = x.shape[1], x.shape[2]
-                x = x.view(-1, ch)
+                x = ops.keep_gn(x.view(-1, ch), x)
                 skips.append((x, ch))
         # 4. mid (:452-457)
         mid = boc[-1]
@@ -586,9 +591,9 @@ class UNetSpatioTemporalConditionModel:
             if blk["up"]:
                 ch = blk["ch"]
                 x = ops.conv3x3(x.view(B * F, st["h"], st["w"], ch), W(f"up_blocks.{i}.upsamplers.0.conv.weight"),
-                                W(f"up_blocks.{i}.upsamplers.0.conv.bias"), upsample=True)
+                                W(f"up_blocks.{i}.upsamplers.0.conv.bias"), upsample=True, gn_stats=TUNE["gn_epilogue"])
                 st["h"], st["w"] = x.shape[1], x.shape[2]
-                x = x.view(-1, ch)
+                x = ops.keep_gn(x.view(-1, ch), x)
         # 6. out (:481-486)
         x = ops.groupnorm(x, W("conv_norm_out.weight"), W("conv_norm_out.bias"), B * F, 1e-5, True)
         y = ops.conv3x3(x.view(B * F, st["h"], st["w"], boc[0]), W("conv_out.weight"), W("conv_out.bias"))

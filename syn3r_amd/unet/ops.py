@@ -31,6 +31,39 @@ def _chk(*ts):
     return dev
 
 
+def _gn_request(dev, M: int, N: int, want: bool):
+    """Ask the NEXT contraction of this thread for GroupNorm partial sums of its [M, N] output (include/syn3r_hip.h
+    syn3r_gemm_set_gn_partials): returns the buffer, or None when the shape has no whole 32-row blocks / 80-column groups."""
+    if not want:
+        return None
+    lib = L.load()
+    nb = lib.syn3r_gn_partials_bytes(int(M), int(N))
+    if not nb:
+        return None
+    part = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+    L.check(lib.syn3r_gemm_set_gn_partials(part.data_ptr(), nb), "syn3r_gemm_set_gn_partials")
+    return part
+
+
+def _gn_collect(out: torch.Tensor, part) -> torch.Tensor:
+    """Attach the partial sums to `out` (attribute `gn_part`) if the kernel that ran wrote them."""
+    if part is not None:
+        lib = L.load()
+        if lib.syn3r_gemm_gn_partials_written():
+            out.gn_part = part
+        else:
+            lib.syn3r_gemm_set_gn_partials(None, 0)        # (an entry that returned before consuming the request)
+    return out
+
+
+def keep_gn(view: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """`view` is a reshape of `src` with the same rows x channels matrix: carry the producer's GroupNorm partial sums over."""
+    part = getattr(src, "gn_part", None)
+    if part is not None:
+        view.gn_part = part
+    return view
+
+
 def _rowvec(rv: Optional[torch.Tensor]):
     """(pointer, row stride) of a per-sample row-vector operand: a [V, N] fp16 matrix or a column slice of a wider one."""
     if rv is None:
@@ -44,9 +77,10 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
            rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0, rv_group_rows: int = 0,
            residual: Optional[torch.Tensor] = None,
            aux: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0, s_aux: float = 1.0,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, gn_stats: bool = False) -> torch.Tensor:
     """x [M,K] @ weight[N,K]^T with the fused epilogue of syn3r_gemm_f16.  x may be a column
-    slice of a wider matrix (stride(0) >= K).  rows_per_vec / rv_group_rows: see include/syn3r_hip.h."""
+    slice of a wider matrix (stride(0) >= K).  rows_per_vec / rv_group_rows: see include/syn3r_hip.h.
+    gn_stats: ask the kernel for GroupNorm partial sums of the output (attribute `gn_part` of the result when written)."""
     dev = L.require_gpu(x, weight)
     M, K = x.shape
     N = weight.shape[0]
@@ -57,6 +91,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if out is None:
         out = torch.empty((M, N), dtype=H, device=dev)
     lib = L.load()
+    part = _gn_request(dev, M, N, gn_stats and out.stride(0) == N)
     rc = lib.syn3r_gemm_f16(x.data_ptr(), x.stride(0), L.ptr(weight), out.data_ptr(), out.stride(0), L.ptr(bias),
                             rv_ptr, rv_ld, int(rows_per_vec), int(rv_group_rows),
                             residual.data_ptr() if residual is not None else None,
@@ -65,7 +100,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
                             float(s_acc), float(s_res), float(s_aux), M, N, K, L.stream_ptr(dev))
     L.check(rc, "syn3r_gemm_f16")
     _count("gemm", 2.0 * M * N * K)
-    return out
+    return _gn_collect(out, part)
 
 
 def pack_geglu(weight: torch.Tensor, bias: torch.Tensor):
@@ -191,7 +226,7 @@ def feedforward_fused(x: torch.Tensor, w1_chunked: torch.Tensor, b1_chunked: tor
 def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride: int = 1,
             upsample: bool = False, rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0,
             residual: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0,
-            pad_lo: int = 1) -> torch.Tensor:
+            pad_lo: int = 1, gn_stats: bool = False) -> torch.Tensor:
     """x [NB,Hi,Wi,Cin] NHWC, weight [Cout,3,3,Cin] -> [NB,Ho,Wo,Cout].  pad_lo = 0: the (0,1,0,1) padding of the
     VAE encoder's stride-2 Downsample2D(padding=0)."""
     dev = _chk(x, weight, bias, residual)
@@ -204,18 +239,19 @@ def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
     Ho, Wo = (Hg + pad_lo - 2) // stride + 1, (Wg + pad_lo - 2) // stride + 1
     out = torch.empty((NB, Ho, Wo, Cout), dtype=H, device=dev)
     lib = L.load()
+    part = _gn_request(dev, NB * Ho * Wo, Cout, gn_stats)
     rc = lib.syn3r_conv2d3x3_f16(L.ptr(x), L.ptr(weight), L.ptr(out), Cout, L.ptr(bias), rv_ptr, rv_ld, int(rows_per_vec),
                                  L.ptr(residual), Cout if residual is not None else 0, float(s_acc), float(s_res),
                                  NB, Hi, Wi, Cin, Cout, int(stride), 1 if upsample else 0, int(pad_lo),
                                  L.stream_ptr(dev))
     L.check(rc, "syn3r_conv2d3x3_f16")
     _count("gemm", 2.0 * NB * Ho * Wo * Cout * 9 * Cin)
-    return out
+    return _gn_collect(out, part)
 
 
 def tconv3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], B: int, F: int, HW: int, *,
            rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0, residual: Optional[torch.Tensor] = None,
-           s_acc: float = 1.0, s_res: float = 1.0) -> torch.Tensor:
+           s_acc: float = 1.0, s_res: float = 1.0, gn_stats: bool = False) -> torch.Tensor:
     """x [B*F*HW, Cin], weight [Cout,3,Cin] -> [B*F*HW, Cout] (3-tap convolution over frames)."""
     dev = _chk(x, weight, bias, residual)
     rv_ptr, rv_ld = _rowvec(rowvec)
@@ -225,12 +261,13 @@ def tconv3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
         raise ValueError("tconv3: shape mismatch")
     out = torch.empty((M, Cout), dtype=H, device=dev)
     lib = L.load()
+    part = _gn_request(dev, M, Cout, gn_stats)
     rc = lib.syn3r_tconv3_f16(L.ptr(x), L.ptr(weight), L.ptr(out), Cout, L.ptr(bias), rv_ptr, rv_ld, int(rows_per_vec), L.ptr(residual),
                               Cout if residual is not None else 0, float(s_acc), float(s_res), B, F, HW, Cin, Cout,
                               L.stream_ptr(dev))
     L.check(rc, "syn3r_tconv3_f16")
     _count("gemm", 2.0 * M * Cout * 3 * Cin)
-    return out
+    return _gn_collect(out, part)
 
 
 def attention(qkv: torch.Tensor, nseq: int, S: int, heads: int) -> torch.Tensor:
@@ -265,15 +302,29 @@ def attention_temporal(qkv: torch.Tensor, B: int, F: int, HW: int, heads: int) -
 
 
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, samples: int, eps: float, silu: bool,
-              x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+              x2: Optional[torch.Tensor] = None, use_partials: bool = True) -> torch.Tensor:
     """x [samples*rows, C] -> same shape; 32 groups, statistics per (sample, group).  With `x2` [samples*rows, C2] the
-    input is the channel concatenation [x | x2], read in place (the result has C + C2 channels)."""
+    input is the channel concatenation [x | x2], read in place (the result has C + C2 channels).
+    Inputs that carry their producer's partial sums (attribute `gn_part`, see `linear(gn_stats=True)`) skip the statistics
+    pass; use_partials = False forces it."""
     dev = _chk(x, gamma, beta, x2)
     M, C = x.shape
     if M % samples:
         raise ValueError("groupnorm: rows not divisible by samples")
     lib = L.load()
     ws = L.workspace(dev, lib.syn3r_groupnorm_workspace_bytes(samples, M // samples), "gn")
+    # statistics from the producers' epilogues (syn3r_groupnorm_pre_f16) when every source carries its partial sums
+    p1 = getattr(x, "gn_part", None) if use_partials else None
+    p2 = getattr(x2, "gn_part", None) if (use_partials and x2 is not None) else None
+    Ct = C + (x2.shape[1] if x2 is not None else 0)
+    if p1 is not None and (x2 is None or p2 is not None) and (M // samples) % 32 == 0 and Ct % 320 == 0 and C % 10 == 0:
+        if x2 is not None and x2.shape[0] != M:
+            raise ValueError("groupnorm: the two sources must have the same rows")
+        y = torch.empty((M, Ct), dtype=H, device=dev)
+        rc = lib.syn3r_groupnorm_pre_f16(L.ptr(x), C, L.ptr(p1), L.ptr(x2), Ct - C, L.ptr(p2), L.ptr(y), samples, M // samples,
+                                         L.ptr(gamma), L.ptr(beta), float(eps), 1 if silu else 0, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+        L.check(rc, "syn3r_groupnorm_pre_f16")
+        return y
     if x2 is not None:
         if x2.shape[0] != M:
             raise ValueError("groupnorm: the two sources must have the same rows")

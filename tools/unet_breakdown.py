@@ -6,6 +6,8 @@ import torch
 import _devlib  # noqa: F401  (SYN3R_LIB_OVERRIDE=<other build>: explicit, tool-side)
 from syn3r_amd import _lib as L
 import os
+from syn3r_amd import tuning
+tuning.from_env()                             # SYN3R_GN_EPILOGUE=0 etc.: host-graph switches for A/B runs (explicit, tool-side)
 from syn3r_amd.pipeline.svd_step import SvdStepBench
 if os.environ.get("SYN3R_SET_TILE"):          # force a contraction kernel family (syn3r_gemm_set_tile), tuning runs
     L.load().syn3r_gemm_set_tile(int(os.environ["SYN3R_SET_TILE"]))
