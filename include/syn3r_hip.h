@@ -360,6 +360,20 @@ int syn3r_feedforward_f16(const void* x, long long ldx, const void* w1_packed, c
                           int M, int C_in, int C_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * syn3r_feedforward_f16 with net.0 on the persistent 256 x 256 tile (round 6, k_gemm_g256: a second look-ahead stage for the
+ * A operand, LDS-free epilogue into the tiled hidden activation; attention.py:608-665, activations.py GEGLU).
+ *   w1_packed64 / b1_packed64: the rows of net.0.proj regrouped per 64-wide hidden chunk j as [hidden 64j..64j+63 | gate
+ *   64j..64j+63] ([2 D, C_in] / [2 D]).  Shapes: syn3r_feedforward_p64_supported(M, D, C_in) (whole tiles: M % 256 == 0,
+ *   D % 128 == 0, C_in >= 128 a multiple of 64), x with dense rows (ldx == C_in); everything else as syn3r_feedforward_f16,
+ *   whose results it reproduces bit for bit (same accumulation order, same gate).
+ */
+int syn3r_feedforward_p64_supported(int M, int D, int C_in);
+int syn3r_feedforward_p64_f16(const void* x, long long ldx, const void* w1_packed64, const void* b1_packed64, int D,
+                              const void* w2, const void* b2, void* out, long long ldc, const void* residual,
+                              long long ldr, const void* aux, long long ldaux, float s_acc, float s_res, float s_aux,
+                              int M, int C_in, int C_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * The same FeedForward.forward (attention.py:608-665, GEGLU of activations.py) in ONE kernel for C_in = C_out = 320
  * (the level-0 transformer blocks of SVD): the gated hidden activation never leaves the CU, no workspace.
  *   w1_chunked [D/64][128][320]: rows of net.0.proj regrouped per 64-wide hidden chunk j as

@@ -68,6 +68,9 @@ SIGNATURES = {
     "syn3r_feedforward_workspace_bytes": (c_sz, [c_i, c_i]),
     "syn3r_feedforward_f16": (c_i, [c_p, c_ll, c_p, c_p, c_i, c_p, c_p, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_f, c_f, c_f,
                                     c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "syn3r_feedforward_p64_f16": (c_i, [c_p, c_ll, c_p, c_p, c_i, c_p, c_p, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_f, c_f, c_f,
+                                    c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "syn3r_feedforward_p64_supported": (c_i, [c_i, c_i, c_i]),
     "syn3r_feedforward_fused_f16": (c_i, [c_p, c_ll, c_p, c_p, c_i, c_p, c_p, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_f, c_f, c_f,
                                           c_i, c_i, c_p]),
     "syn3r_feedforward_fused_ln_f16": (c_i, [c_p, c_ll, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_p, c_ll, c_p, c_ll, c_p, c_ll,

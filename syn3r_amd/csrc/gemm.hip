@@ -42,6 +42,7 @@ namespace {
 #include "gemm_z.h"
 #include "gemm_dmap.h"
 #include "gemm_dmapd.h"
+#include "gemm_g256.h"
 #include "gemm_ffn.h"
 
 // grid of the persistent kernels: the CU count of the CURRENT device (queried once per device; SYN3R_PERSISTENT_BLOCKS overrides
@@ -109,6 +110,30 @@ int launch_widep(const GemmParams& p, hipStream_t stream) {
     SYN3R_LAUNCH_NAMED(name, k_gemm_widep, dim3(blocks), dim3(512), lds, stream, q);
     SYN3R_LAUNCH_CHECK("gemm_widep launch");
     g_gn_written = p.gn_part != nullptr;
+    return SYN3R_OK;
+}
+
+// k_gemm_g256 (gemm_g256.h): the gated projection on whole 256 x 256 tiles into the A-tiled hidden activation
+bool g256_admits(const GemmParams& p) {
+    return p.geglu_D > 0 && p.out_tiled && !p.a_tiled && !p.A2 && !p.rowvec && !p.residual && !p.aux && p.s_acc == 1.0f && p.M % 256 == 0 &&
+           p.geglu_D % 128 == 0 && p.N == 2 * p.geglu_D && p.K >= 2 * BK && p.lda % 8 == 0 && (long long)p.M * p.lda < (1ll << 31) &&
+           (long long)p.N * p.K < (1ll << 31);
+}
+int launch_g256(const GemmParams& p, hipStream_t stream) {
+    static DevOnce once;
+    if (int rc = set_max_lds(once, (const void*)k_gemm_g256, G_LDS, "hipFuncSetAttribute(gemm_g256)")) return rc;
+    const int tiles = (p.M / 256) * (p.N / 256);
+    const int blocks = std::min(tiles, persistent_blocks());
+    GemmParams q = p;
+    static const int band_env = tune_env("SYN3R_G256_BAND", 0);
+    q.band = band_env > 0 ? band_env : 4;
+    char name[96];
+    if (trace_on()) {
+        if (trace_detail()) snprintf(name, sizeof(name), "k_gemm_g256[M%d,N%d,K%d,e2]", p.M, p.N, p.K);
+        else snprintf(name, sizeof(name), "k_gemm_g256");
+    }
+    SYN3R_LAUNCH_NAMED(name, k_gemm_g256, dim3(blocks), dim3(512), G_LDS, stream, q);
+    SYN3R_LAUNCH_CHECK("gemm_g256 launch");
     return SYN3R_OK;
 }
 
@@ -554,6 +579,43 @@ extern "C" int syn3r_feedforward_f16(const void* x, long long ldx, const void* w
     q.bias = (const __half*)b2; q.residual = (const __half*)residual; q.ldr = ldr; q.aux = (const __half*)aux; q.ldaux = ldaux;
     q.s_acc = s_acc; q.s_res = s_res; q.s_aux = s_aux; q.M = M; q.N = C_out; q.K = D;
     rc = check_common(q, "feedforward_f16(net.2)");
+    if (rc) return rc;
+    return launch<MODE_DENSE>(q, (hipStream_t)stream);
+}
+
+extern "C" int syn3r_feedforward_p64_supported(int M, int D, int C_in) {
+    return (SYN3R_DIM_OK(M) && SYN3R_DIM_OK(D) && SYN3R_DIM_OK(C_in) && M % 256 == 0 && D % 128 == 0 && C_in % BK == 0 && C_in >= 2 * BK &&
+            (long long)M * C_in < (1ll << 31) && 2ll * D * C_in < (1ll << 31)) ? 1 : 0;
+}
+
+extern "C" int syn3r_feedforward_p64_f16(const void* x, long long ldx, const void* w1_packed64, const void* b1_packed64, int D,
+                                         const void* w2, const void* b2, void* out, long long ldc, const void* residual,
+                                         long long ldr, const void* aux, long long ldaux, float s_acc, float s_res,
+                                         float s_aux, int M, int C_in, int C_out, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+    SYN3R_REQUIRE(x && w1_packed64 && b1_packed64 && w2 && out, "feedforward_p64_f16: null operand");
+    SYN3R_REQUIRE(syn3r_feedforward_p64_supported(M, D, C_in) != 0 && C_out > 0 && ldx == C_in,
+                  "feedforward_p64_f16: shape M=%d D=%d C_in=%d not served (syn3r_feedforward_p64_supported; x must be dense rows)", M, D, C_in);
+    const size_t need = syn3r_feedforward_workspace_bytes(M, D);
+    if (!workspace || workspace_bytes < need) {
+        set_error("feedforward_p64_f16: workspace %zu < %zu", workspace_bytes, need);
+        return SYN3R_E_WORKSPACE;
+    }
+    SYN3R_REQUIRE((uintptr_t)workspace % 16 == 0, "feedforward_p64_f16: workspace must be 16-byte aligned");
+    GemmParams p{};
+    p.A = (const __half*)x; p.lda = ldx; p.W = (const __half*)w1_packed64; p.out = (__half*)workspace; p.ldc = 2ll * D;
+    p.bias = (const __half*)b1_packed64; p.s_acc = 1.0f; p.M = M; p.N = 2 * D; p.K = C_in; p.geglu_D = D; p.out_tiled = 1;
+    p.out_nt = need >= ((size_t)256 << 20);
+    int rc = check_common(p, "feedforward_p64_f16(net.0)");
+    if (rc) return rc;
+    SYN3R_REQUIRE(g256_admits(p), "feedforward_p64_f16: shape not admitted by the 256 x 256 kernel");
+    rc = launch_g256(p, (hipStream_t)stream);
+    if (rc) return rc;
+    GemmParams q{};
+    q.A = (const __half*)workspace; q.lda = D; q.a_tiled = 1; q.W = (const __half*)w2; q.out = (__half*)out; q.ldc = ldc;
+    q.bias = (const __half*)b2; q.residual = (const __half*)residual; q.ldr = ldr; q.aux = (const __half*)aux; q.ldaux = ldaux;
+    q.s_acc = s_acc; q.s_res = s_res; q.s_aux = s_aux; q.M = M; q.N = C_out; q.K = D;
+    rc = check_common(q, "feedforward_p64_f16(net.2)");
     if (rc) return rc;
     return launch<MODE_DENSE>(q, (hipStream_t)stream);
 }

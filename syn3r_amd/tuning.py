@@ -19,12 +19,13 @@ FLAGS = {
     "unet_graph": False,    # replay captured UNet launch sequences (hipGraph)
     "two_streams": True,    # independent launch sequences of a two-pass step on their own HIP streams
     "merge_passes": True,   # both passes of a step in one stack of UNet launches
+    "ff_g256": True,        # net.0 of the two-kernel feed-forward on the 256 x 256 tile (k_gemm_g256) where whole tiles fit
     "gn_epilogue": True,    # GroupNorm statistics from the producing contraction's epilogue (no k_gn_stats pass)
 }
 
 _ENV = {"ff_fused": "SYN3R_FF_FUSED", "ff_ln": "SYN3R_FF_LN", "ff_tiled": "SYN3R_FF_TILED", "ln_qkv": "SYN3R_LN_QKV",
         "splitk": "SYN3R_SPLITK", "unet_cat": "SYN3R_UNET_CAT", "unet_graph": "SYN3R_UNET_GRAPH",
-        "two_streams": "SYN3R_TWO_STREAMS", "merge_passes": "SYN3R_MERGE_PASSES", "gn_epilogue": "SYN3R_GN_EPILOGUE"}
+        "two_streams": "SYN3R_TWO_STREAMS", "merge_passes": "SYN3R_MERGE_PASSES", "gn_epilogue": "SYN3R_GN_EPILOGUE", "ff_g256": "SYN3R_FF_G256"}
 
 
 def from_env() -> dict:

@@ -304,6 +304,9 @@ class UNetSpatioTemporalConditionModel:
                 else:
                     wp, bp, D = ops.pack_geglu(p.t[k], p.t[pre + "bias"])
                     pk[pre + "geglu_w"], pk[pre + "geglu_b"] = wp, bp
+                    if TUNE["ff_g256"] and D % 128 == 0:
+                        # the 256 x 256 tile's packing beside it (shapes without whole tiles - level 3 at F = 14 - keep the 80-column one)
+                        pk[pre + "geglu_w64"], pk[pre + "geglu_b64"], _ = ops.pack_geglu64(p.t[k], p.t[pre + "bias"])
         # every resnet's time_emb_proj (44 Linear(1280 -> Cout) on the SAME [B,1280] vector, resnet.py:352,630) as ONE
         # contraction per forward: weights / biases stacked once, each block reads its column slice
         names = [k[: -len(".weight")] for k in p.t if k.endswith("time_emb_proj.weight")]
@@ -426,8 +429,10 @@ class UNetSpatioTemporalConditionModel:
         if not TUNE["ff_tiled"]:      # tuning: row-major intermediate, two separate calls
             return ops.linear(ops.linear_geglu(x, wp, self.w(pre + ".net.0.proj.geglu_b"), D),
                               self.w(pre + ".net.2.weight"), self.w(pre + ".net.2.bias"), **epilogue)
+        w64 = self.packed.get(pre + ".net.0.proj.geglu_w64") if TUNE["ff_g256"] else None
+        p64 = (w64, self.packed[pre + ".net.0.proj.geglu_b64"]) if w64 is not None else None
         return ops.feedforward(x, wp, self.w(pre + ".net.0.proj.geglu_b"), D, self.w(pre + ".net.2.weight"),
-                               self.w(pre + ".net.2.bias"), **epilogue)
+                               self.w(pre + ".net.2.bias"), packed64=p64, **epilogue)
 
     def _norm_qkv(self, blk: str, x: torch.Tensor) -> torch.Tensor:
         """attn1's stacked q / k / v projection of norm1(x) (attention.py:340-352, 509-512): one kernel at C = 320

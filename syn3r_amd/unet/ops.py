@@ -120,6 +120,18 @@ def pack_geglu(weight: torch.Tensor, bias: torch.Tensor):
     return wp.contiguous(), bp.contiguous(), D
 
 
+def pack_geglu64(weight: torch.Tensor, bias: torch.Tensor):
+    """Regroup the [2D, K] GEGLU projection per 64-wide hidden chunk j as [hidden 64j..+63 | gate 64j..+63] rows (D a multiple
+    of 64): the layout syn3r_feedforward_p64_f16 (k_gemm_g256) expects."""
+    D2, K = weight.shape
+    D = D2 // 2
+    if D % 64:
+        raise ValueError("pack_geglu64: D must be a multiple of 64")
+    wp = torch.stack([weight[:D].view(D // 64, 64, K), weight[D:].view(D // 64, 64, K)], dim=1).reshape(D2, K)
+    bp = torch.stack([bias[:D].view(D // 64, 64), bias[D:].view(D // 64, 64)], dim=1).reshape(D2)
+    return wp.contiguous(), bp.contiguous(), D
+
+
 def linear_geglu(x: torch.Tensor, wpacked: torch.Tensor, bpacked: torch.Tensor, D: int) -> torch.Tensor:
     """geglu(x @ W^T + b) in one kernel: [M,K] -> [M,D]."""
     dev = _chk(wpacked, bpacked)
@@ -135,9 +147,12 @@ def linear_geglu(x: torch.Tensor, wpacked: torch.Tensor, bpacked: torch.Tensor, 
 
 def feedforward(x: torch.Tensor, w1_packed: torch.Tensor, b1_packed: torch.Tensor, D: int, w2: torch.Tensor,
                 b2: Optional[torch.Tensor] = None, *, residual: Optional[torch.Tensor] = None,
-                aux: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0, s_aux: float = 1.0) -> torch.Tensor:
+                aux: Optional[torch.Tensor] = None, s_acc: float = 1.0, s_res: float = 1.0, s_aux: float = 1.0,
+                packed64: Optional[tuple] = None) -> torch.Tensor:
     """FeedForward.forward with the GEGLU activation (attention.py:608-665): geglu(x @ W1^T + b1) @ W2^T + b2 with
-    the fused epilogue of `linear`; the hidden activation stays in a tiled workspace (syn3r_feedforward_f16)."""
+    the fused epilogue of `linear`; the hidden activation stays in a tiled workspace (syn3r_feedforward_f16).
+    packed64 = (w1, b1) in `pack_geglu64`'s layout: net.0 runs on the 256 x 256 tile (syn3r_feedforward_p64_f16) when the
+    shape has whole tiles; the result is the same bit for bit."""
     dev = _chk(w1_packed, b1_packed, w2, b2, residual, aux)
     L.require_gpu(x)
     M, K = x.shape
@@ -147,12 +162,15 @@ def feedforward(x: torch.Tensor, w1_packed: torch.Tensor, b1_packed: torch.Tenso
     out = torch.empty((M, N), dtype=H, device=dev)
     lib = L.load()
     ws = L.workspace(dev, lib.syn3r_feedforward_workspace_bytes(M, D), "ff")
-    rc = lib.syn3r_feedforward_f16(x.data_ptr(), x.stride(0), L.ptr(w1_packed), L.ptr(b1_packed), D, L.ptr(w2), L.ptr(b2),
-                                   L.ptr(out), N, residual.data_ptr() if residual is not None else None,
-                                   residual.stride(0) if residual is not None else 0,
-                                   aux.data_ptr() if aux is not None else None, aux.stride(0) if aux is not None else 0,
-                                   float(s_acc), float(s_res), float(s_aux), M, K, N, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
-    L.check(rc, "syn3r_feedforward_f16")
+    fn, name = lib.syn3r_feedforward_f16, "syn3r_feedforward_f16"
+    if packed64 is not None and x.stride(0) == K and lib.syn3r_feedforward_p64_supported(M, D, K):
+        w1_packed, b1_packed = packed64
+        fn, name = lib.syn3r_feedforward_p64_f16, "syn3r_feedforward_p64_f16"
+    rc = fn(x.data_ptr(), x.stride(0), L.ptr(w1_packed), L.ptr(b1_packed), D, L.ptr(w2), L.ptr(b2),
+            L.ptr(out), N, residual.data_ptr() if residual is not None else None, residual.stride(0) if residual is not None else 0,
+            aux.data_ptr() if aux is not None else None, aux.stride(0) if aux is not None else 0,
+            float(s_acc), float(s_res), float(s_aux), M, K, N, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+    L.check(rc, name)
     _count("gemm", 2.0 * M * 2 * D * K + 2.0 * M * N * D)
     return out
 

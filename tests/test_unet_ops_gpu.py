@@ -376,6 +376,38 @@ def test_feedforward_tiled_intermediate(M, C, D, gpu):
     close(ops.feedforward(x, wp, bp, D, w2, b2), h @ w2.float().T + b2.float(), tol=4e-3)
 
 
+@pytest.mark.parametrize("M,C,D", [(256, 128, 128), (2048, 640, 2560), (16128, 1280, 5120), (70144, 192, 384), (768, 320, 1280)])
+def test_feedforward_g256_equals_packed80(M, C, D, gpu):
+    """net.0 on the persistent 256 x 256 tile (k_gemm_g256, syn3r_feedforward_p64_f16: [64 hidden | 64 gate] packing, three A and
+    two B ring slots, LDS-free epilogue into the tiled hidden activation) reproduces syn3r_feedforward_f16 bit for bit - one tile,
+    fewer tiles than CUs, several tiles per block (the stage cursors cross tile boundaries; 70144 rows x 3 column tiles = 822
+    tiles), K of 2 to 20 k-tiles - and both match the fp32 restatement of FeedForward (attention.py:608-665)."""
+    from syn3r_amd import _lib
+    from syn3r_amd.unet import ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + C + D)
+    x = rnd(g, M, C, dev=gpu)
+    w1, b1 = rnd(g, 2 * D, C, scale=C ** -0.5, dev=gpu), rnd(g, 2 * D, dev=gpu)
+    w2, b2 = rnd(g, C, D, scale=D ** -0.5, dev=gpu), rnd(g, C, dev=gpu)
+    res = rnd(g, M, C, dev=gpu)
+    wp, bp, _ = ops.pack_geglu(w1, b1)
+    w64, b64, _ = ops.pack_geglu64(w1, b1)
+    assert lib.syn3r_feedforward_p64_supported(M, D, C) == 1
+    ref = ops.feedforward(x, wp, bp, D, w2, b2, residual=res)
+    out = ops.feedforward(x, wp, bp, D, w2, b2, residual=res, packed64=(w64, b64))
+    assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
+    again = ops.feedforward(x, wp, bp, D, w2, b2, residual=res, packed64=(w64, b64))
+    assert torch.equal(out, again)
+    if M <= 4096:
+        y = (x.float() @ w1.float().T + b1.float()).half().float()
+        h = (y[:, :D] * Fn.gelu(y[:, D:])).half().float()
+        close(out, h @ w2.float().T + b2.float() + res.float(), tol=4e-3)
+    # shapes without whole tiles are refused by the entry point and not offered by the wrapper
+    assert lib.syn3r_feedforward_p64_supported(M + 8, D, C) == 0 and lib.syn3r_feedforward_p64_supported(M, D + 64, C) == 0
+    xr = rnd(g, M + 8, C, dev=gpu)
+    assert torch.equal(ops.feedforward(xr, wp, bp, D, w2, b2, packed64=(w64, b64)), ops.feedforward(xr, wp, bp, D, w2, b2))
+
+
 @pytest.mark.parametrize("M,D", [(128, 64), (700, 1280), (4097, 1280), (129, 192)])
 def test_feedforward_fused_layernorm_c320(M, D, gpu):
     """norm3 -> ff in one kernel (syn3r_feedforward_fused_ln_f16): bit for bit the LayerNorm launch followed by the fused
