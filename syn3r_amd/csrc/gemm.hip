@@ -765,4 +765,7 @@ extern "C" int syn3r_tconv3_f16(const void* X, const void* W, void* out, long lo
 extern "C" __attribute__((visibility("default"))) int syn3r_debug_wide_timing(unsigned long long* out64) {
     return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_wide_timing), sizeof(unsigned long long) * 64);
 }
+extern "C" __attribute__((visibility("default"))) int syn3r_debug_g256_timing(unsigned long long* out64) {
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_g256_timing), sizeof(unsigned long long) * 64);
+}
 #endif

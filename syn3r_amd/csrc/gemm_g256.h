@@ -14,9 +14,13 @@
 //             result goes out as 8-byte stores straight from the MFMA layout - the A-tiled layout of the hidden activation
 //             (GemmParams::out_tiled: [128-row block][64-column tile][128][64]) makes the wavefront's 64 x 64 result ONE contiguous
 //             8 KB run, a store instruction covers 16 rows x 32 bytes and four of them complete the rows' 128-byte lines;
-//   waits     the next tile's first stages are waited for BEFORE the stores are issued (they were requested one and two k-tiles
-//             earlier), so that tile's first k-tile needs no vmcnt wait at all and the stores have a whole k-tile to be
-//             acknowledged before a counted wait includes them.
+//   waits     at a tile boundary (one extra barrier) the next tile's stage 1 of B and stage 2 of A are requested into the slots the last
+//             k-tile released, the gate runs while they land, and only then - everything the next tile's k-tiles 0 and 1 read has
+//             landed - are the stores issued: those two k-tiles need no vmcnt wait, and the first counted wait that includes the
+//             stores' acknowledgements comes two k-tiles after their issue (ablation: the same store instructions with ONE active
+//             lane cost 70 % of what the full stores cost - it is their acknowledgement inside a counted wait, not their bytes);
+//   bias      the epilogue's bias values are requested at the START of the tile by inline asm (left to the compiler: four load +
+//             s_waitcnt vmcnt(0) round trips inside the epilogue).
 // Arithmetic: the same MFMA order per accumulator as k_gemm_widep / k_gemm_z (k ascending, v_mfma_f32_16x16x32_f16 with the weight
 // fragment as the A operand), the same gate: results are bit-identical to those kernels' (tests/test_unet_ops_gpu.py).
 // Reference semantics: attention.py:608-665 (FeedForward), activations.py GEGLU.
@@ -24,6 +28,9 @@
 constexpr int G_SLOT = 256 * BK * 2;             // 32,768: one operand stage (256 rows x 64 halfs)
 constexpr int G_B0 = 3 * G_SLOT;                 // A slots at 0 / 32 K / 64 K, B slots at 96 K / 128 K
 constexpr int G_LDS = 5 * G_SLOT;                // 163,840
+#ifdef SYN3R_TIMING
+__device__ unsigned long long g_g256_timing[64];
+#endif
 
 __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -106,9 +113,29 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
     unsigned ra = 0, rb = 0;                    // ring slots of the k-tile being read
     float4v acc[8][4];                          // [column tile: 0-3 hidden, 4-7 gate][row tile]
 
-    // kernel prologue, in the steady state's order (B of stage g + 1 before A of stage g + 2): A0, B0, A1
-    issue_a(); issue_b(); issue_a();
+#ifdef G256_DEPHASE     // developer variant: the blocks of an XCD start G256_DEPHASE x 64 cycles apart (8 phases)
+    for (unsigned d = 0; d < ((blockIdx.x / 8) % 8); ++d) __builtin_amdgcn_s_sleep(G256_DEPHASE);
+#endif
+    // kernel prologue: the first tile's stages 0 and 1 of both operands and stage 2 of A - what every later tile finds requested
+    // (and landed) when it starts, see the tile boundary below
+    issue_a(); issue_b(); issue_a(); issue_b(); issue_a();
     bool first_tile = true;
+#ifdef SYN3R_TIMING     // tools/g256_timing.py: s_memtime ticks per segment of a tile, summed over one block's tiles, per wavefront
+    unsigned long long gt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g_a = __builtin_amdgcn_s_memtime();
+#define GSTAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); gt[i] += t_ - g_a; g_a = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define GSTAMP(i)
+#endif
+    typedef _Float16 half4e __attribute__((ext_vector_type(4)));
+#ifdef G256_DEFER       // developer variant: the gated result stays parked (eight 16-byte pieces) and its stores go out one per k-tile of the NEXT tile, in front of that k-tile's DMA requests
+    u32x4 pv[8];
+    __half* pbase = nullptr;
+    auto store_unit = [&](int u) {
+#define G256_ST(U) case U: { u32x4* dst = (u32x4*)(pbase + ((U) >> 1) * 16 * 64 + ((U) & 1) * 32); if (p.out_nt) __builtin_nontemporal_store(pv[U], dst); else *dst = pv[U]; } break;
+        switch (u) { G256_ST(0) G256_ST(1) G256_ST(2) G256_ST(3) G256_ST(4) G256_ST(5) G256_ST(6) G256_ST(7) default: break; }
+#undef G256_ST
+    };
+#endif
     for (unsigned tl = blockIdx.x / 8; tl < t_len; tl += t_stride) {
         int m0, tile_n;
         tile_origin(t_start + tl, m0, tile_n);
@@ -122,6 +149,20 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
             swz[0] = (unsigned)(((0 + fq) ^ (fr & 7)) << 4);
             swz[1] = (unsigned)(((4 + fq) ^ (fr & 7)) << 4);
         }
+        // the epilogue's bias values, requested NOW (inline asm: left to the compiler they are four load + s_waitcnt vmcnt(0) round trips
+        // inside the epilogue); they are older than every stage request of this tile, so the waits of the k-loop cover them
+        half4e bh[4], bg[4];
+        {
+            const __half* bptr = p.bias + tile_n * 256 + wn * 128 + (lane >> 4) * 4;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(bh[0]) : "v"(bptr));
+            asm volatile("global_load_dwordx2 %0, %1, off offset:32" : "=v"(bh[1]) : "v"(bptr));
+            asm volatile("global_load_dwordx2 %0, %1, off offset:64" : "=v"(bh[2]) : "v"(bptr));
+            asm volatile("global_load_dwordx2 %0, %1, off offset:96" : "=v"(bh[3]) : "v"(bptr));
+            asm volatile("global_load_dwordx2 %0, %1, off offset:128" : "=v"(bg[0]) : "v"(bptr));
+            asm volatile("global_load_dwordx2 %0, %1, off offset:160" : "=v"(bg[1]) : "v"(bptr));
+            asm volatile("global_load_dwordx2 %0, %1, off offset:192" : "=v"(bg[2]) : "v"(bptr));
+            asm volatile("global_load_dwordx2 %0, %1, off offset:224" : "=v"(bg[3]) : "v"(bptr));
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -131,16 +172,28 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
         for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(af[i]));
 #pragma unroll
         for (int j = 0; j < 8; ++j) asm volatile("" : "=v"(bf[j]));
+        // A k-half: twelve fragment reads (the four A fragments first), then the MFMAs column tile by column tile, each group of
+        // four behind a COUNTED wait for its own weight fragment - the first group issues when five of the twelve reads have arrived
         auto read_half = [&](int kh) {
             const unsigned aa = lds0 + ra * G_SLOT + a_row + swz[kh], ba = lds0 + rb * G_SLOT + b_row + swz[kh];
             DS_READ128(af[0], aa, 0); DS_READ128(af[1], aa, 2048); DS_READ128(af[2], aa, 4096); DS_READ128(af[3], aa, 6144);
             DS_READ128(bf[0], ba, 0); DS_READ128(bf[1], ba, 2048); DS_READ128(bf[2], ba, 4096); DS_READ128(bf[3], ba, 6144);
             DS_READ128(bf[4], ba, 8192); DS_READ128(bf[5], ba, 10240); DS_READ128(bf[6], ba, 12288); DS_READ128(bf[7], ba, 14336);
+        };
+#define G256_GROUP(J) do { \
+            if constexpr ((J) == 0) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0])); \
+            else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bf[J]) : "i"(7 - (J))); \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[J][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[J], af[i], acc[J][i], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifndef G256_UNCOUNTED
+        auto mma = [&]() {
+            G256_GROUP(0); G256_GROUP(1); G256_GROUP(2); G256_GROUP(3); G256_GROUP(4); G256_GROUP(5); G256_GROUP(6); G256_GROUP(7);
+        };
+#else
+        auto mma = [&]() {
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]),
                            "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7]));
-        };
-        auto mma = [&]() {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -148,25 +201,49 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[j][i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);   // the next reads reuse af / bf: keep them behind these MFMAs
         };
+#endif
         for (int kt = 0; kt < nkt; ++kt) {
-            // stage kt of both operands has landed once only the youngest four requests (the A pieces of stage kt + 1) are in flight;
-            // a later tile's first stages were waited for in front of the previous tile's stores
-            if (kt > 0 || first_tile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // stage kt of both operands has landed once only the youngest four requests (the A pieces of stage kt + 1) are in flight.
+            // k-tiles 0 and 1 find their stages landed: they were requested, and waited for, in front of the previous tile's stores
+            // (the kernel's first tile: requested by the prologue) - the first counted wait that includes those stores' acknowledgements
+            // is k-tile 2's, two k-tiles after they were issued
+            if (kt >= 2) {
+                GSTAMP(4);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#ifdef SYN3R_TIMING
+                if (kt == 2) GSTAMP(1) else GSTAMP(2)
+#endif
+            }
+            else if (first_tile && kt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            if (kt >= 2) { GSTAMP(3); }
             if (defer && kt > 0) mma();                          // second k-half of stage kt - 1 (fragments read before the barrier)
+            if (kt > 0) {
+#ifdef G256_DEFER
+            if (pbase && kt >= 1 && kt <= 8) store_unit(kt - 1);
+#endif
             issue_b();                                           // stage kt + 1 of B: the slot every wavefront finished reading in iteration kt - 1
             issue_a();                                           // stage kt + 2 of A: likewise
+            }
             read_half(0);
             mma();
             read_half(1);
+            // (drained in every wavefront: the deferred ones multiply behind the next barrier, whose DMA refills the slot these reads come from)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]),
+                           "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7]));
             if (!defer) mma();
             ra = ra == 2 ? 0u : ra + 1;
             rb ^= 1u;
+            if (kt == 1) { GSTAMP(0); }
         }
         if (defer) mma();
         first_tile = false;
-        // the next tile's stage 0 (both operands) has landed; its A stage 1 may still be in flight.  No store is outstanding here.
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        GSTAMP(4);
+        // tile boundary: every wavefront is done with the last k-tile's slots - the next tile's stage 1 of B and stage 2 of A go out
+        // now and land under the gate
+        __builtin_amdgcn_s_barrier();
+        issue_b(); issue_a();
 
         // ---- epilogue: gate in registers, 8-byte stores from the MFMA layout into the A-tiled hidden activation
         int le = lane;
@@ -174,36 +251,104 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
         const int fr = le & 15, fq = le >> 4;
         const int gn = tile_n * 256 + wn * 128;                  // packed column origin of this wavefront: [64 hidden | 64 gate]
         const int gm0 = m0 + wm * 64, go0 = tile_n * 128 + wn * 64;
-        typedef _Float16 half4e __attribute__((ext_vector_type(4)));
         __half* obase = p.out + tiled_off(gm0, go0, p.geglu_D) + fr * 64 + fq * 4;
-        half4e o[4][4];                                          // [row tile][column tile]: the gated result, 32 registers
+        unsigned o2[4][4][2];                                    // [row tile][column tile][column pair]: the gated result as packed fp16 pairs, 32 registers
+        // (the bias loads are older than everything this wait could leave in flight)
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2]), "+v"(bh[3]), "+v"(bg[0]), "+v"(bg[1]), "+v"(bg[2]), "+v"(bg[3]) :: "memory");
+        typedef _Float16 half2e __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = gn + j * 16 + fq * 4;
-            float bh[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) {
-                const half4e b0 = *(const half4e*)(p.bias + n), b1 = *(const half4e*)(p.bias + n + 64);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { bh[r] = (float)b0[r]; bg[r] = (float)b1[r]; }
-            }
+            // packed arithmetic throughout: bias add (v_pk_add_f32), rounding of the projection to fp16 and back (v_cvt_pk_f16_f32 + two
+            // v_cvt_f32_f16), gate, rounding of the result - the values and roundings of the scalar form (activations.py GEGLU on fp16)
+            const syn3r_f2 bhf[2] = {__builtin_convertvector((half2e){bh[j][0], bh[j][1]}, syn3r_f2), __builtin_convertvector((half2e){bh[j][2], bh[j][3]}, syn3r_f2)};
+            const syn3r_f2 bgf[2] = {__builtin_convertvector((half2e){bg[j][0], bg[j][1]}, syn3r_f2), __builtin_convertvector((half2e){bg[j][2], bg[j][3]}, syn3r_f2)};
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {
-                    const syn3r_f2 hv = (syn3r_f2){(float)(_Float16)(acc[j][i][r] + bh[r]), (float)(_Float16)(acc[j][i][r + 1] + bh[r + 1])};
-                    const syn3r_f2 gv = (syn3r_f2){(float)(_Float16)(acc[j + 4][i][r] + bg[r]), (float)(_Float16)(acc[j + 4][i][r + 1] + bg[r + 1])};
+                    const half2e hh = __builtin_convertvector((syn3r_f2){acc[j][i][r], acc[j][i][r + 1]} + bhf[r >> 1], half2e);
+                    const half2e gh = __builtin_convertvector((syn3r_f2){acc[j + 4][i][r], acc[j + 4][i][r + 1]} + bgf[r >> 1], half2e);
+                    const syn3r_f2 hv = __builtin_convertvector(hh, syn3r_f2), gv = __builtin_convertvector(gh, syn3r_f2);
+#ifdef G256_NOGATE      // developer ablation
+                    const syn3r_f2 y = hv + gv;
+#else
                     const syn3r_f2 y = hv * gelu_pk(gv);
-                    o[i][j][r] = (_Float16)y.x; o[i][j][r + 1] = (_Float16)y.y;
+#endif
+                    o2[i][j][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(y, half2e));
                 }
         }
+        // every stage the next tile's k-tiles 0 and 1 read has landed (requested at least a gate's length ago): nothing but this tile's
+        // stores is in flight when that tile starts
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GSTAMP(5);
+#if defined(G256_NOSTORE)   // developer ablation: one store per tile keeps the gate alive
+        {
+            unsigned x_ = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x_ ^= o2[i][j][0] ^ o2[i][j][1];
+            if (x_ == 0x12345678u) *(unsigned*)obase = x_;
+        }
+#elif defined(G256_DEFER)
+        pbase = p.out + tiled_off(gm0, go0, p.geglu_D) + fr * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                auto r0 = __builtin_amdgcn_permlane16_swap(o2[i][j][0], o2[i][j + 1][0], false, false);
+                auto r1 = __builtin_amdgcn_permlane16_swap(o2[i][j][1], o2[i][j + 1][1], false, false);
+                pv[i * 2 + (j >> 1)] = (u32x4){(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+            }
+#elif !defined(G256_ST8)    // 16-byte stores (two v_permlane16_swap per pair of column tiles): 16 rows x 64 bytes per instruction
+        {
+            // lanes of 16-lane row q hold columns 4 q .. 4 q + 3 of a column tile; after the swaps rows 0 / 2 hold columns 0-7 / 8-15 of tile
+            // j and rows 1 / 3 those of tile j + 1: piece (row q) = tile j + (q & 1), columns 8 (q >> 1) .. + 7
+#ifdef G256_STSMALL     // developer ablation: every block stores into its own fixed 64 KB (cache-resident: no write traffic beyond the L2)
+            __half* pb = p.out + (size_t)blockIdx.x * 32768 + (wv * 4096) + fr * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
+#else
+            __half* pb = p.out + tiled_off(gm0, go0, p.geglu_D) + fr * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
+#endif
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    auto r0 = __builtin_amdgcn_permlane16_swap(o2[i][j][0], o2[i][j + 1][0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane16_swap(o2[i][j][1], o2[i][j + 1][1], false, false);
+                    const u32x4 v = (u32x4){(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+                    u32x4* dst = (u32x4*)(pb + i * 16 * 64 + j * 16);
+#ifdef G256_ST1LANE     // developer ablation: the same store instructions with ONE active lane (16 bytes instead of 1 KB each)
+                    if (le == 0) *dst = v;
+#else
+                    if (p.out_nt) __builtin_nontemporal_store(v, dst); else *dst = v;
+#endif
+                }
+        }
+#elif !defined(G256_DEFER)
         // four consecutive stores complete the 128-byte lines of 16 rows
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                half4e* dst = (half4e*)(obase + i * 16 * 64 + j * 16);
-                if (p.out_nt) __builtin_nontemporal_store(o[i][j], dst); else *dst = o[i][j];
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                u2* dst = (u2*)(obase + i * 16 * 64 + j * 16);
+                const u2 v2 = (u2){o2[i][j][0], o2[i][j][1]};
+                if (p.out_nt) __builtin_nontemporal_store(v2, dst); else *dst = v2;
             }
+#endif
+        GSTAMP(6);
+#ifdef SYN3R_TIMING
+        ++gt[7];
+#endif
     }
+#ifdef SYN3R_TIMING
+    if (blockIdx.x == gridDim.x / 2 && lane == 0)
+        for (int i = 0; i < 8; ++i) g_g256_timing[wv * 8 + i] = gt[i];
+#endif
+#undef GSTAMP
+#undef G256_GROUP
+#ifdef G256_DEFER
+    if (pbase) for (int u = 0; u < 8; ++u) store_unit(u);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the exhausted cursors' last requests)
 }
