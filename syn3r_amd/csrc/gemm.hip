@@ -147,6 +147,8 @@ int launch_z(const GemmParams& p, hipStream_t stream) {
     const int blocks = std::min(tiles, persistent_blocks());
     GemmParams q = p;
     q.band = band_width(p);
+    if constexpr (MODE == MODE_CONV2D) q.a_bytes = (unsigned)((long long)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2);      // (launch_dma: < 2^32 - 2^20)
+    if constexpr (MODE == MODE_TCONV) q.a_bytes = (unsigned)((long long)p.M * p.Cin * 2);
     const GemmParams& p_ = q;
     char name[96];
     if (trace_on()) {

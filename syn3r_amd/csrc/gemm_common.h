@@ -78,6 +78,9 @@ struct GemmParams {
     // group (C = 320 .. 2560), so any consumer folds whole units; the statistics pass over the activation (k_gn_stats) is not
     // launched (resnet.py:272,286,574,588, transformer_temporal.py:235).  null: not written.  Needs M % 32 == 0 and N % 80 == 0.
     float* gn_part; int gn_units;
+    // k_gemm_z convolution modes (round 6): bytes of the input tensor, the extent of the buffer resource the A pieces are fetched
+    // through - a padded chunk is an out-of-range offset and the LDS-DMA writes zeros (tools/ubench/buffer_lds_oob.hip)
+    unsigned a_bytes;
 };
 
 // element offset of (row m, column d) in the A-tiled layout of a matrix with D columns

@@ -215,8 +215,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm_dmap(GemmParams p) {
             __half* st = (__half*)(smem_raw + last * STAGE) + wv * (32 * EPI_LD);
             const int gm0 = m0 + wm * WM, gn0 = n0 + wn * WN;
             const bool full = gm0 + WM <= p.M && gn0 + WN <= p.N;
-            lean_store<2>(p, acc, st, le, gm0, gn0, p.N, p.bias, p.residual, p.aux, full);
-            lean_store<2>(p, acc + 2, st, le, gm0 + 32, gn0, p.N, p.bias, p.residual, p.aux, full);
+            lean_store<2, true>(p, acc, st, le, gm0, gn0, p.N, p.bias, p.residual, p.aux, full);
+            lean_store<2, true>(p, acc + 2, st, le, gm0 + 32, gn0, p.N, p.bias, p.residual, p.aux, full);
         }
         // (the next tile's first barrier orders these staging reads before the DMA that reuses the slot)
     }

@@ -89,7 +89,7 @@ __device__ __forceinline__ void gn_tile_stats(const GemmParams& p, const __half*
     }
 }
 
-template <int NI>
+template <int NI, bool HOIST = false>
 __device__ __forceinline__ void lean_store(const GemmParams& p, float4v (*acc)[TN], __half* st, int lane, int gm0,
                                            int gn0, int N, const __half* bias, const __half* residual, const __half* aux, bool full) {
     typedef _Float16 half4e __attribute__((ext_vector_type(4)));
@@ -105,27 +105,63 @@ __device__ __forceinline__ void lean_store(const GemmParams& p, float4v (*acc)[T
             rv[i] = p.rowvec + (long long)vi * p.ldrv;
         }
     }
+    if constexpr (HOIST) {
+    // Every bias / row-vector value of the call is REQUESTED before the first is used (round 6, HOIST; k_gemm_dmap): written
+        // load-use-load-use, the compiler gave each of the up to 25 loads its own s_waitcnt vmcnt(0) - 5 to 25 serialised L2 round trips inside the epilogue.
+        half4e bq[TN], rq[NI][TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = gn0 + j * 16 + fq * 4;
-        float b4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias && n < N) {
-            const half4e b = *(const half4e*)(bias + n);
+        for (int j = 0; j < TN; ++j) {
+            const int n = gn0 + j * 16 + fq * 4;
+            bq[j] = (half4e){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            if (bias && n < N) bq[j] = *(const half4e*)(bias + n);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) b4[r] = (float)b[r];
+            for (int i = 0; i < NI; ++i) {
+                rq[i][j] = (half4e){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                if (p.rowvec && n < N) rq[i][j] = *(const half4e*)(rv[i] + n);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            float a4[4] = {b4[0], b4[1], b4[2], b4[3]};
-            if (p.rowvec && n < N) {
-                const half4e t = *(const half4e*)(rv[i] + n);
+        for (int j = 0; j < TN; ++j) {
+            float b4[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a4[r] += (float)t[r];
+            for (int r = 0; r < 4; ++r) b4[r] = (float)bq[j][r];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                float a4[4] = {b4[0], b4[1], b4[2], b4[3]};
+                if (p.rowvec) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a4[r] += (float)rq[i][j][r];
+                }
+                half4e o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)((acc[i][j][r] + a4[r]) * p.s_acc);
+                *(half4e*)(st + (i * 16 + fr) * EPI_LD + j * 16 + fq * 4) = o;
             }
-            half4e o;
+        }
+    } else {
+        // (the kernels whose accumulators leave no registers for that - k_gemm_widep, k_gemm_z: 160 accumulators - load where they use)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (_Float16)((acc[i][j][r] + a4[r]) * p.s_acc);
-            *(half4e*)(st + (i * 16 + fr) * EPI_LD + j * 16 + fq * 4) = o;
+        for (int j = 0; j < TN; ++j) {
+            const int n = gn0 + j * 16 + fq * 4;
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias && n < N) {
+                const half4e b = *(const half4e*)(bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b4[r] = (float)b[r];
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                float a4[4] = {b4[0], b4[1], b4[2], b4[3]};
+                if (p.rowvec && n < N) {
+                    const half4e t = *(const half4e*)(rv[i] + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a4[r] += (float)t[r];
+                }
+                half4e o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)((acc[i][j][r] + a4[r]) * p.s_acc);
+                *(half4e*)(st + (i * 16 + fr) * EPI_LD + j * 16 + fq * 4) = o;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();      // the staging area is the wavefront's own: program order is enough

@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
     // chunk it fetches for the current k-tile; kPad = the chunk is padding (source: the zero page)
     constexpr unsigned kPad = 0xffffffffu;
     constexpr int NCV = MODE == MODE_DENSE ? 1 : 4;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(MODE == MODE_DENSE ? 0u : p.a_bytes), 0x00020000);
     unsigned cv_off[NCV];
     // MODE_CONV2D walks K as (64-channel chunk, filter tap) with the TAPS INNERMOST - W's [Cout][tap][Cin] rows are read at
     // (tap Cin + 64 chunk) - so the nine shifted reads of one channel slice of an XCD's band of image rows (64 rows x 128 pixels
@@ -227,6 +228,10 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
                 n = n < p.N - 8 ? n : p.N - 8;
                 ob[j] = 2u * (unsigned)n * (unsigned)p.K;
             }
+            // (convolution modes: whatever vector-memory operation this once-per-tile branch left pending - hipcc spills inside
+            // conv_tile - is drained HERE: left to the merge point, the compiler's scoreboard put an s_waitcnt vmcnt(0) behind the
+            // first DMA request of EVERY k-tile)
+            if constexpr (MODE != MODE_DENSE) __builtin_amdgcn_s_waitcnt(0x0F70);
         } else if (TWOSRC && c_ks == kt_switch) {              // from here on the A columns come from the second source
             abase = (const char*)p.A2;
             second = true;
@@ -271,6 +276,11 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
     auto piece = [&](auto IDX) {
         constexpr int idx = decltype(IDX)::value;
         char* st = smem_raw + c_slot;
+        // Convolution modes (round 6): the A pieces go through a BUFFER RESOURCE over the input tensor - a padded chunk is an
+        // out-of-range offset, for which the LDS-DMA writes zeros (tools/ubench/buffer_lds_oob.hip): one 32-bit offset per lane and
+        // piece instead of a 64-bit address selected against a zero page.  (With the 64-bit form hipcc kept the per-lane gather state
+        // in scratch and reloaded it - scratch_load + s_waitcnt vmcnt(0), three times per k-tile, in front of the DMA requests of
+        // groups 0-2 - and re-fetched the zero page's address with an s_load + lgkmcnt(0) inside the k-loop.)
         if constexpr (idx < 4 && MODE == MODE_CONV2D) {
             const unsigned mk = tap_mask << (6 * idx);
             const bool ok = (cv_flags & mk) == mk;
@@ -279,12 +289,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
                 o += (cv_flags & (1u << (24 + 2 * (idx & 3)))) ? 0u : add_y;
                 o += (cv_flags & (2u << (24 + 2 * (idx & 3)))) ? 0u : add_x;
             }
-            const char* src = ok ? (const char*)p.A + (size_t)o : (const char*)g_zero_page;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wv * 4 + idx) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void_t*)(st + (wv * 4 + idx) * 1024), 16, (int)(ok ? o : kPad), 0, 0, 0);
         } else if constexpr (idx < 4 && MODE != MODE_DENSE) {
-            const unsigned o = cv_off[idx < NCV ? idx : 0];
-            const char* src = o == kPad ? (const char*)g_zero_page : (const char*)p.A + (size_t)o;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wv * 4 + idx) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void_t*)(st + (wv * 4 + idx) * 1024), 16, (int)cv_off[idx < NCV ? idx : 0], 0, 0, 0);
         } else if constexpr (idx < 4) {
             const unsigned va = (TWOSRC && second) ? voff_a2 : voff_a;
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase + (size_t)(oa[idx] + va)), (lds_void_t*)(st + (wv * 4 + idx) * 1024), 16, 0, 0);
@@ -367,6 +374,16 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
     for (unsigned tl = blockIdx.x / 8; tl < t_len; tl += t_stride) {
         int m0, n0, tile_n;
         tile_origin(t_start + tl, m0, n0, tile_n);
+        // Convolution modes (round 6): the per-lane gather state of THIS tile is rebuilt here (it was built once already, one k-tile
+        // before the previous tile's epilogue, for the cross-tile request of stage 0).  Carried across the epilogue instead, hipcc
+        // kept it in scratch for the whole kernel and reloaded it inside the k-loop - scratch_load + s_waitcnt vmcnt(0) in front of
+        // the DMA requests, i.e. every k-tile waited for the pieces it had just requested.  ~100 instructions per tile of >= 9 k-tiles.
+        if constexpr (MODE != MODE_DENSE) {
+            if (c_ks == 1 && c_m0 == m0) {               // (the cursor stands one stage into this tile; exhausted or K = 64: keep what it has)
+                conv_tile();
+                if constexpr (MODE == MODE_TCONV) conv_tap(0);
+            }
+        }
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
@@ -389,10 +406,21 @@ __global__ void __launch_bounds__(512, 2) k_gemm_z(GemmParams p) {
             z_read_b<0, RB>(bf, rb); z_read_b<1, RB>(bf, rb); z_read_b<2, RB>(bf, rb);
             if constexpr (LA >= 4) z_read_b<3, RB>(bf, rb);
         }
+        // (every per-lane constant of the k-loop is "used" here: where hipcc reloads one of them from scratch behind the epilogue, the
+        // reload's s_waitcnt lands in front of the loop - left to the first use INSIDE the loop, the scoreboard's merge of the entry
+        // path and the back edge keeps an s_waitcnt vmcnt(0) behind the first DMA request of every k-tile)
+        asm volatile("" :: "v"(voff_a), "v"(voff_a2), "v"(voff_b), "v"(ra[0]), "v"(ra[1]), "v"(rb[0]), "v"(rb[1]));
+        if constexpr (MODE == MODE_CONV2D) asm volatile("" :: "v"(cv_base[0]), "v"(cv_base[1]), "v"(cv_base[2]), "v"(cv_base[3]), "v"(cv_flags));
+        if constexpr (MODE == MODE_TCONV) asm volatile("" :: "v"(cv_off[0]), "v"(cv_off[1]), "v"(cv_off[2]), "v"(cv_off[3]));
         for (int kt = 0; kt < nkt; ++kt) {
             // groups 0-8 carry the nine DMA pieces of the NEXT stage (into the slot the previous barrier released)
             ZSTAMP(5);
             cursor_begin();
+            // (convolution modes: where hipcc keeps the gather state in scratch, this use makes it reload ALL of it here - no DMA
+            // request of this k-tile is in flight yet, so the reload's s_waitcnt vmcnt(0) waits for the scratch loads alone - instead
+            // of piece by piece behind the requests of groups 0-2)
+            if constexpr (MODE == MODE_CONV2D) asm volatile("" :: "v"(cv_base[0]), "v"(cv_base[1]), "v"(cv_base[2]), "v"(cv_base[3]), "v"(cv_flags));
+            if constexpr (MODE == MODE_TCONV) asm volatile("" :: "v"(cv_off[0]), "v"(cv_off[1]), "v"(cv_off[2]), "v"(cv_off[3]));
             Z_GROUP(0); Z_GROUP(1); Z_GROUP(2); Z_GROUP(3); Z_GROUP(4); Z_GROUP(5); Z_GROUP(6); Z_GROUP(7);
             Z_GROUP(8);
             ZSTAMP(0);
