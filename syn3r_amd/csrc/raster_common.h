@@ -38,7 +38,7 @@ static_assert(sizeof(Splat) == 48, "Splat must be 48 bytes");
 
 // Geometry state carved from the caller's buffer (all arrays 256-byte aligned).
 struct GeomState {
-    unsigned* header;        // [0] = number of (Gaussian, tile) pairs, [1] = 1 if a render ran out of pair capacity, [2] = entries of the super-tile lists
+    unsigned* header;        // [0] = number of (Gaussian, tile) pairs (the EXACT count, [3], when the lists were clipped), [1] = 1 if a render ran out of pair capacity, [2] = entries of the super-tile lists, [3] = sum of the tile rectangles' areas (hierarchical binning)
     float* depths;           // [N]
     float* means2D;          // [N,2]
     float* cov3D;            // [N,6]

@@ -388,13 +388,16 @@ __device__ __forceinline__ unsigned block_scan_1024(unsigned v, unsigned* smem /
     return res;
 }
 
-// Super-tiles of 4 x 4 tiles where that gives at most 512 of them (up to ~1080p: short lists, a block per list sorts ~600 keys),
-// else 8 x 8 (up to ~4K); `ss` = log2 of the side.  The Gaussians go through the count / append kernels in chunks of
+// Super-tiles of the SMALLEST side (1, 2, 4, 8 tiles) that gives at most 512 of them: 4 x 4 at 1080p (510 super-tiles, a block per
+// list sorts ~1 000 keys), 8 x 8 up to ~4K; 2 x 2 at the LLFF / DTU image sizes the reference trains on (504 x 378: 192 super-tiles -
+// with 4 x 4 its 48 lists of a 200 000-Gaussian model were ~4x longer than the LDS piece and k_super_sort's single-block global-
+// memory merge took 370 of the iteration's 957 us, profiles/r06/raster_breakdown_504x378.txt), single tiles below 512
+// tiles; `ss` = log2 of the side.  The Gaussians go through the count / append kernels in chunks of
 // rounds x 512, as many chunks as keep the (chunk, super-tile) count table within kBinCounters.
 struct BinPlan { int ss, sgx, sgy, nsuper, rounds, nchunks; bool ok; };
 inline BinPlan bin_plan(int N, int gx, int gy) {
     BinPlan b;
-    for (b.ss = 2; b.ss <= 3; ++b.ss) {
+    for (b.ss = 0; b.ss <= 3; ++b.ss) {
         const int side = 1 << b.ss;
         b.sgx = (gx + side - 1) / side; b.sgy = (gy + side - 1) / side;
         b.nsuper = b.sgx * b.sgy;
@@ -434,14 +437,16 @@ __device__ __forceinline__ unsigned short clip_rect(const BinRect& q, int sx, in
 
 __global__ void __launch_bounds__(kBinThreads) k_super_count(int N, const float* __restrict__ means2D, const int* __restrict__ radii,
                                                              int gx, int gy, int ss, int sgx, int nsuper, int rounds, int nchunks,
-                                                             unsigned* __restrict__ counters) {
+                                                             unsigned* __restrict__ counters, unsigned* __restrict__ header) {
     __shared__ unsigned tot[kMaxSuper];
     for (int s = threadIdx.x; s < nsuper; s += kBinThreads) tot[s] = 0u;
     __syncthreads();
+    int pairs = 0;            // the EXACT number of (Gaussian, tile) pairs of this block's Gaussians: header[3] (see k_tile_offsets)
     for (int r = 0; r < rounds; ++r) {
         const int i = (blockIdx.x * rounds + r) * kBinThreads + threadIdx.x;
         const BinRect q = bin_rect(i, N, means2D, radii, gx, gy);
         if (q.x1 > q.x0 && q.y1 > q.y0) {
+            pairs += (q.x1 - q.x0) * (q.y1 - q.y0);
             const int side1 = (1 << ss) - 1, sx0 = q.x0 >> ss, sx1 = (q.x1 + side1) >> ss, sy0 = q.y0 >> ss, sy1 = (q.y1 + side1) >> ss;
             for (int sy = sy0; sy < sy1; ++sy)
                 for (int sx = sx0; sx < sx1; ++sx) atomicAdd(&tot[sy * sgx + sx], 1u);
@@ -449,6 +454,8 @@ __global__ void __launch_bounds__(kBinThreads) k_super_count(int N, const float*
     }
     __syncthreads();
     for (int s = threadIdx.x; s < nsuper; s += kBinThreads) counters[(size_t)blockIdx.x * nsuper + s] = tot[s];   // chunk-major: k_super_append reads it coalesced
+    pairs = wave_sum_i(pairs);
+    if ((threadIdx.x & 63) == 0 && pairs) atomicAdd(&header[3], (unsigned)pairs);     // (integer: any order gives the same sum)
 }
 
 // Appends the keys (depth bits << 32 | index) of this chunk's Gaussians to the lists of the super-tiles their rectangles meet.
@@ -734,8 +741,13 @@ __global__ void __launch_bounds__(kOffThreads) k_tile_offsets(int tiles, const u
         }
     }
     if (threadIdx.x == 0) {
-        header[0] = carry;
-        if (carry > cap || header[2] > cap) header[1] = 1u;
+        // `carry` sums the per-tile counts taken from super-tile lists that are CLIPPED to the capacity: once a render overflows it
+        // under-counts (every key past `cap` is dropped and uncounted), and a caller that sizes its next buffer from header[0] would
+        // at best double per round.  header[3] is the exact pair count (sum of the tile rectangles' areas, k_super_count): reported
+        // whenever the lists did not fit, so ONE re-render recovers (tests/test_raster_gpu.py).
+        const bool over = carry > cap || header[2] > cap;
+        header[0] = over ? max(carry, max(header[3], header[2])) : carry;
+        if (over) header[1] = 1u;
     }
 }
 
@@ -1036,7 +1048,7 @@ extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const i
         static DevOnce once;
         if (int rc2 = set_max_lds(once, (const void*)k_super_sort, kSortLds * 8, "hipFuncSetAttribute(super_sort)")) return rc2;
         SYN3R_LAUNCH(k_super_count, dim3(bp.nchunks), dim3(kBinThreads), 0, stream, N, (const float*)g.means2D, radii, gx, gy, bp.ss, bp.sgx,
-                     bp.nsuper, bp.rounds, bp.nchunks, counters);
+                     bp.nsuper, bp.rounds, bp.nchunks, counters, g.header);
         SYN3R_LAUNCH(k_super_append, dim3(bp.nchunks), dim3(kBinThreads), 0, stream, N, (const float*)g.depths, (const float*)g.means2D, radii,
                      gx, gy, bp.ss, bp.sgx, bp.nsuper, bp.rounds, bp.nchunks, (const unsigned*)counters, sstart, (unsigned)P, skeys, g.header);
         SYN3R_LAUNCH(k_super_sort, dim3(bp.nsuper), dim3(kSuperSortThreads), kSortLds * 8, stream, N, (const float*)g.means2D, radii, gx, gy,

@@ -567,6 +567,11 @@ class GSTrainer:
         dev = g._xyz.device
         N = g._xyz.shape[0]
         stream = L.stream_ptr(dev)
+        # this step discards the rasteriser's confidence gradient (slot 6 of its backward): the per-Gaussian confidence is data here,
+        # as in the call sites (model/diffusionGS.py:139,1640); a trainable one has to take the autograd path
+        conf = g.confidence
+        if conf is not None and getattr(conf, "requires_grad", False):
+            raise ValueError("_explicit_step: a confidence tensor that requires grad needs train_step(explicit=False)")
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         with torch.no_grad():
             sc, ro, op = new(N, 3), new(N, 4), new(N, 1)
@@ -587,7 +592,10 @@ class GSTrainer:
             else:
                 loss = _L1Loss.forward(lctx, color, cam.original_image, w)
                 d_color = _L1Loss.backward(lctx, self._one(dev))[0]
-            d_m3, d_m2, d_sh, d_op, d_sc, d_ro, _, _ = _Rasterize.backward(rctx, d_color, None, None, None)
+            grads = _Rasterize.backward(rctx, d_color, None, None, None)
+            if len(grads) != 8:      # (means3D, means2D, sh, opacity, scales, rotations, confidence, settings): the order this step reads
+                raise RuntimeError(f"_Rasterize.backward returned {len(grads)} gradients, the explicit step reads 8")
+            d_m3, d_m2, d_sh, d_op, d_sc, d_ro, _, _ = grads
             d_ls, d_rr, d_lg = new(N, 3), new(N, 4), new(N, 1)
             L.check(lib.syn3r_gaussian_activate_backward(N, L.ptr(g._rotation), L.ptr(sc), L.ptr(ro), L.ptr(op), L.ptr(d_sc),
                                                          L.ptr(d_ro), L.ptr(d_op), L.ptr(d_ls), L.ptr(d_rr), L.ptr(d_lg), stream),

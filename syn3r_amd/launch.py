@@ -87,8 +87,51 @@ def parse(argv: Optional[Sequence[str]] = None) -> argparse.Namespace:
     # FSGS' parameter groups (scripts/train.py:44-46: -s, --eval, --n_views, --resolution, --use_dust3r ... of the batch scripts)
     # belong to the absent submodule: a command line that carries them is accepted, they are kept in `ignored_flags`
     args, rest = ap.parse_known_args(argv)
+    # Only the flags of FSGS' ModelParams / OptimizationParams / PipelineParams groups that the reference's batch scripts pass
+    # (bash_scripts/*.sh) are tolerated; anything else is a misspelling of one of ours and an error - a dropped
+    # `--iteratons 500` must not start a multi-hour job on the defaults.
+    unknown = [t for t in rest if t.startswith("-") and not _is_number(t) and t not in FSGS_FLAGS]
+    if unknown:
+        ap.error(f"unknown argument(s): {' '.join(unknown)} (flags of the FSGS parameter groups that are accepted and ignored: "
+                 f"{' '.join(sorted(FSGS_FLAGS))})")
     args.ignored_flags = list(rest)
     return args
+
+
+# scripts/train.py:44-46 builds FSGS' three parameter groups on the parser; these are the flags of theirs that the reference's
+# bash_scripts/batch_{llff,dtu,dl3dv}_train.sh pass on the command line
+FSGS_FLAGS = frozenset([
+    "-s", "--source_path", "-m", "-r", "--resolution", "--images", "-i", "--eval", "--n_views", "--use_dust3r", "--rand_pcd",
+    "--num_train_samples", "--sample_pseudo_interval", "--sample_svd_pseudo_interval", "--start_sample_svd_frame",
+    "--start_sample_pseudo", "--end_sample_pseudo", "--svd_depth_warmup", "--svd_lpips_weight", "--use_proximity_densify",
+    "--percent_dense", "--densify_grad_threshold", "--densify_from_iter", "--densify_until_iter", "--densification_interval",
+    "--opacity_reset_interval", "--position_lr_init", "--position_lr_final", "--position_lr_max_steps", "--feature_lr",
+    "--opacity_lr", "--scaling_lr", "--rotation_lr", "--depth_weight", "--depth_pseudo_weight", "--white_background", "--sh_degree",
+    "--data_device", "--convert_SHs_python", "--compute_cov3D_python", "--debug", "--checkpoint", "--video", "-a", "-p", "-f", "-d",
+])
+# the types the orchestrator accepts (model/diffusionGS.py:115-124, :244-255; syn3r_amd/diffusionGS.py raises on the rest)
+DIFFUSION_TYPES = ("2PassProbUncertain", "2PassProbUncertainPost")
+DENSIFY_TYPES = ("interpolate_loop0_gs", "interpolate_gs_v2")
+
+
+def _is_number(t: str) -> bool:
+    try:
+        float(t)
+        return True
+    except ValueError:
+        return False
+
+
+def validate(args) -> None:
+    """What `parse` cannot reject without departing from the reference's parser (whose DEFAULTS, '2Pass' / 'interpolate', are
+    types its own orchestrator refuses): checked by `main` before any GPU work, so a bad command line exits non-zero instead
+    of producing one NaN record per scene."""
+    if args.diffusion_type not in DIFFUSION_TYPES:              # (DiffusionGS.__init__ raises on it whatever the cycle count)
+        raise SystemExit(f"--diffusion_type {args.diffusion_type!r} is not accepted by the orchestrator (model/diffusionGS.py:115-124): "
+                         f"pass one of {', '.join(DIFFUSION_TYPES)}")
+    if args.refine_cycle_num > 0 and args.densify_type not in DENSIFY_TYPES:
+        raise SystemExit(f"--densify_type {args.densify_type!r} is not accepted by the orchestrator (model/diffusionGS.py:244-255): "
+                         f"pass one of {', '.join(DENSIFY_TYPES)}")
 
 
 def synthetic_scene(name: str, args, device) -> dict:
@@ -190,6 +233,7 @@ def run_scene(name: str, args, device, factory: Callable) -> List[float]:
 
 def main(argv: Optional[Sequence[str]] = None) -> int:
     args = parse(argv)
+    validate(args)
     rank, world, local = D.init(args.backend)
     if rank == 0 and args.ignored_flags:
         print(f"[syn3r] flags of the absent FSGS parameter groups ignored: {' '.join(args.ignored_flags)}", file=sys.stderr, flush=True)

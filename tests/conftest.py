@@ -46,3 +46,10 @@ def record_measurement(name: str, **values) -> None:
             f.write(json.dumps({"test": name, **values}) + "\n")
     except OSError:
         pass
+
+
+@pytest.fixture
+def measurements():
+    """`record_measurement` as a fixture (tests need not import this module as `tests.conftest`, which depends on the rootdir
+    being on sys.path)."""
+    return record_measurement

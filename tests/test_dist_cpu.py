@@ -1,4 +1,5 @@
 """Scene-parallel path with world_size 2 over gloo on the CPU (the N>1 path of bench.py)."""
+import pytest
 import os
 import socket
 import subprocess
@@ -117,3 +118,15 @@ def test_launcher_defaults_are_the_reference_scripts(golden_dir):
                      "--num_views_for_pcd_densification 1 -s /data/fern --eval --n_views 3 --resolution 1 --use_dust3r 0".split())
     assert b.refine_cycle_num == 2 and b.num_views_for_pcd_densification == 1 and b.weight_clamp == 0.2
     assert b.ignored_flags == ["-s", "/data/fern", "--eval", "--n_views", "3", "--resolution", "1", "--use_dust3r", "0"]
+    launch.validate(b)
+    # ... but only those: a misspelled flag of ours is an error, not a silently dropped setting
+    for bad in (["--iteratons", "500"], ["--lambda-dssim", "0.3"], ["--diffusion-type", "2PassProbUncertain"]):
+        with pytest.raises(SystemExit):
+            launch.parse(["--scenes", "x"] + bad)
+    # the reference's own defaults name types its orchestrator refuses (model/diffusionGS.py:115-124, :244-255): rejected before any
+    # GPU work instead of one NaN record per scene
+    with pytest.raises(SystemExit, match="diffusion_type"):
+        launch.validate(launch.parse(["--scenes", "x"]))
+    with pytest.raises(SystemExit, match="densify_type"):
+        launch.validate(launch.parse(["--scenes", "x", "--diffusion_type", "2PassProbUncertainPost"]))
+    launch.validate(launch.parse(["--scenes", "x", "--diffusion_type", "2PassProbUncertainPost", "--refine_cycle_num", "0"]))

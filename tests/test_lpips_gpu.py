@@ -19,7 +19,7 @@ def _images(H, W, seed):
 
 
 @pytest.mark.parametrize("H,W", [(64, 96), (50, 70), (136, 240)])
-def test_lpips_value_and_gradient_vs_oracle(gpu, H, W):
+def test_lpips_value_and_gradient_vs_oracle(gpu, H, W, measurements):
     from syn3r_amd.gs.lpips import LPIPS
     m = LPIPS().init_random(gpu, seed=3)
     sd = {}
@@ -43,11 +43,15 @@ def test_lpips_value_and_gradient_vs_oracle(gpu, H, W):
     gh, go = pred.grad.double().cpu(), ao.grad
     rel = float((gh - go).norm() / go.norm())
     cos = float((gh * go).sum() / (gh.norm() * go.norm()))
-    from tests.conftest import record_measurement
-    record_measurement(f"lpips:{H}x{W}", value_rel=abs(float(loss) - float(ref)) / abs(float(ref)), grad_rel=rel, grad_cos=cos)
+    measurements(f"lpips:{H}x{W}", value_rel=abs(float(loss) - float(ref)) / abs(float(ref)), grad_rel=rel, grad_cos=cos)
     # measured (round 5, gpurun_out/test_measurements.jsonl): value 9e-7 .. 2.5e-5 relative, gradient 5.4-5.7e-2 relative, cosine
     # 0.9983-0.9986 (the gradient's error is the 13 fp16 backward-data convolutions, profiles/r04/lpips_layers.txt)
     assert abs(float(loss.detach()) - float(ref.detach())) < 1e-4 * abs(float(ref.detach())), (float(loss.detach()), float(ref.detach()))
+    # The gradient bar is NOT the suite's "2x the measurement" rule, on purpose: 2 x 5.7e-2 would accept a gradient that is 11 % off, i.e.
+    # say nothing.  The error is the fp16 rounding of the 13 backward-data convolutions' activations and gradients against a float64
+    # chain (per-layer table: profiles/r04/lpips_layers.txt); the bars sit ~5 % above the worst recorded value (5.7e-2, cosine 0.9983),
+    # so a change of accumulation order may trip them - re-measure (gpurun_out/test_measurements.jsonl) before moving them, and the LPIPS
+    # weights are unpinned anyway.
     assert rel < 6e-2 and cos > 0.998, (rel, cos)              # fp16 activations / gradients against float64
     # a second call with the same target object reuses its cached features and gives the same number
     assert float(m(pred.detach(), target)) == float(loss)

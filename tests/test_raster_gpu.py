@@ -199,6 +199,26 @@ def test_async_pair_count_mode_matches_sync(gpu):
         with pytest.raises(Exception):
             raster.flush_pair_checks()
         assert raster._capacity[key] > 16
+        # ONE re-render recovers: the overflowed render reports the exact pair count (the sum of the tile rectangles' areas), not
+        # the count of its clipped lists - a larger scene, > 100 000 pairs against a capacity of 16
+        big = scene(30000, 128, 192, seed=5)
+        (cb, _, db, ab), _, _ = hip_render(big, gpu)            # (sync mode: sized exactly)
+        raster.set_pair_count_mode("async")
+        kb = (gpu.index, big["N"], big["H"], big["W"])
+        stb = GaussianRasterizationSettings(big["H"], big["W"], big["tfx"], big["tfy"], f(big["bg"]), 1.0, f(big["view"]),
+                                            f(big["proj"]), 3, f(big["campos"]), False, False)
+        rb = lambda: GaussianRasterizer(stb)(f(big["m"]), None, f(big["o"]), shs=f(big["sh"]), scales=f(big["s"]), rotations=f(big["q"]))
+        rb(); raster.flush_pair_checks()                         # first call of the shape sizes exactly and records the true count
+        true_cap = raster._capacity[kb]
+        assert true_cap > 100000
+        raster._capacity[kb] = 16
+        rb()
+        with pytest.raises(Exception):
+            raster.flush_pair_checks()
+        assert raster._capacity[kb] >= true_cap - 8192, (raster._capacity[kb], true_cap)     # not merely doubled
+        c2, _, d2, a2 = rb()
+        raster.flush_pair_checks()                               # no overflow this time
+        assert torch.equal(c2, cb) and torch.equal(d2, db) and torch.equal(a2, ab)
     finally:
         raster._pending.clear()
         raster.set_pair_count_mode("sync")

@@ -96,6 +96,41 @@ def test_explicit_step_equals_autograd_step(lambda_dssim, gpu):
         assert ((a - b).abs() > 1e-6).double().mean() < 1e-3          # Adam's first step is lr * sign(grad)
 
 
+@pytest.mark.parametrize("looks_away", [False, True])
+def test_explicit_step_density_statistics_equal_autograd_path(looks_away, gpu):
+    """With the density control on: the explicit step hands `add_densification_stats` the radii (its visible set is
+    radii > 0, one HIP launch) where the autograd path hands it a boolean filter - the accumulators agree; and a view that sees
+    no Gaussian at all (camera turned away: N_visible = 0) steps without error, with zero gradients and untouched statistics.
+    A confidence tensor that asks for a gradient is refused by the explicit step (it discards that gradient)."""
+    from syn3r_amd.gs import Camera, GSTrainer, OptimizationParams
+    N, H, W = 2000, 64, 96
+    w2c = np.eye(4, dtype=np.float32)
+    if looks_away:
+        w2c = np.diag([-1.0, 1.0, -1.0, 1.0]).astype(np.float32)      # half a turn about y: the cloud is behind the camera
+    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(9))
+    stats = []
+    for explicit in (True, False):
+        gm, K = make_scene(N, H, W, 13, gpu)
+        cam = Camera.from_w2c(w2c, K, H, W, image=target, data_device=gpu, cam_confidence=1.0)
+        tr = GSTrainer(gm, [cam], OptimizationParams(iterations=10, lambda_dssim=0.2))
+        tr.densify = True
+        tr.train_step(cam, explicit=explicit)
+        torch.cuda.synchronize()
+        stats.append((gm.xyz_gradient_accum.clone(), gm.denom.clone(), gm.max_radii2D.clone(), [p.detach().clone() for p in gm.parameters()]))
+    (a_acc, a_den, a_rad, a_par), (b_acc, b_den, b_rad, b_par) = stats
+    assert torch.equal(a_den, b_den) and torch.equal(a_rad, b_rad)
+    assert float((a_acc - b_acc).abs().max()) <= 2e-5 * (float(b_acc.abs().max()) + 1e-20)
+    if looks_away:
+        assert float(a_den.sum()) == 0.0 and float(a_acc.abs().sum()) == 0.0
+    for x, y in zip(a_par, b_par):
+        assert ((x - y).abs() > 1e-6).double().mean() < 1e-3
+    gm, K = make_scene(N, H, W, 13, gpu)
+    gm.confidence = torch.ones(N, device=gpu, requires_grad=True)
+    cam = Camera.from_w2c(np.eye(4, dtype=np.float32), K, H, W, image=target, data_device=gpu)
+    with pytest.raises(ValueError, match="confidence"):
+        GSTrainer(gm, [cam], OptimizationParams(iterations=1))._explicit_step(cam)
+
+
 def test_training_loop_fits_a_view(gpu):
     from syn3r_amd.gs import Camera, GSTrainer, OptimizationParams
     N, H, W = 1500, 64, 96

@@ -1,5 +1,5 @@
 """Per-kernel device time of the bench's raster iteration (developer tool):
-python tools/raster_breakdown.py [iters] [l1|l1+ssim]"""
+python tools/raster_breakdown.py [iters] [l1|l1+ssim] [height width [gaussians]]   (e.g. 20 l1 378 504: an LLFF / DTU-size image)"""
 import sys
 import time
 from pathlib import Path
@@ -11,7 +11,10 @@ from syn3r_amd import _lib as L, raster
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 loss = sys.argv[2] if len(sys.argv) > 2 else "l1"
-sys.argv = sys.argv[:1] + ["--loss", loss]
+extra = []
+if len(sys.argv) > 4:
+    extra = ["--height", sys.argv[3], "--width", sys.argv[4]] + (["--gaussians", sys.argv[5]] if len(sys.argv) > 5 else [])
+sys.argv = sys.argv[:1] + ["--loss", loss] + extra
 args = bench.parse()
 loop = bench.RasterLoop(args, torch.device("cuda", 0))
 for _ in range(5):
