@@ -36,6 +36,11 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
 # vector-instruction issue: 256 CUs x 4 SIMDs, one wave64 VALU instruction per SIMD every 4 cycles (MI355X_MICROARCH.md, cycle
 # constants: v_fma_f32 "one wave alone: 4") at the 2.4 GHz maximum clock = 614.4 G wave-instructions / s
 VALU_ISSUE_PEAK_GINST = 256 * 4 * 2.4 / 4.0   # = 614.4 G wave-instructions / s
+# ... and what the chip MEASURES for that roof: tools/ubench/valu_rate.hip, raw output in profiles/r06/valu_rate.txt - 8 independent
+# v_fma_f32 per iteration, 1 / 2 / 4 wavefronts per SIMD: 3.88 / 2.02 / 2.11 ns per wave-instruction and SIMD (2.06 beside an MFMA).  One
+# wavefront alone is latency-bound; from two wavefronts on a wave64 VALU instruction occupies its SIMD for 2.02-2.11 ns = 4 cycles at the
+# 1.9-2.0 GHz the chip holds under that load - 4 cycles, not the 2 of the guide's SIMD-32 row.  1024 SIMDs / 2.02 ns:
+VALU_ISSUE_MEASURED_GINST = 1024 / 2.02       # = 506.9 G wave-instructions / s (profiles/r06/valu_rate.txt, best of the 2 / 4 wavefront rows)
 # SQ_INSTS_VALU per launch of the blend kernels on the bench scene (200 000 Gaussians, 1920x1080, seed 0), used when the committed
 # PMC summary of THIS build carries none: profiles/r05/pmc/pmc_counters_by_kernel.json (the same counts as round 4's: the blend
 # loops are unchanged, round 5 changed the order in which the tiles are taken and how their lists are built)
@@ -343,12 +348,17 @@ def other_rooflines(kern, alg, loop_b, units):
             # the roof that binds them: vector-instruction ISSUE.  Executed wave-instructions per launch come
             # from the SQ_INSTS_VALU pass of the committed PMC summary (this build's if it has one), the launch time is measured here.
             insts, src = _pmc_traffic(name, field="valu_insts_per_launch")
-            if insts is None:
+            stale = insts is None       # no PMC summary of THIS build's sources: an earlier build's count, said so in the line
+            if stale:
                 insts, src = VALU_INSTS_FALLBACK[name]
             ginst = insts / avg_s / 1e9
             ach = alg[name] / avg_s / 1e9
             out[name] = dict(bound="valu_issue", achieved=round(ginst, 1), peak=round(VALU_ISSUE_PEAK_GINST, 1), unit="G wave-instructions/s",
-                             frac=round(ginst / VALU_ISSUE_PEAK_GINST, 4), valu_insts_per_launch=int(insts), valu_insts_source=src,
+                             frac=round(ginst / VALU_ISSUE_PEAK_GINST, 4), stale=stale,
+                             frac_of_measured_issue_rate=round(ginst / VALU_ISSUE_MEASURED_GINST, 4),
+                             measured_issue_rate=dict(value=round(VALU_ISSUE_MEASURED_GINST, 1), unit="G wave-instructions/s",
+                                                      source="profiles/r06/valu_rate.txt: v_fma_f32, 2 wavefronts per SIMD, 2.02 ns per instruction and SIMD"),
+                             valu_insts_per_launch=int(insts), valu_insts_source=src,
                              avg_ms=round(ms / calls, 4), calls=calls,
                              hbm_byte_model=dict(note="SURVEY 8d byte model: how far the traffic is from mattering, not the binding roof",
                                                  achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
