@@ -464,6 +464,18 @@ int pack_weights(syn3r_unet& m, const StFile& f, std::vector<HostPack>& packs) {
                 }
             }
             packs.push_back(std::move(pw)); packs.push_back(std::move(pb));
+            if (K != 320 && D % 128 == 0) {                                              // ops.pack_geglu64 beside it: per 64-wide hidden chunk [64 hidden | 64 gate] (k_gemm_g256, round 6)
+                HostPack qw, qb;
+                qw.name = pre + "geglu_w64"; qb.name = pre + "geglu_b64";
+                qw.rows = 2 * D; qw.cols = K; qw.d.resize((size_t)(2 * D * K)); qb.rows = 2 * D; qb.cols = 1; qb.d.resize((size_t)(2 * D));
+                for (long long j = 0; j < D / 64; ++j) {
+                    memcpy(&qw.d[(size_t)(128 * j * K)], &wv[(size_t)(64 * j * K)], (size_t)(64 * K) * 2);
+                    memcpy(&qw.d[(size_t)((128 * j + 64) * K)], &wv[(size_t)((D + 64 * j) * K)], (size_t)(64 * K) * 2);
+                    memcpy(&qb.d[(size_t)(128 * j)], &bv[(size_t)(64 * j)], 64 * 2);
+                    memcpy(&qb.d[(size_t)(128 * j + 64)], &bv[(size_t)(D + 64 * j)], 64 * 2);
+                }
+                packs.push_back(std::move(qw)); packs.push_back(std::move(qb));
+            }
         }
     }
     {
@@ -820,7 +832,14 @@ struct Run {
             const size_t wsb = syn3r_feedforward_workspace_bytes((int)x.rows, D);
             void* ws = ok() ? ar.alloc(wsb) : nullptr;
             if (ok() && !ws) { set_error("unet_forward: workspace too small (needs syn3r_unet_workspace_bytes)"); rc = SYN3R_E_WORKSPACE; }
-            if (go())
+            // model.py:_ff - net.0 on the 256 x 256 tile where the shape has whole tiles (bit-identical to the 80-column path)
+            static const int g256_env = tune_env("SYN3R_FF_G256", 1);
+            const bool p64 = g256_env != 0 && m.w.count(pre + ".net.0.proj.geglu_w64") && syn3r_feedforward_p64_supported((int)x.rows, D, x.cols);
+            if (go() && p64)
+                chk(syn3r_feedforward_p64_f16(x.p, x.cols, Wp(pre + ".net.0.proj.geglu_w64"), Wp(pre + ".net.0.proj.geglu_b64"), D, Wp(w2), Wp(b2), out.p, N,
+                                              e.residual ? e.residual->p : nullptr, e.residual ? e.residual->cols : 0, e.aux ? e.aux->p : nullptr,
+                                              e.aux ? e.aux->cols : 0, e.s_acc, e.s_res, e.s_aux, (int)x.rows, x.cols, N, ws, wsb, stream));
+            else if (go())
                 chk(syn3r_feedforward_f16(x.p, x.cols, Wp(pre + ".net.0.proj.geglu_w"), Wp(pre + ".net.0.proj.geglu_b"), D, Wp(w2), Wp(b2), out.p, N,
                                           e.residual ? e.residual->p : nullptr, e.residual ? e.residual->cols : 0, e.aux ? e.aux->p : nullptr,
                                           e.aux ? e.aux->cols : 0, e.s_acc, e.s_res, e.s_aux, (int)x.rows, x.cols, N, ws, wsb, stream));
