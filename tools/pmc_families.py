@@ -13,7 +13,7 @@ import csv
 import json
 import sys
 
-FAMILIES = [("k_gemm_widep", "k_gemm_widep"), ("k_gemm_z", "k_gemm_z"), ("k_gemm_dmap", "k_gemm_dmap"), ("k_gemm_dma<1, 256>", "k_gemm_dma<1,256>"),
+FAMILIES = [("k_gemm_g256", "k_gemm_g256"), ("k_gemm_dmapd", "k_gemm_dmapd"), ("k_gemm_widep", "k_gemm_widep"), ("k_gemm_z", "k_gemm_z"), ("k_gemm_dmap", "k_gemm_dmap"), ("k_gemm_dma<1, 256>", "k_gemm_dma<1,256>"),
             ("k_gemm_dma<1,256>", "k_gemm_dma<1,256>"), ("k_gemm_dma", "k_gemm_dma<other>"), ("k_gemm_w128", "k_gemm_w128"),
             ("k_ffn320", "k_ffn320"), ("k_lnlin320", "k_lnlin320"), ("k_gemm_skinny", "k_gemm_skinny"), ("k_attn_spatial", "k_attn_spatial"),
             ("k_attn_temporal", "k_attn_temporal"), ("k_render_bwd", "k_render_bwd"), ("k_render", "k_render"),
