@@ -363,7 +363,7 @@ int syn3r_feedforward_f16(const void* x, long long ldx, const void* w1_packed, c
  * syn3r_feedforward_f16 with net.0 on the persistent 256 x 256 tile (round 6, k_gemm_g256: a second look-ahead stage for the
  * A operand, LDS-free epilogue into the tiled hidden activation; attention.py:608-665, activations.py GEGLU).
  *   w1_packed64 / b1_packed64: the rows of net.0.proj regrouped per 64-wide hidden chunk j as [hidden 64j..64j+63 | gate
- *   64j..64j+63] ([2 D, C_in] / [2 D]).  Shapes: syn3r_feedforward_p64_supported(M, D, C_in) (whole tiles: M % 256 == 0,
+ *   64j..64j+63] ([2 D, C_in] / [2 D]).  Shapes: syn3r_feedforward_p64_supported(M, D, C_in) (M % 128 == 0, M >= 256,
  *   D % 128 == 0, C_in >= 128 a multiple of 64), x with dense rows (ldx == C_in); everything else as syn3r_feedforward_f16,
  *   whose results it reproduces bit for bit (same accumulation order, same gate).
  */

@@ -115,14 +115,14 @@ int launch_widep(const GemmParams& p, hipStream_t stream) {
 
 // k_gemm_g256 (gemm_g256.h): the gated projection on whole 256 x 256 tiles into the A-tiled hidden activation
 bool g256_admits(const GemmParams& p) {
-    return p.geglu_D > 0 && p.out_tiled && !p.a_tiled && !p.A2 && !p.rowvec && !p.residual && !p.aux && p.s_acc == 1.0f && p.M % 256 == 0 &&
+    return p.geglu_D > 0 && p.out_tiled && !p.a_tiled && !p.A2 && !p.rowvec && !p.residual && !p.aux && p.s_acc == 1.0f && p.M % 128 == 0 && p.M >= 256 &&
            p.geglu_D % 128 == 0 && p.N == 2 * p.geglu_D && p.K >= 2 * BK && p.lda % 8 == 0 && (long long)p.M * p.lda < (1ll << 31) &&
            (long long)p.N * p.K < (1ll << 31);
 }
 int launch_g256(const GemmParams& p, hipStream_t stream) {
     static DevOnce once;
     if (int rc = set_max_lds(once, (const void*)k_gemm_g256, G_LDS, "hipFuncSetAttribute(gemm_g256)")) return rc;
-    const int tiles = (p.M / 256) * (p.N / 256);
+    const int tiles = ((p.M + 255) / 256) * (p.N / 256);
     const int blocks = std::min(tiles, persistent_blocks());
     GemmParams q = p;
     static const int band_env = tune_env("SYN3R_G256_BAND", 0);
@@ -586,7 +586,7 @@ extern "C" int syn3r_feedforward_f16(const void* x, long long ldx, const void* w
 }
 
 extern "C" int syn3r_feedforward_p64_supported(int M, int D, int C_in) {
-    return (SYN3R_DIM_OK(M) && SYN3R_DIM_OK(D) && SYN3R_DIM_OK(C_in) && M % 256 == 0 && D % 128 == 0 && C_in % BK == 0 && C_in >= 2 * BK &&
+    return (SYN3R_DIM_OK(M) && SYN3R_DIM_OK(D) && SYN3R_DIM_OK(C_in) && M % 128 == 0 && M >= 256 && D % 128 == 0 && C_in % BK == 0 && C_in >= 2 * BK &&
             (long long)M * C_in < (1ll << 31) && 2ll * D * C_in < (1ll << 31)) ? 1 : 0;
 }
 

@@ -50,7 +50,14 @@ __device__ __forceinline__ void ln_tile320(char* smem_raw, int tid, int m0, int 
     // row swizzle: the 2-way conflict of profiles/r05/pmc; chunks part / part + 4 put a group's rows on disjoint bank quarters).
     {
         const int r = tid >> 2, part = tid & 3;
-        half8 xv[5][2], addv[5][2];
+        // Which of its two chunks a thread touches FIRST alternates with bit 1 of the row (f): the 16 lanes of a ds_read_b128 /
+        // ds_write_b128 pass are four consecutive rows x four parts, a row's pass covers one 64-byte quarter of the 256-byte bank
+        // space - quarter 2 (r & 1) + (e ^ (r >> 2 & 1)) with chunks part / part + 4 in a fixed order, i.e. rows r and r + 2 on the
+        // SAME quarter (the 2-way conflict that was left: 0.25 of the kernel's LDS cycles, profiles/r06/pmc); with slot e reading chunk
+        // part + 4 (e ^ f) the four rows take the four quarters.  The partial sums keep their identity (sa: chunks part, sb: chunks
+        // part + 4, each summed over the k-tiles in order), so the bits are k_layernorm<8>'s as before.
+        const int f = (r >> 1) & 1;
+        half8 xv[5][2], addv[5][2];        // [k-tile][slot]: slot e holds chunk part + 4 (e ^ f)
         if (add) {       // requested before the wait for the x tile: one latency, not two
             int m = m0 + r;
             m = m < M ? m : M - 1;
@@ -58,32 +65,33 @@ __device__ __forceinline__ void ln_tile320(char* smem_raw, int tid, int m0, int 
 #pragma unroll
             for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) addv[kt][e] = *(const half8*)(av + (kt * 8 + part + 4 * e) * 8);
+                for (int e = 0; e < 2; ++e) addv[kt][e] = *(const half8*)(av + (kt * 8 + part + 4 * (e ^ f)) * 8);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        float sa = 0.f, sb = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
             for (int e = 0; e < 2; ++e)
-                xv[kt][e] = *(const half8*)(smem_raw + kt * 16384 + r * 128 + (((part + 4 * e) ^ (r & 7)) << 4));
+                xv[kt][e] = *(const half8*)(smem_raw + kt * 16384 + r * 128 + (((part + 4 * (e ^ f)) ^ (r & 7)) << 4));
         if (add) {       // norm_in of the temporal block normalises hidden + frame-position embedding (attention.py:500-507)
 #pragma unroll
             for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) xv[kt][e] = xv[kt][e] + addv[kt][e];   // fp16 add, as k_layernorm
         }
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { sa += (float)xv[kt][0][i]; sb += (float)xv[kt][1][i]; }
+            for (int i = 0; i < 8; ++i) { s0 += (float)xv[kt][0][i]; s1 += (float)xv[kt][1][i]; }
+        const float sa = f ? s1 : s0, sb = f ? s0 : s1;      // sa: the chunks part, sb: the chunks part + 4
         float s = sa + sb;                                   // xor 4: sub-lanes part and part + 4 live in this thread
         s += __shfl_xor(s, 2, 64);
         s += __shfl_xor(s, 1, 64);
         // cf = 320 as a run-time value: the same division k_layernorm compiles to
         const float mean = s / cf;
-        float qa = 0.f, qb = 0.f;
+        float q0 = 0.f, q1 = 0.f;
         {
 #pragma clang fp contract(off)      // k_layernorm's squares are a packed multiply followed by adds, not an fma: the same bits here
 #pragma unroll
@@ -92,9 +100,10 @@ __device__ __forceinline__ void ln_tile320(char* smem_raw, int tid, int m0, int 
                 for (int i = 0; i < 8; ++i) {
                     const float da = (float)xv[kt][0][i] - mean, db = (float)xv[kt][1][i] - mean;
                     const float da2 = da * da, db2 = db * db;
-                    qa += da2; qb += db2;
+                    q0 += da2; q1 += db2;
                 }
         }
+        const float qa = f ? q1 : q0, qb = f ? q0 : q1;
         float qq = qa + qb;
         qq += __shfl_xor(qq, 2, 64);
         qq += __shfl_xor(qq, 1, 64);
@@ -103,12 +112,12 @@ __device__ __forceinline__ void ln_tile320(char* smem_raw, int tid, int m0, int 
         for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int cv = kt * 8 + part + 4 * e;
+                const int cv = kt * 8 + part + 4 * (e ^ f);
                 const half8 g = *(const half8*)(ln_g + cv * 8), b = *(const half8*)(ln_b + cv * 8);
                 half8 o;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = (_Float16)(((float)xv[kt][e][i] - mean) * rstd * (float)g[i] + (float)b[i]);
-                *(half8*)(smem_raw + kt * 16384 + r * 128 + (((part + 4 * e) ^ (r & 7)) << 4)) = o;
+                *(half8*)(smem_raw + kt * 16384 + r * 128 + (((part + 4 * (e ^ f)) ^ (r & 7)) << 4)) = o;
             }
         __syncthreads();
     }

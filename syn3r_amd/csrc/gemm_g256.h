@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
-    const int tiles_n = p.N / 256, tiles_m = p.M / 256;          // (launch_g256: whole tiles only)
+    const int tiles_n = p.N / 256, tiles_m = (p.M + 255) / 256;  // (launch_g256: M a multiple of 128 - the last row tile may be a half: its rows 128-255 re-read valid rows and are never stored)
     const unsigned nblk = (unsigned)(tiles_m * tiles_n);
     const unsigned xcd = blockIdx.x % 8, q8 = nblk / 8, r8 = nblk % 8;
     const unsigned t_start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
@@ -75,7 +75,11 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
                 int m0_, tn_;
                 tile_origin(t_start + ca_tl, m0_, tn_);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) oa[i] = 2u * (unsigned)(m0_ + wv * 32 + i * 8) * (unsigned)p.lda;
+                for (int i = 0; i < 4; ++i) {
+                    int r = m0_ + wv * 32 + i * 8;
+                    r = r < p.M - 8 ? r : p.M - 8;
+                    oa[i] = 2u * (unsigned)r * (unsigned)p.lda;
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) oa[i] += 2u * BK;
@@ -281,6 +285,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
         // stores is in flight when that tile starts
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GSTAMP(5);
+        const bool rows_in = gm0 < p.M;                          // (wave-uniform: a half last tile's wavefronts 4-7 have nothing to store)
 #if defined(G256_NOSTORE)   // developer ablation: one store per tile keeps the gate alive
         {
             unsigned x_ = 0;
@@ -291,7 +296,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
             if (x_ == 0x12345678u) *(unsigned*)obase = x_;
         }
 #elif defined(G256_DEFER)
-        pbase = p.out + tiled_off(gm0, go0, p.geglu_D) + fr * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
+        pbase = rows_in ? p.out + tiled_off(gm0, go0, p.geglu_D) + fr * 64 + (fq & 1) * 16 + (fq >> 1) * 8 : nullptr;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -320,7 +325,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
 #ifdef G256_ST1LANE     // developer ablation: the same store instructions with ONE active lane (16 bytes instead of 1 KB each)
                     if (le == 0) *dst = v;
 #else
-                    if (p.out_nt) __builtin_nontemporal_store(v, dst); else *dst = v;
+                    if (rows_in) { if (p.out_nt) __builtin_nontemporal_store(v, dst); else *dst = v; }
 #endif
                 }
         }
@@ -333,7 +338,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
                 typedef unsigned u2 __attribute__((ext_vector_type(2)));
                 u2* dst = (u2*)(obase + i * 16 * 64 + j * 16);
                 const u2 v2 = (u2){o2[i][j][0], o2[i][j][1]};
-                if (p.out_nt) __builtin_nontemporal_store(v2, dst); else *dst = v2;
+                if (rows_in) { if (p.out_nt) __builtin_nontemporal_store(v2, dst); else *dst = v2; }
             }
 #endif
         GSTAMP(6);

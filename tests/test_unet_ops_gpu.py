@@ -376,12 +376,13 @@ def test_feedforward_tiled_intermediate(M, C, D, gpu):
     close(ops.feedforward(x, wp, bp, D, w2, b2), h @ w2.float().T + b2.float(), tol=4e-3)
 
 
-@pytest.mark.parametrize("M,C,D", [(256, 128, 128), (2048, 640, 2560), (16128, 1280, 5120), (70144, 192, 384), (768, 320, 1280)])
+@pytest.mark.parametrize("M,C,D", [(256, 128, 128), (384, 128, 128), (2048, 640, 2560), (16128, 1280, 5120), (28800, 1280, 5120),
+                                   (70144, 192, 384), (768, 320, 1280)])
 def test_feedforward_g256_equals_packed80(M, C, D, gpu):
     """net.0 on the persistent 256 x 256 tile (k_gemm_g256, syn3r_feedforward_p64_f16: [64 hidden | 64 gate] packing, three A and
     two B ring slots, LDS-free epilogue into the tiled hidden activation) reproduces syn3r_feedforward_f16 bit for bit - one tile,
     fewer tiles than CUs, several tiles per block (the stage cursors cross tile boundaries; 70144 rows x 3 column tiles = 822
-    tiles), K of 2 to 20 k-tiles - and both match the fp32 restatement of FeedForward (attention.py:608-665)."""
+    tiles), a HALF last row tile (M = 384; 28 800 = the level-2 rows of an F = 25 unit), K of 2 to 20 k-tiles - and both match the fp32 restatement of FeedForward (attention.py:608-665)."""
     from syn3r_amd import _lib
     from syn3r_amd.unet import ops
     lib = _lib.load()
@@ -403,7 +404,7 @@ def test_feedforward_g256_equals_packed80(M, C, D, gpu):
         h = (y[:, :D] * Fn.gelu(y[:, D:])).half().float()
         close(out, h @ w2.float().T + b2.float() + res.float(), tol=4e-3)
     # shapes without whole tiles are refused by the entry point and not offered by the wrapper
-    assert lib.syn3r_feedforward_p64_supported(M + 8, D, C) == 0 and lib.syn3r_feedforward_p64_supported(M, D + 64, C) == 0
+    assert lib.syn3r_feedforward_p64_supported(M + 8, D, C) == 0 and lib.syn3r_feedforward_p64_supported(M, D + 64, C) == 0 and lib.syn3r_feedforward_p64_supported(128, D, C) == 0
     xr = rnd(g, M + 8, C, dev=gpu)
     assert torch.equal(ops.feedforward(xr, wp, bp, D, w2, b2, packed64=(w64, b64)), ops.feedforward(xr, wp, bp, D, w2, b2))
 
