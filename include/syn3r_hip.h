@@ -560,6 +560,12 @@ int syn3r_photo_loss_backward(const float* image, const float* target, int C, in
  * param -= lr/(1-beta1^step) * exp_avg / (sqrt(exp_avg_sq)/sqrt(1-beta2^step) + eps).  step is 1-based. */
 int syn3r_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                     float beta1, float beta2, float eps, int step, void* stream);
+/* The same update of up to 8 tensors in ONE launch (the trainer's parameter groups: torch's _multi_tensor_adam; element for
+ * element the arithmetic of syn3r_adam_step).  Host arrays of `count` entries: device pointers, element counts, learning rates,
+ * eps and 1-based steps per tensor; beta1 / beta2 are shared. */
+int syn3r_adam_step_multi(int count, float* const* params, const float* const* grads, float* const* exp_avgs,
+                          float* const* exp_avg_sqs, const long long* numels, const float* lrs, float beta1, float beta2,
+                          const float* epss, const int* steps, void* stream);
 
 /* The parameter activations of the published 3DGS model that FSGS' trainer applies before every render inside
  * gsTrainer.training() / finetune() (model/diffusionGS.py:139,1640; GaussianModel.get_scaling / get_rotation / get_opacity):

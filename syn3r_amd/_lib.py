@@ -105,6 +105,7 @@ SIGNATURES = {
     "syn3r_photo_loss": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_sz, c_p]),
     "syn3r_photo_loss_backward": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_p]),
     "syn3r_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_i, c_p]),
+    "syn3r_adam_step_multi": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p]),
     "syn3r_knn3_workspace_bytes": (c_sz, [c_i]),
     "syn3r_knn3_mean_dist2": (c_i, [c_p, c_i, c_p, c_p, c_sz, c_p]),
     "syn3r_conv2d3x3_act_f16": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -149,7 +149,11 @@ class FusedAdam:
 
     @torch.no_grad()
     def step(self):
+        """One update of every parameter that has a gradient: ONE launch per (beta1, beta2) and up to 8 tensors
+        (`syn3r_adam_step_multi`; the trainer's five / six groups share their betas), element for element `torch.optim.Adam`."""
+        import ctypes as C
         lib = L.load()
+        batches: dict = {}
         for g in self.param_groups:
             b1, b2 = g["betas"]
             for p in g["params"]:
@@ -163,6 +167,15 @@ class FusedAdam:
                     st = self.state[p] = {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
                 st["step"] += 1
                 grad = p.grad.contiguous()
-                L.check(lib.syn3r_adam_step(L.ptr(p), L.ptr(grad), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
-                                            p.numel(), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
-                                            int(st["step"]), L.stream_ptr(p.device)), "adam_step")
+                batches.setdefault((float(b1), float(b2), p.device), []).append((p, grad, st, float(g["lr"]), float(g["eps"])))
+        for (b1, b2, dev), items in batches.items():
+            for k0 in range(0, len(items), 8):
+                chunk = items[k0:k0 + 8]
+                n = len(chunk)
+                ptrs = lambda sel: (C.c_void_p * n)(*[sel(it) for it in chunk])
+                rc = lib.syn3r_adam_step_multi(
+                    n, ptrs(lambda it: it[0].data_ptr()), ptrs(lambda it: it[1].data_ptr()), ptrs(lambda it: it[2]["exp_avg"].data_ptr()),
+                    ptrs(lambda it: it[2]["exp_avg_sq"].data_ptr()), (C.c_longlong * n)(*[it[0].numel() for it in chunk]),
+                    (C.c_float * n)(*[it[3] for it in chunk]), b1, b2, (C.c_float * n)(*[it[4] for it in chunk]),
+                    (C.c_int * n)(*[int(it[2]["step"]) for it in chunk]), L.stream_ptr(dev))
+                L.check(rc, "adam_step_multi")

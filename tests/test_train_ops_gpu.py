@@ -66,6 +66,54 @@ def test_fused_adam_matches_torch_adam(gpu):
     assert all(p.grad is None for p in hip_p)
 
 
+def test_adam_multi_tensor_equals_per_tensor_launches(gpu):
+    """`syn3r_adam_step_multi` (one launch over a descriptor table; round 6) against `syn3r_adam_step` per tensor: the same bits in the
+    parameters and both moments, for ragged sizes, different learning rates / eps / steps, and more tensors than one table holds
+    (FusedAdam splits them); bad tables are refused."""
+    import ctypes as C
+    from syn3r_amd import _lib as L
+    from syn3r_amd.gs.train_ops import FusedAdam
+    lib = L.load()
+    g = torch.Generator().manual_seed(8)
+    sizes = [3 * 1000, 45 * 1000 + 7, 1, 255, 257, 4 * 1000, 1000, 513, 12345, 31]      # 10 tensors: two tables
+    mk = lambda n: torch.randn(n, generator=g).to(gpu)
+    P = [mk(n) for n in sizes]; G = [mk(n) for n in sizes]; M1 = [mk(n).abs() * 0.1 for n in sizes]; V1 = [mk(n).abs() * 0.01 for n in sizes]
+    lrs = [10.0 ** (-2 - (k % 3)) for k in range(len(sizes))]
+    epss = [1e-15 if k % 2 else 1e-8 for k in range(len(sizes))]
+    steps = [1 + 3 * k for k in range(len(sizes))]
+    ref = [(p.clone(), m.clone(), v.clone()) for p, m, v in zip(P, M1, V1)]
+    for (p, m, v), gr, lr, ep, stp in zip(ref, G, lrs, epss, steps):
+        L.check(lib.syn3r_adam_step(L.ptr(p), L.ptr(gr), L.ptr(m), L.ptr(v), p.numel(), lr, 0.9, 0.999, ep, stp, L.stream_ptr(gpu)), "adam_step")
+    for k0 in (0, 8):
+        idx = list(range(k0, min(k0 + 8, len(sizes))))
+        n = len(idx)
+        arr = lambda ts: (C.c_void_p * n)(*[ts[i].data_ptr() for i in idx])
+        rc = lib.syn3r_adam_step_multi(n, arr(P), arr(G), arr(M1), arr(V1), (C.c_longlong * n)(*[sizes[i] for i in idx]),
+                                       (C.c_float * n)(*[lrs[i] for i in idx]), 0.9, 0.999, (C.c_float * n)(*[epss[i] for i in idx]),
+                                       (C.c_int * n)(*[steps[i] for i in idx]), L.stream_ptr(gpu))
+        L.check(rc, "adam_step_multi")
+    torch.cuda.synchronize()
+    for (rp, rm, rv), p, m, v in zip(ref, P, M1, V1):
+        assert torch.equal(rp, p) and torch.equal(rm, m) and torch.equal(rv, v)
+    one = (C.c_void_p * 1)(P[0].data_ptr())
+    ll, ff, ii = (C.c_longlong * 1)(sizes[0]), (C.c_float * 1)(1e-3), (C.c_int * 1)(1)
+    assert lib.syn3r_adam_step_multi(0, one, one, one, one, ll, ff, 0.9, 0.999, ff, ii, None) != 0
+    assert lib.syn3r_adam_step_multi(9, one, one, one, one, ll, ff, 0.9, 0.999, ff, ii, None) != 0
+    assert lib.syn3r_adam_step_multi(1, one, one, one, one, ll, ff, 0.9, 0.999, ff, (C.c_int * 1)(0), None) != 0 and b"1-based" in lib.syn3r_last_error()
+    # FusedAdam over ten groups (two launches) == ten torch.optim.Adam groups
+    ref_p = [torch.randn(n, generator=g).requires_grad_(True) for n in sizes]
+    hip_p = [p.detach().clone().to(gpu).requires_grad_(True) for p in ref_p]
+    ro = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(ref_p, lrs)], eps=1e-15)
+    ho = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(hip_p, lrs)], eps=1e-15)
+    for _ in range(3):
+        for rp, hp in zip(ref_p, hip_p):
+            gr = torch.randn(rp.shape, generator=g)
+            rp.grad, hp.grad = gr, gr.to(gpu)
+        ro.step(); ho.step()
+    for rp, hp in zip(ref_p, hip_p):
+        torch.testing.assert_close(hp.detach().cpu(), rp.detach(), rtol=2e-6, atol=1e-7)
+
+
 def test_fused_adam_skips_params_without_grad_and_rejects_cpu(gpu):
     from syn3r_amd import _lib
     from syn3r_amd.gs.train_ops import FusedAdam
