@@ -57,8 +57,11 @@ struct GeomState {
     void* scan_scratch;
 };
 
-constexpr size_t kBinCounters = 65536;          // (chunk, super-tile) counters of the hierarchical binning
-constexpr size_t kMaxSuperSlots = 1024;         // ... followed by the super-tile list starts (at most 512 + 1)
+#ifndef SYN3R_BIN_COUNTERS
+#define SYN3R_BIN_COUNTERS 65536
+#endif
+constexpr size_t kBinCounters = SYN3R_BIN_COUNTERS;          // (chunk, super-tile) counters of the hierarchical binning
+constexpr size_t kMaxSuperSlots = 4096;         // ... followed by the super-tile list starts (at most kMaxSuper + 1)
 struct ImageState {
     uint2* ranges;           // [tiles] (start, end) into the sorted pair list
     unsigned* n_contrib;     // [H*W] index (1-based, within the tile list) of the last contributor

@@ -357,7 +357,10 @@ __global__ void __launch_bounds__(256) k_tile_ranges(long long P_cap, const unsi
 // Shapes it does not take (more than 512 super-tiles: images beyond ~4K) keep the argsort and the pair sort.
 constexpr int kBinThreads = 512;          // Gaussians per round of a binning block
 constexpr int kOffThreads = 1024;         // k_tile_offsets: one block
-constexpr int kMaxSuper = 512;
+#ifndef SYN3R_MAX_SUPER
+#define SYN3R_MAX_SUPER 512
+#endif
+constexpr int kMaxSuper = SYN3R_MAX_SUPER;     // (developer builds: -DSYN3R_MAX_SUPER=2048 takes 1080p to 2 x 2-tile super-tiles, profiles/r06/binning_supertiles.txt)
 
 // exclusive scan of one value per thread over a 1024-thread block (sort.hip's block_exclusive_scan, local to this file)
 __device__ __forceinline__ unsigned block_scan_1024(unsigned v, unsigned* smem /*[17]*/, unsigned& total) {
@@ -454,8 +457,15 @@ __global__ void __launch_bounds__(kBinThreads) k_super_count(int N, const float*
     }
     __syncthreads();
     for (int s = threadIdx.x; s < nsuper; s += kBinThreads) counters[(size_t)blockIdx.x * nsuper + s] = tot[s];   // chunk-major: k_super_append reads it coalesced
+    // ONE global atomic per block (integer: any order gives the same sum): the wavefronts meet in LDS first - eight atomics per block
+    // on one address cost the kernel 8 of its 14 us
+    __shared__ unsigned pairs_s;
+    if (threadIdx.x == 0) pairs_s = 0u;
+    __syncthreads();
     pairs = wave_sum_i(pairs);
-    if ((threadIdx.x & 63) == 0 && pairs) atomicAdd(&header[3], (unsigned)pairs);     // (integer: any order gives the same sum)
+    if ((threadIdx.x & 63) == 0 && pairs) atomicAdd(&pairs_s, (unsigned)pairs);
+    __syncthreads();
+    if (threadIdx.x == 0 && pairs_s) atomicAdd(&header[3], pairs_s);
 }
 
 // Appends the keys (depth bits << 32 | index) of this chunk's Gaussians to the lists of the super-tiles their rectangles meet.
@@ -469,7 +479,7 @@ __global__ void __launch_bounds__(kBinThreads) k_super_append(int N, const float
                                                               unsigned long long* __restrict__ skeys, unsigned* __restrict__ header) {
     __shared__ unsigned run[kMaxSuper];            // next free position of (super-tile, this chunk)
     __shared__ unsigned tot_s[kMaxSuper], pre_s[kMaxSuper];
-    __shared__ unsigned part_tot[kBinThreads], part_pre[kBinThreads];   // nsuper * PARTS <= kBinThreads
+    __shared__ unsigned part_tot[kMaxSuper > kBinThreads ? kMaxSuper : kBinThreads], part_pre[kMaxSuper > kBinThreads ? kMaxSuper : kBinThreads];   // nsuper * PARTS <= max(kBinThreads, nsuper)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     {
         const int PARTS = max(1, min(8, kBinThreads / nsuper));  // (super-tile, part) items: one per thread, one pass
