@@ -9,7 +9,7 @@
 // MI355X mapping: each wavefront owns a 16 x 8 pixel half of the tile, two pixels per lane on packed fp32
 // arithmetic, and walks only the splats that can reach alpha >= 1/255 on that half (splat_reaches_rect,
 // raster_common.h).  Per visited splat the up to 128 pixel contributions to 10 quantities are summed by
-// reduce12 (two half/row swap levels + DPP row rotates,
+// reduce10 (two half/row swap levels + DPP row rotates,
 // 30 VALU instructions), accumulated per (tile, splat) in LDS across the two wavefronts, and flushed with
 // ONE atomic per record slot onto a contiguous 64-byte gradient record (MI355X float atomics want
 // contiguous segments, MI355X_MICROARCH.md "Global float atomics").
@@ -35,33 +35,48 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     return start + k;
 }
 
-// Sum each of 12 per-lane values over the 64 lanes.  Returns, on lane l with (l & 15) < 3, the total of value
-// 3 * (l >> 4) + (l & 15)  (each 16-lane row ends up owning three consecutive values).
-// Two transposing levels use gfx950's half/row swaps (v_permlane32_swap, v_permlane16_swap): one VALU
-// instruction moves BOTH directions of the exchange, so a level costs a swap and an add per surviving value
-// and halves the number of live registers (12 -> 6 -> 3).  The last four levels stay inside a 16-lane row and
-// are v_add_f32 with a DPP row rotate (shift and add in one instruction); no LDS-pipe ds_bpermute anywhere.
-__device__ __forceinline__ float reduce12(float (&v)[12], int lane) {
-    float w6[6], w3[3];
+// Sum each of the 10 per-lane gradient terms over the 64 lanes.  Returns, on lane l with column c = l & 15 and 16-lane row q = l >> 4,
+// the total of value base(q) + c for c < 3 (even rows) / c < 2 (odd rows), base = 0, 3, 5, 8: row 0 owns values 0-2, row 1 values 3-4,
+// row 2 values 5-7, row 3 values 8-9 (reduce_slot below).
+// Two transposing levels use gfx950's half / row swaps (v_permlane32_swap, v_permlane16_swap): one VALU instruction moves BOTH
+// directions of the exchange, so a level costs a swap and an add per surviving value and halves the number of live registers
+// (10 -> 5 -> 3; the odd one of the second level is swapped against a copy of itself).  The last four levels stay inside a 16-lane
+// row: v_add_f32 with a DPP row rotate, written as inline asm - through __builtin_amdgcn_update_dpp hipcc split the row_ror:1 step into
+// v_mov 0 + v_mov_dpp + v_add, and the 12-value form of rounds 2-5 swapped two zero pads through both levels: 38 instructions, now 29
+// (round 6; the kernel is bound by vector issue, 128 -> 119 instructions per visit).  No LDS-pipe ds_bpermute anywhere.
+__device__ __forceinline__ float row_sum16(float x) {
+    float y;
+    asm("v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
+    asm("v_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(y));
+    asm("v_add_f32_dpp %0, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
+    asm("v_add_f32_dpp %0, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(y));
+    return x;
+}
+__device__ __forceinline__ float reduce10(float (&v)[10], int lane) {
+    float a[5];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {   // lanes 32-63 of v[k] <-> lanes 0-31 of v[k+6]: lower half owns k, upper k+6
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v[k]), __float_as_int(v[k + 6]), false, false);
-        w6[k] = __int_as_float(r[0]) + __int_as_float(r[1]);
+    for (int k = 0; k < 5; ++k) {   // lanes 32-63 of v[k] <-> lanes 0-31 of v[k+5]: the lower half owns k, the upper k + 5
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v[k]), __float_as_int(v[k + 5]), false, false);
+        a[k] = __int_as_float(r[0]) + __int_as_float(r[1]);
     }
+    float b[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {   // odd 16-lane rows of w6[k] <-> even rows of w6[k+3]: even rows own k, odd k+3
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(w6[k]), __float_as_int(w6[k + 3]), false, false);
-        w3[k] = __int_as_float(r[0]) + __int_as_float(r[1]);
+    for (int k = 0; k < 2; ++k) {   // odd 16-lane rows of a[k] <-> even rows of a[k+3]: even rows own k, odd rows k + 3
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(a[k]), __float_as_int(a[k + 3]), false, false);
+        b[k] = __int_as_float(r[0]) + __int_as_float(r[1]);
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        w3[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w3[k]), 0x128 /* row_ror:8 */, 0xF, 0xF, false));
-        w3[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w3[k]), 0x124 /* row_ror:4 */, 0xF, 0xF, false));
-        w3[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w3[k]), 0x122 /* row_ror:2 */, 0xF, 0xF, false));
-        w3[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w3[k]), 0x121 /* row_ror:1 */, 0xF, 0xF, false));
+    {                                // a[2] against itself: both rows of a pair get the pair's total (the odd rows' copy is not stored)
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(a[2]), __float_as_int(a[2]), false, false);
+        b[2] = __int_as_float(r[0]) + __int_as_float(r[1]);
     }
+    b[0] = row_sum16(b[0]); b[1] = row_sum16(b[1]); b[2] = row_sum16(b[2]);
     const int c = lane & 15;
-    return c == 0 ? w3[0] : (c == 1 ? w3[1] : w3[2]);
+    return c == 0 ? b[0] : (c == 1 ? b[1] : b[2]);
+}
+// the gradient slot reduce10's return value belongs to on this lane, or -1
+__device__ __forceinline__ int reduce_slot(int lane) {
+    const int c = lane & 15, q = lane >> 4;
+    return c < ((q & 1) ? 2 : 3) ? ((5 * q + 1) >> 1) + c : -1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -73,7 +88,7 @@ __device__ __forceinline__ float reduce12(float (&v)[12], int lane) {
 // v_pk_mul_f32 / v_pk_add_f32: two pixels per VALU issue); only exp, rcp, min and the compares stay one per pixel.
 // The kernel is VALU-bound (rocprofv3 round 1: 78 % VALU issue): against one pixel per lane this halves the issue
 // slots of the chain-rule arithmetic and halves the number of cross-lane reductions per pixel (the two pixels of a
-// lane are added before reduce12).  The visit list is per wavefront, i.e. per 16 x 8 half: coarser than the former
+// lane are added before reduce10).  The visit list is per wavefront, i.e. per 16 x 8 half: coarser than the former
 // 8 x 8 quadrant (more visits pass the reach test), but a visit now carries 128 pixels for ~0.6 of the issue cost
 // of two 64-pixel visits.  Splats are staged 128 at a time (one per thread).
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -144,6 +159,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_render_bwd(
     float last_r = 0.f, last_g = 0.f, last_b = 0.f, last_d = 0.f;      // colour of the last visited splat: wave-uniform
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
+    const int rslot = reduce_slot(lane);
     int todo = total;
     // The records of round rd + 1 are requested (list entry, then the 48-byte record: two dependent global loads)
     // BEFORE round rd is processed and land in registers meanwhile: the gather latency is off the critical path.
@@ -235,13 +251,11 @@ __global__ void __launch_bounds__(kBwdThreads) k_render_bwd(
             w[G_CXY] = -(gdx * dy) * dL_dG;
             w[G_CYY] = -0.5f * (gdy * dy) * dL_dG;
             w[G_OP] = G * dL_da;
-            float v[12];
+            float v[10];
 #pragma unroll
             for (int k = 0; k < 10; ++k) v[k] = w[k].x + w[k].y;
-            v[10] = 0.0f; v[11] = 0.0f;
-            float s = reduce12(v, lane);
-            const int slot = 3 * (lane >> 4) + (lane & 15);
-            if ((lane & 15) < 3 && slot < G_USED) atomicAdd(&sacc[j * kGradSlots + slot], s);   // LDS, 10 banks
+            const float s = reduce10(v, lane);
+            if (rslot >= 0) atomicAdd(&sacc[j * kGradSlots + rslot], s);   // LDS, 10 banks
           }
         }
         // one global atomic per (tile, splat) instead of one per (wavefront, splat): 16 lanes per record, so a
