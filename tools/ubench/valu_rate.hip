@@ -33,7 +33,20 @@ __global__ void __launch_bounds__(256) k(float* out, int iters) {
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
         }
     }
-    if (MODE >= 6) {
+    if (MODE == 9 || MODE == 10) {   // packed fp32: 4 independent v_pk_fma_f32 / 2 v_pk_fma_f32 + 2 v_fma_f32 (round 6: what a packed instruction costs the SIMD)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
+        for (int it = 0; it < iters; ++it) {
+            if (MODE == 9)
+                asm volatile("v_pk_fma_f32 %0, %0, %0, %0\n v_pk_fma_f32 %1, %1, %1, %1\n v_pk_fma_f32 %2, %2, %2, %2\n v_pk_fma_f32 %3, %3, %3, %3"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+            else
+                asm volatile("v_pk_mul_f32 %0, %0, %0\n v_pk_mul_f32 %1, %1, %1\n v_pk_add_f32 %2, %2, %2\n v_pk_add_f32 %3, %3, %3"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+        }
+        a0 = p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+    }
+    if (MODE >= 6 && MODE <= 8) {
         // phase-structured like attention: 8 MFMAs (two dependent chains of 4) -> NV dependent VALU ops -> 8 MFMAs
         float16v b0 = acc, b1 = acc, c0 = acc, c1 = acc;
         for (int it = 0; it < iters; ++it) {
@@ -69,7 +82,7 @@ __global__ void __launch_bounds__(256) k(float* out, int iters) {
 
 template <int MODE>
 void run(const char* name, int waves_per_simd, float ops_per_iter) {
-    int iters = MODE >= 6 ? 2000 : 20000;
+    int iters = (MODE >= 6 && MODE <= 8) ? 2000 : 20000;
     int blocks = 256 * waves_per_simd;   // 256 CUs x (4 waves = 1 per SIMD) per block
     float* out; hipMalloc(&out, (size_t)blocks * 256 * 4);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -93,6 +106,8 @@ int main() {
         run<4>("1 mfma 32x32x16", w, 1);
         run<3>("1 mfma + 8 fma", w, 9);
         run<5>("1 mfma + 8 exp", w, 9);
+        run<9>("4 x v_pk_fma_f32", w, 4);
+        run<10>("2 v_pk_mul + 2 v_pk_add f32", w, 4);
     }
     for (int w : {1, 2, 3, 4}) {
         run<8>("phases: 16 mfma only", w, 16);
