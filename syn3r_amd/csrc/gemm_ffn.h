@@ -234,8 +234,16 @@ __global__ void __launch_bounds__(512, 2) k_ffn320r(FfnParams q) {
                 int m = m0 + wm * 32 + i * 16 + fr;
                 m = m < p.M ? m : p.M - 1;
                 const __half* av = q.ln_add + (long long)(m / q.ln_add_rpv) * F_C + fq * 8;
+                // five requests at a time: written load-add-load-add, hipcc gave every load its own s_waitcnt vmcnt(0) - ten serialised
+                // round trips per row tile (round 6; all ten at once spills)
 #pragma unroll
-                for (int ks = 0; ks < 10; ++ks) xf[i][ks] = xf[i][ks] + *(const half8*)(av + ks * 32);   // fp16 add, as k_layernorm
+                for (int k5 = 0; k5 < 10; k5 += 5) {
+                    half8 addv[5];
+#pragma unroll
+                    for (int ks = 0; ks < 5; ++ks) addv[ks] = *(const half8*)(av + (k5 + ks) * 32);
+#pragma unroll
+                    for (int ks = 0; ks < 5; ++ks) xf[i][k5 + ks] = xf[i][k5 + ks] + addv[ks];   // fp16 add, as k_layernorm
+                }
             }
             float sa = 0.f, sb = 0.f;
 #pragma unroll
