@@ -85,7 +85,7 @@ def run_ffn():
 if "--ffn" in sys.argv:
     run_ffn()
 elif "--persistent" in sys.argv:
-    for M, N, K, g in [(64512, 5120, 640, True), (64512, 1920, 640, False), (16128, 10240, 1280, True), (16128, 1280, 5120, False)]:
+    for M, N, K, g in [(64512, 640, 2560, False), (64512, 1920, 640, False), (16128, 3840, 1280, False), (16128, 1280, 5120, False)]:
         run_persistent(M, N, K, g)
 else:
     for shape in [(16128, 1280, 5120), (64512, 5120, 640), (258048, 2560, 320)]:
