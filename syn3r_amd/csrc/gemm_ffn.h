@@ -425,15 +425,19 @@ __global__ void __launch_bounds__(512, 2) k_ffn320r(FfnParams q) {
                 } else res[it] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
             }
         }
+        // the ten bias requests first (round 6): written load-use per column tile, hipcc gave each its own s_waitcnt vmcnt(0) - ten
+        // serialised round trips per block
+        half4e bq[10];
 #pragma unroll
         for (int jt = 0; jt < 10; ++jt) {
-            const int n = gn0 + jt * 16 + fq * 4;
-            float b4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) {
-                const half4e b = *(const half4e*)(p.bias + n);
+            bq[jt] = (half4e){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            if (p.bias) bq[jt] = *(const half4e*)(p.bias + gn0 + jt * 16 + fq * 4);
+        }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) b4[r] = (float)b[r];
-            }
+        for (int jt = 0; jt < 10; ++jt) {
+            float b4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4[r] = (float)bq[jt][r];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 half4e o;
