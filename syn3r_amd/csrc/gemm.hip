@@ -71,6 +71,8 @@ thread_local void* g_gn_pending = nullptr;
 thread_local size_t g_gn_pending_bytes = 0;
 thread_local bool g_gn_written = false;
 size_t gn_partials_bytes(long long M, long long N) { return (size_t)(M / 32) * 2 * (size_t)(N / 10) * sizeof(float); }
+// entry points whose kernels never write partial sums: a request left pending by the caller must not reach a later, unrelated launch
+void gn_drop() { g_gn_pending = nullptr; g_gn_pending_bytes = 0; g_gn_written = false; }
 void gn_take(GemmParams& p) {
     g_gn_written = false;
     void* buf = g_gn_pending;
@@ -115,7 +117,7 @@ int launch_widep(const GemmParams& p, hipStream_t stream) {
 
 // k_gemm_g256 (gemm_g256.h): the gated projection on whole 256 x 256 tiles into the A-tiled hidden activation
 bool g256_admits(const GemmParams& p) {
-    return p.geglu_D > 0 && p.out_tiled && !p.a_tiled && !p.A2 && !p.rowvec && !p.residual && !p.aux && p.s_acc == 1.0f && p.M % 128 == 0 && p.M >= 256 &&
+    return p.geglu_D > 0 && p.bias != nullptr && p.out_tiled && !p.a_tiled && !p.A2 && !p.rowvec && !p.residual && !p.aux && p.s_acc == 1.0f && p.M % 128 == 0 && p.M >= 256 &&
            p.geglu_D % 128 == 0 && p.N == 2 * p.geglu_D && p.K >= 2 * BK && p.lda % 8 == 0 && (long long)p.M * p.lda < (1ll << 31) &&
            (long long)p.N * p.K < (1ll << 31);
 }
@@ -530,6 +532,7 @@ extern "C" int syn3r_gemm_2src_f16(const void* A1, long long lda1, int K1, const
 
 extern "C" int syn3r_gemm_geglu_f16(const void* A, long long lda, const void* Wpacked, const void* bias_packed, void* out,
                                     long long ldc, int M, int D, int K, void* stream) {
+    gn_drop();
     GemmParams p{};
     SYN3R_REQUIRE(SYN3R_DIM_OK(D), "gemm_geglu_f16: bad D=%d", D);
     const int tiles = (D + WN - 1) / WN;
@@ -555,6 +558,7 @@ extern "C" int syn3r_feedforward_f16(const void* x, long long ldx, const void* w
                                      long long ldr, const void* aux, long long ldaux, float s_acc, float s_res,
                                      float s_aux, int M, int C_in, int C_out, void* workspace, size_t workspace_bytes,
                                      void* stream) {
+    gn_drop();
     SYN3R_REQUIRE(x && w1_packed && b1_packed && w2 && out, "feedforward_f16: null operand");
     SYN3R_REQUIRE(M > 0 && D > 0 && D % BK == 0 && C_in > 0 && C_out > 0, "feedforward_f16: bad sizes M=%d D=%d C_in=%d C_out=%d (D must be a multiple of %d)",
                   M, D, C_in, C_out, BK);
@@ -595,6 +599,7 @@ extern "C" int syn3r_feedforward_p64_f16(const void* x, long long ldx, const voi
                                          long long ldr, const void* aux, long long ldaux, float s_acc, float s_res,
                                          float s_aux, int M, int C_in, int C_out, void* workspace, size_t workspace_bytes,
                                          void* stream) {
+    gn_drop();
     SYN3R_REQUIRE(x && w1_packed64 && b1_packed64 && w2 && out, "feedforward_p64_f16: null operand");
     SYN3R_REQUIRE(syn3r_feedforward_p64_supported(M, D, C_in) != 0 && C_out > 0 && ldx == C_in,
                   "feedforward_p64_f16: shape M=%d D=%d C_in=%d not served (syn3r_feedforward_p64_supported; x must be dense rows)", M, D, C_in);
@@ -662,6 +667,7 @@ int feedforward_fused(const void* x, long long ldx, const void* ln_gamma, const 
                       const void* b1_chunked, int D, const void* w2, const void* b2, void* out, long long ldc, const void* residual,
                       long long ldr, const void* aux, long long ldaux, float s_acc, float s_res, float s_aux, int M, int C, void* stream,
                       const void* addvec, int rows_per_vec) {
+    gn_drop();
     SYN3R_REQUIRE(x && w1_chunked && b1_chunked && w2 && out, "feedforward_fused_f16: null operand");
     SYN3R_REQUIRE(C == F_C, "feedforward_fused_f16: the fused kernel is built for C = %d channels (got %d): use syn3r_feedforward_f16", F_C, C);
     SYN3R_REQUIRE(M > 0 && D >= F_HC && D % F_HC == 0, "feedforward_fused_f16: bad sizes M=%d D=%d (D must be a multiple of %d)", M, D, F_HC);
@@ -683,6 +689,7 @@ int feedforward_fused(const void* x, long long ldx, const void* ln_gamma, const 
 
 extern "C" int syn3r_layernorm_linear320_f16(const void* x, long long ldx, const void* ln_gamma, const void* ln_beta, float ln_eps,
                                              const void* W, void* out, long long ldc, int M, int N, int C, void* stream) {
+    gn_drop();
     SYN3R_REQUIRE(x && ln_gamma && ln_beta && W && out, "layernorm_linear320_f16: null operand");
     SYN3R_REQUIRE(C == F_C, "layernorm_linear320_f16: the kernel is built for C = %d channels (got %d): use syn3r_layernorm_f16 + syn3r_gemm_f16", F_C, C);
     SYN3R_REQUIRE(SYN3R_DIM_OK(M) && SYN3R_DIM_OK(N) && N % F_C == 0, "layernorm_linear320_f16: bad sizes M=%d N=%d (N must be a multiple of %d)", M, N, F_C);
@@ -725,6 +732,7 @@ extern "C" int syn3r_conv2d3x3_f16(const void* X, const void* W, void* out, long
 
 extern "C" int syn3r_conv2d3x3_act_f16(const void* X, const void* W, void* out, const void* bias, int relu, const void* relu_mask,
                                        int NB, int Hi, int Wi, int Cin, int Cout, void* stream) {
+    gn_drop();
     SYN3R_REQUIRE(NB > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv2d3x3_act: bad sizes");
     SYN3R_REQUIRE(Cin % BK == 0 && Cout % 8 == 0, "conv2d3x3_act: Cin=%d must be a multiple of %d, Cout=%d of 8", Cin, BK, Cout);
     GemmParams p{};

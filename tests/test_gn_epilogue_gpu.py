@@ -203,6 +203,20 @@ def test_requests_that_cannot_be_served_fall_back(gpu):
     # the request did not leak into the next launch
     z = ops.linear(x, w)
     assert lib.syn3r_gemm_gn_partials_written() == 0 and getattr(z, "gn_part", None) is None
+    # a request followed by an entry point that never writes partial sums (the gated projection): dropped there, not kept for the
+    # next contraction of the thread
+    part = torch.zeros(lib.syn3r_gn_partials_bytes(1024, 320) // 4, dtype=torch.float32, device=gpu)
+    _lib.check(lib.syn3r_gemm_set_gn_partials(part.data_ptr(), part.numel() * 4), "set_gn_partials")
+    wg, bg = rnd(g, 2 * 160, 64, scale=0.125, dev=gpu), rnd(g, 2 * 160, dev=gpu)
+    wp, bp, _ = ops.pack_geglu(wg, bg)
+    ops.linear_geglu(x, wp, bp, 160)
+    try:
+        _lib.check(lib.syn3r_gemm_set_tile(-256), "set_tile")
+        ops.linear(x, w)
+    finally:
+        lib.syn3r_gemm_set_tile(0)
+    torch.cuda.synchronize()
+    assert lib.syn3r_gemm_gn_partials_written() == 0 and float(part.abs().sum()) == 0.0
     ga, be = rnd(g, 320, dev=gpu), rnd(g, 320, dev=gpu)
     close(ops.groupnorm(y, ga, be, 4, 1e-5, False), gn_ref(y, 4, ga, be, 1e-5, False))
     # rows per sample not a multiple of 32 with partial sums present: the statistics pass
