@@ -10,10 +10,10 @@
 //   LDS       THREE 32 KB slots for A and TWO for B = 163,840 B: the A pieces of k-tile g + 2 and the B pieces of k-tile g + 1 are
 //             requested during k-tile g (A streams from HBM / the memory-side cache, the band's weight panel sits in the L2), the
 //             stage cursors run on across tile boundaries;
-//   epilogue  no LDS: the gate runs in registers (activations.py GEGLU.forward on the fp16-rounded projection, gelu_pk) and the
-//             result goes out as 8-byte stores straight from the MFMA layout - the A-tiled layout of the hidden activation
-//             (GemmParams::out_tiled: [128-row block][64-column tile][128][64]) makes the wavefront's 64 x 64 result ONE contiguous
-//             8 KB run, a store instruction covers 16 rows x 32 bytes and four of them complete the rows' 128-byte lines;
+//   epilogue  no LDS: the gate runs in registers (activations.py GEGLU.forward on the fp16-rounded projection, gelu_pk, packed fp32
+//             throughout) and the result goes out straight from the MFMA layout - two v_permlane16_swap per pair of column tiles give
+//             every lane a 16-byte piece; the A-tiled layout of the hidden activation (GemmParams::out_tiled: [128-row block][64-column
+//             tile][128][64]) makes the wavefront's 64 x 64 result ONE contiguous 8 KB run, a store instruction covers 16 rows x 64 bytes;
 //   waits     at a tile boundary (one extra barrier) the next tile's stage 1 of B and stage 2 of A are requested into the slots the last
 //             k-tile released, the gate runs while they land, and only then - everything the next tile's k-tiles 0 and 1 read has
 //             landed - are the stores issued: those two k-tiles need no vmcnt wait, and the first counted wait that includes the
@@ -24,6 +24,8 @@
 // Arithmetic: the same MFMA order per accumulator as k_gemm_widep / k_gemm_z (k ascending, v_mfma_f32_16x16x32_f16 with the weight
 // fragment as the A operand), the same gate: results are bit-identical to those kernels' (tests/test_unet_ops_gpu.py).
 // Reference semantics: attention.py:608-665 (FeedForward), activations.py GEGLU.
+// (The ablation / variant builds behind profiles/r06/g256_ablations.txt - no stores, one-lane stores, cache-resident stores, 8-byte stores,
+// parked and spread stores, de-phased CUs - are profiles/r06/g256_ablation_variants.patch against this file.)
 
 constexpr int G_SLOT = 256 * BK * 2;             // 32,768: one operand stage (256 rows x 64 halfs)
 constexpr int G_B0 = 3 * G_SLOT;                 // A slots at 0 / 32 K / 64 K, B slots at 96 K / 128 K
@@ -117,9 +119,6 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
     unsigned ra = 0, rb = 0;                    // ring slots of the k-tile being read
     float4v acc[8][4];                          // [column tile: 0-3 hidden, 4-7 gate][row tile]
 
-#ifdef G256_DEPHASE     // developer variant: the blocks of an XCD start G256_DEPHASE x 64 cycles apart (8 phases)
-    for (unsigned d = 0; d < ((blockIdx.x / 8) % 8); ++d) __builtin_amdgcn_s_sleep(G256_DEPHASE);
-#endif
     // kernel prologue: the first tile's stages 0 and 1 of both operands and stage 2 of A - what every later tile finds requested
     // (and landed) when it starts, see the tile boundary below
     issue_a(); issue_b(); issue_a(); issue_b(); issue_a();
@@ -131,15 +130,6 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
 #define GSTAMP(i)
 #endif
     typedef _Float16 half4e __attribute__((ext_vector_type(4)));
-#ifdef G256_DEFER       // developer variant: the gated result stays parked (eight 16-byte pieces) and its stores go out one per k-tile of the NEXT tile, in front of that k-tile's DMA requests
-    u32x4 pv[8];
-    __half* pbase = nullptr;
-    auto store_unit = [&](int u) {
-#define G256_ST(U) case U: { u32x4* dst = (u32x4*)(pbase + ((U) >> 1) * 16 * 64 + ((U) & 1) * 32); if (p.out_nt) __builtin_nontemporal_store(pv[U], dst); else *dst = pv[U]; } break;
-        switch (u) { G256_ST(0) G256_ST(1) G256_ST(2) G256_ST(3) G256_ST(4) G256_ST(5) G256_ST(6) G256_ST(7) default: break; }
-#undef G256_ST
-    };
-#endif
     for (unsigned tl = blockIdx.x / 8; tl < t_len; tl += t_stride) {
         int m0, tile_n;
         tile_origin(t_start + tl, m0, tile_n);
@@ -189,23 +179,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
             else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bf[J]) : "i"(7 - (J))); \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[J][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[J], af[i], acc[J][i], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0); } while (0)
-#ifndef G256_UNCOUNTED
         auto mma = [&]() {
             G256_GROUP(0); G256_GROUP(1); G256_GROUP(2); G256_GROUP(3); G256_GROUP(4); G256_GROUP(5); G256_GROUP(6); G256_GROUP(7);
         };
-#else
-        auto mma = [&]() {
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]),
-                           "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7]));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[j][i], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);   // the next reads reuse af / bf: keep them behind these MFMAs
-        };
-#endif
         for (int kt = 0; kt < nkt; ++kt) {
             // stage kt of both operands has landed once only the youngest four requests (the A pieces of stage kt + 1) are in flight.
             // k-tiles 0 and 1 find their stages landed: they were requested, and waited for, in front of the previous tile's stores
@@ -223,9 +199,6 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
             if (kt >= 2) { GSTAMP(3); }
             if (defer && kt > 0) mma();                          // second k-half of stage kt - 1 (fragments read before the barrier)
             if (kt > 0) {
-#ifdef G256_DEFER
-            if (pbase && kt >= 1 && kt <= 8) store_unit(kt - 1);
-#endif
             issue_b();                                           // stage kt + 1 of B: the slot every wavefront finished reading in iteration kt - 1
             issue_a();                                           // stage kt + 2 of A: likewise
             }
@@ -249,13 +222,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
         __builtin_amdgcn_s_barrier();
         issue_b(); issue_a();
 
-        // ---- epilogue: gate in registers, 8-byte stores from the MFMA layout into the A-tiled hidden activation
+        // ---- epilogue: gate in registers, 16-byte pieces (v_permlane16_swap) stored straight into the A-tiled hidden activation
         int le = lane;
         asm volatile("" : "+v"(le));
         const int fr = le & 15, fq = le >> 4;
         const int gn = tile_n * 256 + wn * 128;                  // packed column origin of this wavefront: [64 hidden | 64 gate]
         const int gm0 = m0 + wm * 64, go0 = tile_n * 128 + wn * 64;
-        __half* obase = p.out + tiled_off(gm0, go0, p.geglu_D) + fr * 64 + fq * 4;
         unsigned o2[4][4][2];                                    // [row tile][column tile][column pair]: the gated result as packed fp16 pairs, 32 registers
         // (the bias loads are older than everything this wait could leave in flight)
         asm volatile("s_waitcnt vmcnt(8)" : "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2]), "+v"(bh[3]), "+v"(bg[0]), "+v"(bg[1]), "+v"(bg[2]), "+v"(bg[3]) :: "memory");
@@ -273,11 +245,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
                     const half2e hh = __builtin_convertvector((syn3r_f2){acc[j][i][r], acc[j][i][r + 1]} + bhf[r >> 1], half2e);
                     const half2e gh = __builtin_convertvector((syn3r_f2){acc[j + 4][i][r], acc[j + 4][i][r + 1]} + bgf[r >> 1], half2e);
                     const syn3r_f2 hv = __builtin_convertvector(hh, syn3r_f2), gv = __builtin_convertvector(gh, syn3r_f2);
-#ifdef G256_NOGATE      // developer ablation
-                    const syn3r_f2 y = hv + gv;
-#else
                     const syn3r_f2 y = hv * gelu_pk(gv);
-#endif
                     o2[i][j][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(y, half2e));
                 }
         }
@@ -286,34 +254,10 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GSTAMP(5);
         const bool rows_in = gm0 < p.M;                          // (wave-uniform: a half last tile's wavefronts 4-7 have nothing to store)
-#if defined(G256_NOSTORE)   // developer ablation: one store per tile keeps the gate alive
-        {
-            unsigned x_ = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) x_ ^= o2[i][j][0] ^ o2[i][j][1];
-            if (x_ == 0x12345678u) *(unsigned*)obase = x_;
-        }
-#elif defined(G256_DEFER)
-        pbase = rows_in ? p.out + tiled_off(gm0, go0, p.geglu_D) + fr * 64 + (fq & 1) * 16 + (fq >> 1) * 8 : nullptr;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                auto r0 = __builtin_amdgcn_permlane16_swap(o2[i][j][0], o2[i][j + 1][0], false, false);
-                auto r1 = __builtin_amdgcn_permlane16_swap(o2[i][j][1], o2[i][j + 1][1], false, false);
-                pv[i * 2 + (j >> 1)] = (u32x4){(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
-            }
-#elif !defined(G256_ST8)    // 16-byte stores (two v_permlane16_swap per pair of column tiles): 16 rows x 64 bytes per instruction
         {
             // lanes of 16-lane row q hold columns 4 q .. 4 q + 3 of a column tile; after the swaps rows 0 / 2 hold columns 0-7 / 8-15 of tile
             // j and rows 1 / 3 those of tile j + 1: piece (row q) = tile j + (q & 1), columns 8 (q >> 1) .. + 7
-#ifdef G256_STSMALL     // developer ablation: every block stores into its own fixed 64 KB (cache-resident: no write traffic beyond the L2)
-            __half* pb = p.out + (size_t)blockIdx.x * 32768 + (wv * 4096) + fr * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
-#else
             __half* pb = p.out + tiled_off(gm0, go0, p.geglu_D) + fr * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
-#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -322,25 +266,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
                     auto r1 = __builtin_amdgcn_permlane16_swap(o2[i][j][1], o2[i][j + 1][1], false, false);
                     const u32x4 v = (u32x4){(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
                     u32x4* dst = (u32x4*)(pb + i * 16 * 64 + j * 16);
-#ifdef G256_ST1LANE     // developer ablation: the same store instructions with ONE active lane (16 bytes instead of 1 KB each)
-                    if (le == 0) *dst = v;
-#else
                     if (rows_in) { if (p.out_nt) __builtin_nontemporal_store(v, dst); else *dst = v; }
-#endif
                 }
         }
-#elif !defined(G256_DEFER)
-        // four consecutive stores complete the 128-byte lines of 16 rows
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                typedef unsigned u2 __attribute__((ext_vector_type(2)));
-                u2* dst = (u2*)(obase + i * 16 * 64 + j * 16);
-                const u2 v2 = (u2){o2[i][j][0], o2[i][j][1]};
-                if (rows_in) { if (p.out_nt) __builtin_nontemporal_store(v2, dst); else *dst = v2; }
-            }
-#endif
         GSTAMP(6);
 #ifdef SYN3R_TIMING
         ++gt[7];
@@ -352,8 +280,5 @@ __global__ void __launch_bounds__(512, 2) k_gemm_g256(GemmParams p) {
 #endif
 #undef GSTAMP
 #undef G256_GROUP
-#ifdef G256_DEFER
-    if (pbase) for (int u = 0; u < 8; ++u) store_unit(u);
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the exhausted cursors' last requests)
 }
