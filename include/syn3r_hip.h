@@ -230,6 +230,19 @@ int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, const float* me
                             const float* projmatrix, const float* campos, float tanfovx, float tanfovy, int H,
                             int W, int* radii, void* geom, size_t geom_bytes, long long* num_rendered_host,
                             void* stream);
+/*
+ * The same stage on the trainer's PARAMETERS: log_scales [N,3], raw_rotations [N,4] (unnormalised), opacity_logits [N] - the
+ * published activations (exp / normalize / sigmoid: GaussianModel.get_scaling / get_rotation / get_opacity, applied before every
+ * render inside gsTrainer.training() / finetune(), model/diffusionGS.py:139,1640) happen inside the projection kernel, in
+ * syn3r_gaussian_activate's arithmetic: bit for bit the state syn3r_gaussian_activate + syn3r_raster_preprocess leave, one launch
+ * and three intermediate tensors less per training iteration.  Pair it with syn3r_raster_backward_raw.
+ */
+int syn3r_raster_preprocess_raw(int N, int sh_degree, int sh_coeffs, const float* means3D, const float* log_scales,
+                                const float* raw_rotations, const float* opacity_logits, const float* shs,
+                                const float* confidence, float scale_modifier, const float* viewmatrix,
+                                const float* projmatrix, const float* campos, float tanfovx, float tanfovy, int H,
+                                int W, int* radii, void* geom, size_t geom_bytes, long long* num_rendered_host,
+                                void* stream);
 
 /*
  * Stage 2: the per-tile lists of Gaussians in depth order - entry for entry the
@@ -266,6 +279,21 @@ int syn3r_raster_backward(int N, int sh_degree, int sh_coeffs, long long P, cons
                           const float* dL_ddepth, const float* dL_dalpha, float* dL_dmeans3D, float* dL_dscales,
                           float* dL_drotations, float* dL_dopacities, float* dL_dshs, float* dL_dmeans2D,
                           float* dL_dconfidence, void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * Backward of a forward that started with syn3r_raster_preprocess_raw: the same three parameter tensors in, the gradients
+ * with respect to THEM out (syn3r_gaussian_activate_backward's chain rule applied where the activated gradients are formed:
+ * d_log_scales = d_scales * scales, d_raw_rotations = (g - qhat (qhat . g)) / max(|q|, 1e-12), d_logits = d_opacities * s (1 - s);
+ * the same bits as syn3r_raster_backward followed by syn3r_gaussian_activate_backward).
+ */
+int syn3r_raster_backward_raw(int N, int sh_degree, int sh_coeffs, long long P, const float* means3D,
+                              const float* log_scales, const float* raw_rotations, const float* opacity_logits,
+                              const float* shs, const float* confidence, float scale_modifier, const float* viewmatrix,
+                              const float* projmatrix, const float* campos, float tanfovx, float tanfovy, int H, int W,
+                              const float* bg, const int* radii, void* geom, size_t geom_bytes,
+                              const unsigned* point_list, void* image, size_t image_bytes, const float* dL_dcolor,
+                              const float* dL_ddepth, const float* dL_dalpha, float* dL_dmeans3D, float* dL_dlog_scales,
+                              float* dL_draw_rotations, float* dL_dopacity_logits, float* dL_dshs, float* dL_dmeans2D,
+                              float* dL_dconfidence, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits) — the
@@ -554,6 +582,11 @@ int syn3r_photo_loss(const float* image, const float* target, int C, int H, int 
                      float* loss3, void* ws, size_t ws_bytes, void* stream);
 int syn3r_photo_loss_backward(const float* image, const float* target, int C, int H, int W, float lambda_dssim,
                               float weight, const float* grad_loss, const void* ws, float* grad_image, void* stream);
+/* Value AND gradient in two launches (a training step wants both): syn3r_photo_loss followed by syn3r_photo_loss_backward on the
+ * same arguments, except that loss3 is written by the gradient pass (its first block forms the forward's sums; the gradient does
+ * not depend on them) instead of by a single-block launch between the passes.  Same bits in loss3 and grad_image. */
+int syn3r_photo_loss_step(const float* image, const float* target, int C, int H, int W, float lambda_dssim, float weight,
+                          const float* grad_loss, float* loss3, float* grad_image, void* ws, size_t ws_bytes, void* stream);
 
 /* One torch.optim.Adam update (no weight decay, no amsgrad) of n fp32 parameters in place, in torch's
  * operation order: exp_avg.lerp_(g, 1-beta1); exp_avg_sq = beta2*exp_avg_sq + (1-beta2)*g*g;

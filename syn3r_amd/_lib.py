@@ -50,12 +50,17 @@ SIGNATURES = {
     "syn3r_raster_binning_bytes": (c_sz, [c_ll]),
     "syn3r_raster_preprocess": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_f, c_f,
                                       c_i, c_i, c_p, c_p, c_sz, C.POINTER(c_ll), c_p]),
+    "syn3r_raster_preprocess_raw": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_f, c_f,
+                                          c_i, c_i, c_p, c_p, c_sz, C.POINTER(c_ll), c_p]),
     "syn3r_raster_render": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p, c_sz, c_p, c_sz, c_ll, c_p, c_p, c_p,
                                   C.POINTER(c_p), c_p]),
     "syn3r_raster_backward_workspace_bytes": (c_sz, [c_i]),
     "syn3r_raster_backward": (c_i, [c_i, c_i, c_i, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_f, c_f,
                                     c_i, c_i, c_p, c_p, c_p, c_sz, c_p, c_p, c_sz, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                     c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "syn3r_raster_backward_raw": (c_i, [c_i, c_i, c_i, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_f, c_f,
+                                        c_i, c_i, c_p, c_p, c_p, c_sz, c_p, c_p, c_sz, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                        c_p, c_p, c_p, c_p, c_sz, c_p]),
     "syn3r_sort_pairs_workspace_bytes": (c_sz, [c_ll]),
     "syn3r_sort_pairs": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_i, c_p, c_sz, C.POINTER(c_i), c_p]),
     "syn3r_gaussian_activate": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
@@ -104,6 +109,7 @@ SIGNATURES = {
     "syn3r_photo_loss_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "syn3r_photo_loss": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_sz, c_p]),
     "syn3r_photo_loss_backward": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_p]),
+    "syn3r_photo_loss_step": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "syn3r_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_i, c_p]),
     "syn3r_adam_step_multi": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p]),
     "syn3r_knn3_workspace_bytes": (c_sz, [c_i]),

@@ -198,3 +198,28 @@ __device__ __forceinline__ syn3r_f2 gelu_pk(syn3r_f2 g) {
     for (int k = SYN3R_GELU_DEG - 2; k >= 0; --k) a = a * t + c[k];
     return g * (gc * a + 0.5f);
 }
+
+// The published 3DGS parameter activations (GaussianModel.get_scaling / get_rotation / get_opacity: exp, normalize, sigmoid) and
+// their chain rule, as torch writes them (normalize = x / max(|x|_2, 1e-12); d/dx = (g - xhat (xhat . g)) / max(|x|, eps);
+// sigmoid' = s (1 - s); exp' = e).  ONE arithmetic for k_activate[_bwd] (train.hip, built without fma contraction) and for the
+// raw-parameter rasteriser entries (raster_fwd.hip / raster_bwd.hip, built with it): contraction is off inside these bodies, so
+// both routes leave the same bits.
+__device__ __forceinline__ float act_exp(float x) { return expf(x); }
+__device__ __forceinline__ float act_sigmoid(float x) {
+#pragma clang fp contract(off)
+    return 1.0f / (1.0f + expf(-x));
+}
+__device__ __forceinline__ float act_quat_inv_norm(float4 q) {
+#pragma clang fp contract(off)
+    return 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+}
+__device__ __forceinline__ float4 act_quat(float4 q, float inv) { return make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv); }
+__device__ __forceinline__ float4 act_quat_bwd(float4 h /*normalised*/, float4 g, float inv) {
+#pragma clang fp contract(off)
+    const float dot = h.x * g.x + h.y * g.y + h.z * g.z + h.w * g.w;
+    return make_float4((g.x - h.x * dot) * inv, (g.y - h.y * dot) * inv, (g.z - h.z * dot) * inv, (g.w - h.w * dot) * inv);
+}
+__device__ __forceinline__ float act_sigmoid_bwd(float s, float g) {
+#pragma clang fp contract(off)
+    return g * s * (1.0f - s);
+}

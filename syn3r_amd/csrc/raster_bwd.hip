@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
     const float* __restrict__ conf, float scale_mod, Camera cam, const int* __restrict__ radii, GeomState g,
     const float* __restrict__ grad_rec, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drots, float* __restrict__ dL_dopacity, float* __restrict__ dL_dshs,
-    float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconf) {
+    float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dconf, int raw) {
     __shared__ float shl[STAGED ? 256 * kShLd : 1];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const size_t blk0 = (size_t)blockIdx.x * 256 * 48;                // first float of the block's rows
@@ -458,13 +458,25 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
     dL_dmeans3D[3 * i] = dmean.x; dL_dmeans3D[3 * i + 1] = dmean.y; dL_dmeans3D[3 * i + 2] = dmean.z;
 
     // ---- opacity / confidence (blend used opacity * confidence)
+    // raw (syn3r_raster_backward_raw): `scales` / `rots` / `opacities` are the trainer's PARAMETERS; the activations are formed
+    // again (k_activate's arithmetic, common.h) and the gradients leave through their chain rule (k_activate_bwd's): the same bits
+    // as the two-launch route
     float cf = conf ? conf[i] : 1.0f;
-    dL_dopacity[i] = gr[G_OP] * cf;
-    if (dL_dconf) dL_dconf[i] = gr[G_OP] * opacities[i];
+    const float op_a = raw ? act_sigmoid(opacities[i]) : opacities[i];
+    dL_dopacity[i] = raw ? act_sigmoid_bwd(op_a, gr[G_OP] * cf) : gr[G_OP] * cf;
+    if (dL_dconf) dL_dconf[i] = gr[G_OP] * op_a;
 
     // ---- Sigma = M M^T, M = R S  -> scale, rotation
-    float sx = scale_mod * scales[3 * i], sy = scale_mod * scales[3 * i + 1], sz = scale_mod * scales[3 * i + 2];
-    float qr = rots[4 * i], qx = rots[4 * i + 1], qy = rots[4 * i + 2], qz = rots[4 * i + 3];
+    float s0 = scales[3 * i], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
+    float4 q4 = make_float4(rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3]);
+    float q_inv = 1.0f;
+    if (raw) {
+        s0 = act_exp(s0); s1 = act_exp(s1); s2 = act_exp(s2);
+        q_inv = act_quat_inv_norm(q4);
+        q4 = act_quat(q4, q_inv);
+    }
+    float sx = scale_mod * s0, sy = scale_mod * s1, sz = scale_mod * s2;
+    float qr = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
     float R00 = 1.f - 2.f * (qy * qy + qz * qz), R01 = 2.f * (qx * qy - qr * qz), R02 = 2.f * (qx * qz + qr * qy);
     float R10 = 2.f * (qx * qy + qr * qz), R11 = 1.f - 2.f * (qx * qx + qz * qz), R12 = 2.f * (qy * qz - qr * qx);
     float R20 = 2.f * (qx * qz - qr * qy), R21 = 2.f * (qy * qz + qr * qx), R22 = 1.f - 2.f * (qx * qx + qy * qy);
@@ -479,19 +491,26 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
           dM12 = 2.f * (G01 * m02 + G11 * m12 + G12 * m22);
     float dM20 = 2.f * (G02 * m00 + G12 * m10 + G22 * m20), dM21 = 2.f * (G02 * m01 + G12 * m11 + G22 * m21),
           dM22 = 2.f * (G02 * m02 + G12 * m12 + G22 * m22);
-    dL_dscales[3 * i] = scale_mod * (dM00 * R00 + dM10 * R10 + dM20 * R20);
-    dL_dscales[3 * i + 1] = scale_mod * (dM01 * R01 + dM11 * R11 + dM21 * R21);
-    dL_dscales[3 * i + 2] = scale_mod * (dM02 * R02 + dM12 * R12 + dM22 * R22);
+    float ds0 = scale_mod * (dM00 * R00 + dM10 * R10 + dM20 * R20);
+    float ds1 = scale_mod * (dM01 * R01 + dM11 * R11 + dM21 * R21);
+    float ds2 = scale_mod * (dM02 * R02 + dM12 * R12 + dM22 * R22);
     float dR00 = dM00 * sx, dR01 = dM01 * sy, dR02 = dM02 * sz;
     float dR10 = dM10 * sx, dR11 = dM11 * sy, dR12 = dM12 * sz;
     float dR20 = dM20 * sx, dR21 = dM21 * sy, dR22 = dM22 * sz;
-    dL_drots[4 * i] = 2.f * (-qz * dR01 + qy * dR02 + qz * dR10 - qx * dR12 - qy * dR20 + qx * dR21);
-    dL_drots[4 * i + 1] = 2.f * (qy * dR01 + qz * dR02 + qy * dR10 - 2.f * qx * dR11 - qr * dR12 + qz * dR20 + qr * dR21 -
-                                 2.f * qx * dR22);
-    dL_drots[4 * i + 2] = 2.f * (-2.f * qy * dR00 + qx * dR01 + qr * dR02 + qx * dR10 + qz * dR12 - qr * dR20 + qz * dR21 -
-                                 2.f * qy * dR22);
-    dL_drots[4 * i + 3] = 2.f * (-2.f * qz * dR00 - qr * dR01 + qx * dR02 + qr * dR10 - 2.f * qz * dR11 + qy * dR12 +
-                                 qx * dR20 + qy * dR21);
+    float4 dq;
+    dq.x = 2.f * (-qz * dR01 + qy * dR02 + qz * dR10 - qx * dR12 - qy * dR20 + qx * dR21);
+    dq.y = 2.f * (qy * dR01 + qz * dR02 + qy * dR10 - 2.f * qx * dR11 - qr * dR12 + qz * dR20 + qr * dR21 -
+                  2.f * qx * dR22);
+    dq.z = 2.f * (-2.f * qy * dR00 + qx * dR01 + qr * dR02 + qx * dR10 + qz * dR12 - qr * dR20 + qz * dR21 -
+                  2.f * qy * dR22);
+    dq.w = 2.f * (-2.f * qz * dR00 - qr * dR01 + qx * dR02 + qr * dR10 - 2.f * qz * dR11 + qy * dR12 +
+                  qx * dR20 + qy * dR21);
+    if (raw) {
+        ds0 *= s0; ds1 *= s1; ds2 *= s2;
+        dq = act_quat_bwd(q4, dq, q_inv);
+    }
+    dL_dscales[3 * i] = ds0; dL_dscales[3 * i + 1] = ds1; dL_dscales[3 * i + 2] = ds2;
+    dL_drots[4 * i] = dq.x; dL_drots[4 * i + 1] = dq.y; dL_drots[4 * i + 2] = dq.z; dL_drots[4 * i + 3] = dq.w;
     } while (0);
     if constexpr (STAGED) {
         __syncthreads();
@@ -512,7 +531,7 @@ extern "C" size_t syn3r_raster_backward_workspace_bytes(int N) {
     return N > 0 ? align256((size_t)N * kGradSlots * sizeof(float)) : 0;
 }
 
-extern "C" int syn3r_raster_backward(int N, int sh_degree, int sh_coeffs, long long P, const float* means3D,
+static int raster_backward(int raw, int N, int sh_degree, int sh_coeffs, long long P, const float* means3D,
                                      const float* scales, const float* rotations, const float* opacities,
                                      const float* shs, const float* confidence, float scale_modifier,
                                      const float* viewmatrix, const float* projmatrix, const float* campos,
@@ -553,13 +572,46 @@ extern "C" int syn3r_raster_backward(int N, int sh_degree, int sh_coeffs, long l
     if (staged)
         SYN3R_LAUNCH(k_preprocess_bwd<true>, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
                        scales, rotations, opacities, shs, confidence, scale_modifier, cam, radii, g, grad_rec,
-                       dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacities, dL_dshs, dL_dmeans2D, dL_dconfidence);
+                       dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacities, dL_dshs, dL_dmeans2D, dL_dconfidence, raw);
     else
     SYN3R_LAUNCH(k_preprocess_bwd<false>, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
                        scales, rotations, opacities, shs, confidence, scale_modifier, cam, radii, g, grad_rec,
-                       dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacities, dL_dshs, dL_dmeans2D, dL_dconfidence);
+                       dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacities, dL_dshs, dL_dmeans2D, dL_dconfidence, raw);
     SYN3R_LAUNCH_CHECK("raster_backward launch");
     return SYN3R_OK;
+}
+
+extern "C" int syn3r_raster_backward(int N, int sh_degree, int sh_coeffs, long long P, const float* means3D,
+                                     const float* scales, const float* rotations, const float* opacities,
+                                     const float* shs, const float* confidence, float scale_modifier,
+                                     const float* viewmatrix, const float* projmatrix, const float* campos,
+                                     float tanfovx, float tanfovy, int H, int W, const float* bg, const int* radii,
+                                     void* geom, size_t geom_bytes_, const unsigned* point_list, void* image,
+                                     size_t image_bytes_, const float* dL_dcolor, const float* dL_ddepth,
+                                     const float* dL_dalpha, float* dL_dmeans3D, float* dL_dscales,
+                                     float* dL_drotations, float* dL_dopacities, float* dL_dshs, float* dL_dmeans2D,
+                                     float* dL_dconfidence, void* workspace, size_t workspace_bytes, void* stream_) {
+    return raster_backward(0, N, sh_degree, sh_coeffs, P, means3D, scales, rotations, opacities, shs, confidence, scale_modifier,
+                           viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, bg, radii, geom, geom_bytes_, point_list, image,
+                           image_bytes_, dL_dcolor, dL_ddepth, dL_dalpha, dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacities,
+                           dL_dshs, dL_dmeans2D, dL_dconfidence, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int syn3r_raster_backward_raw(int N, int sh_degree, int sh_coeffs, long long P, const float* means3D,
+                                         const float* log_scales, const float* raw_rotations, const float* opacity_logits,
+                                         const float* shs, const float* confidence, float scale_modifier,
+                                         const float* viewmatrix, const float* projmatrix, const float* campos,
+                                         float tanfovx, float tanfovy, int H, int W, const float* bg, const int* radii,
+                                         void* geom, size_t geom_bytes_, const unsigned* point_list, void* image,
+                                         size_t image_bytes_, const float* dL_dcolor, const float* dL_ddepth,
+                                         const float* dL_dalpha, float* dL_dmeans3D, float* dL_dlog_scales,
+                                         float* dL_draw_rotations, float* dL_dopacity_logits, float* dL_dshs, float* dL_dmeans2D,
+                                         float* dL_dconfidence, void* workspace, size_t workspace_bytes, void* stream_) {
+    return raster_backward(1, N, sh_degree, sh_coeffs, P, means3D, log_scales, raw_rotations, opacity_logits, shs, confidence,
+                           scale_modifier, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, bg, radii, geom, geom_bytes_,
+                           point_list, image, image_bytes_, dL_dcolor, dL_ddepth, dL_dalpha, dL_dmeans3D, dL_dlog_scales,
+                           dL_draw_rotations, dL_dopacity_logits, dL_dshs, dL_dmeans2D, dL_dconfidence, workspace, workspace_bytes,
+                           stream_);
 }
 
 #ifdef SYN3R_RASTER_STATS

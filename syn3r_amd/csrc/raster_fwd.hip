@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256) k_preprocess(int N, int D, int M, const f
                                                     const float* __restrict__ opacities,
                                                     const float* __restrict__ shs, const float* __restrict__ conf,
                                                     float scale_mod, Camera cam, int* __restrict__ radii,
-                                                    GeomState g) {
+                                                    GeomState g, int raw) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     if (i < 4) g.header[i] = 0u;            // pair count (written by the scan that follows) and overflow flag
@@ -187,8 +187,16 @@ __global__ void __launch_bounds__(256) k_preprocess(int N, int D, int M, const f
     float ndcx = ph.x * pw, ndcy = ph.y * pw;
 
     // 3D covariance  Sigma = R S^2 R^T  (q = (r, x, y, z), not renormalised here)
-    float sx = scale_mod * scales[3 * i], sy = scale_mod * scales[3 * i + 1], sz = scale_mod * scales[3 * i + 2];
-    float qr = rots[4 * i], qx = rots[4 * i + 1], qy = rots[4 * i + 2], qz = rots[4 * i + 3];
+    // raw (syn3r_raster_preprocess_raw): the tensors are the trainer's PARAMETERS (log-scales, unnormalised quaternions, opacity
+    // logits) and the published activations are applied here, in k_activate's arithmetic (common.h: the same bits)
+    float s0 = scales[3 * i], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
+    float4 q4 = make_float4(rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3]);
+    if (raw) {
+        s0 = act_exp(s0); s1 = act_exp(s1); s2 = act_exp(s2);
+        q4 = act_quat(q4, act_quat_inv_norm(q4));
+    }
+    float sx = scale_mod * s0, sy = scale_mod * s1, sz = scale_mod * s2;
+    float qr = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
     float R00 = 1.f - 2.f * (qy * qy + qz * qz), R01 = 2.f * (qx * qy - qr * qz), R02 = 2.f * (qx * qz + qr * qy);
     float R10 = 2.f * (qx * qy + qr * qz), R11 = 1.f - 2.f * (qx * qx + qz * qz), R12 = 2.f * (qy * qz - qr * qx);
     float R20 = 2.f * (qx * qz - qr * qy), R21 = 2.f * (qy * qz + qr * qx), R22 = 1.f - 2.f * (qx * qx + qy * qy);
@@ -235,7 +243,7 @@ __global__ void __launch_bounds__(256) k_preprocess(int N, int D, int M, const f
 
     unsigned cl;
     float3 rgb = sh_to_rgb(D, M, p, cam.campos, shs + (size_t)i * M * 3, cl);
-    float op = opacities[i];
+    float op = raw ? act_sigmoid(opacities[i]) : opacities[i];
     float cf = conf ? conf[i] : 1.0f;
     g.depths[i] = t.z;
     g.dkeys_a[i] = __float_as_uint(t.z);    // t.z > kNearClip > 0: the bit pattern orders like the float
@@ -967,12 +975,12 @@ extern "C" size_t syn3r_raster_geom_bytes(int N) { return SYN3R_DIM_OK(N) ? geom
 extern "C" size_t syn3r_raster_image_bytes(int H, int W) { return (SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W)) ? image_bytes(H, W) : 0; }
 extern "C" size_t syn3r_raster_binning_bytes(long long P) { return P >= 0 ? binning_bytes(P) : 0; }
 
-extern "C" int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, const float* means3D,
-                                       const float* scales, const float* rotations, const float* opacities,
-                                       const float* shs, const float* confidence, float scale_modifier,
-                                       const float* viewmatrix, const float* projmatrix, const float* campos,
-                                       float tanfovx, float tanfovy, int H, int W, int* radii, void* geom,
-                                       size_t geom_bytes_, long long* num_rendered_host, void* stream_) {
+static int raster_preprocess(int raw, int N, int sh_degree, int sh_coeffs, const float* means3D,
+                             const float* scales, const float* rotations, const float* opacities,
+                             const float* shs, const float* confidence, float scale_modifier,
+                             const float* viewmatrix, const float* projmatrix, const float* campos,
+                             float tanfovx, float tanfovy, int H, int W, int* radii, void* geom,
+                             size_t geom_bytes_, long long* num_rendered_host, void* stream_) {
     SYN3R_REQUIRE(SYN3R_DIM_OK(N) && SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W), "raster_preprocess: bad sizes N=%d H=%d W=%d", N, H, W);
     SYN3R_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "raster_preprocess: sh_degree %d not in 0..3", sh_degree);
     SYN3R_REQUIRE(sh_coeffs >= (sh_degree + 1) * (sh_degree + 1) && sh_coeffs <= 1024,
@@ -990,7 +998,7 @@ extern "C" int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, cons
     Camera cam;
     fill_camera(cam, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W);
     SYN3R_LAUNCH(k_preprocess, dim3(ceil_div(N, 256)), dim3(256), 0, stream, N, sh_degree, sh_coeffs, means3D,
-                       scales, rotations, opacities, shs, confidence, scale_modifier, cam, radii, g);
+                       scales, rotations, opacities, shs, confidence, scale_modifier, cam, radii, g, raw);
     int rc = SYN3R_OK;
     const bool hier = hier_binning(N, cam.grid_x, cam.grid_y);
     if (!hier) {
@@ -1019,6 +1027,28 @@ extern "C" int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, cons
         *num_rendered_host = (long long)total;
     }
     return SYN3R_OK;
+}
+
+extern "C" int syn3r_raster_preprocess(int N, int sh_degree, int sh_coeffs, const float* means3D,
+                                       const float* scales, const float* rotations, const float* opacities,
+                                       const float* shs, const float* confidence, float scale_modifier,
+                                       const float* viewmatrix, const float* projmatrix, const float* campos,
+                                       float tanfovx, float tanfovy, int H, int W, int* radii, void* geom,
+                                       size_t geom_bytes_, long long* num_rendered_host, void* stream_) {
+    return raster_preprocess(0, N, sh_degree, sh_coeffs, means3D, scales, rotations, opacities, shs, confidence, scale_modifier,
+                             viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, radii, geom, geom_bytes_, num_rendered_host,
+                             stream_);
+}
+
+extern "C" int syn3r_raster_preprocess_raw(int N, int sh_degree, int sh_coeffs, const float* means3D,
+                                           const float* log_scales, const float* raw_rotations, const float* opacity_logits,
+                                           const float* shs, const float* confidence, float scale_modifier,
+                                           const float* viewmatrix, const float* projmatrix, const float* campos,
+                                           float tanfovx, float tanfovy, int H, int W, int* radii, void* geom,
+                                           size_t geom_bytes_, long long* num_rendered_host, void* stream_) {
+    return raster_preprocess(1, N, sh_degree, sh_coeffs, means3D, log_scales, raw_rotations, opacity_logits, shs, confidence,
+                             scale_modifier, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, radii, geom, geom_bytes_,
+                             num_rendered_host, stream_);
 }
 
 extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const int* radii, void* geom,

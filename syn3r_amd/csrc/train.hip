@@ -136,11 +136,10 @@ __global__ void __launch_bounds__(kThreads) k_activate(int N, const float* __res
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= N) return;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) scale[3 * i + c] = expf(log_scale[3 * i + c]);
+    for (int c = 0; c < 3; ++c) scale[3 * i + c] = act_exp(log_scale[3 * i + c]);
     const float4 q = *(const float4*)(rot + 4 * i);
-    const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-    *(float4*)(rot_n + 4 * i) = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
-    opacity[i] = 1.0f / (1.0f + expf(-logit[i]));
+    *(float4*)(rot_n + 4 * i) = act_quat(q, act_quat_inv_norm(q));
+    opacity[i] = act_sigmoid(logit[i]);
 }
 
 __global__ void __launch_bounds__(kThreads) k_activate_bwd(int N, const float* __restrict__ rot, const float* __restrict__ scale,
@@ -153,11 +152,8 @@ __global__ void __launch_bounds__(kThreads) k_activate_bwd(int N, const float* _
 #pragma unroll
     for (int c = 0; c < 3; ++c) d_log_scale[3 * i + c] = d_scale[3 * i + c] * scale[3 * i + c];
     const float4 q = *(const float4*)(rot + 4 * i), h = *(const float4*)(rot_n + 4 * i), g = *(const float4*)(d_rot_n + 4 * i);
-    const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-    const float dot = h.x * g.x + h.y * g.y + h.z * g.z + h.w * g.w;
-    *(float4*)(d_rot + 4 * i) = make_float4((g.x - h.x * dot) * inv, (g.y - h.y * dot) * inv, (g.z - h.z * dot) * inv, (g.w - h.w * dot) * inv);
-    const float s = opacity[i];
-    d_logit[i] = d_opacity[i] * s * (1.0f - s);
+    *(float4*)(d_rot + 4 * i) = act_quat_bwd(h, g, act_quat_inv_norm(q));
+    d_logit[i] = act_sigmoid_bwd(opacity[i], d_opacity[i]);
 }
 
 // GaussianModel.add_densification_stats of the published trainer for the visible Gaussians (radii > 0): torch.norm(grad[:, :2]) is
@@ -350,28 +346,33 @@ __global__ void __launch_bounds__(kPhotoThreads) k_photo_fwd(const float* __rest
     }
 }
 
-// loss[0] = w*((1-lam)*L1 + lam*(1-SSIM)), loss[1] = L1, loss[2] = SSIM  (fixed-order double sums)
-__global__ void __launch_bounds__(256) k_photo_final(const float* __restrict__ partial, long long nblocks, double inv_n,
-                                                     float lam, float weight, float* __restrict__ loss) {
+// loss[0] = w*((1-lam)*L1 + lam*(1-SSIM)), loss[1] = L1, loss[2] = SSIM  (fixed-order double sums; a block of 256 threads)
+struct PhotoFinal { const float* partial; long long nblocks; double inv_n; float lam, weight; float* loss; };
+__device__ __forceinline__ void photo_final(const PhotoFinal f) {
+    static_assert(kPhotoThreads == 256, "photo_final: one sum per thread of a 256-thread block");
     double sl = 0.0, ss = 0.0;
-    for (long long i = threadIdx.x; i < nblocks; i += 256) { sl += (double)partial[2 * i]; ss += (double)partial[2 * i + 1]; }
+    for (long long i = threadIdx.x; i < f.nblocks; i += 256) { sl += (double)f.partial[2 * i]; ss += (double)f.partial[2 * i + 1]; }
     sl = wave_sum_d(sl); ss = wave_sum_d(ss);
     __shared__ double w1[4], w2[4];
     if ((threadIdx.x & 63) == 0) { w1[threadIdx.x >> 6] = sl; w2[threadIdx.x >> 6] = ss; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double l1 = ((w1[0] + w1[1]) + (w1[2] + w1[3])) * inv_n, ssim = ((w2[0] + w2[1]) + (w2[2] + w2[3])) * inv_n;
-        loss[0] = (float)((double)weight * ((1.0 - (double)lam) * l1 + (double)lam * (1.0 - ssim)));
-        loss[1] = (float)l1;
-        loss[2] = (float)ssim;
+        const double l1 = ((w1[0] + w1[1]) + (w1[2] + w1[3])) * f.inv_n, ssim = ((w2[0] + w2[1]) + (w2[2] + w2[3])) * f.inv_n;
+        f.loss[0] = (float)((double)f.weight * ((1.0 - (double)f.lam) * l1 + (double)f.lam * (1.0 - ssim)));
+        f.loss[1] = (float)l1;
+        f.loss[2] = (float)ssim;
     }
 }
+__global__ void __launch_bounds__(256) k_photo_final(PhotoFinal f) { photo_final(f); }
 
 __global__ void __launch_bounds__(kPhotoThreads) k_photo_bwd(const float* __restrict__ img, const float* __restrict__ gt, int H,
                                                    int W, int C, SsimWindow win, int vec, const float* __restrict__ maps, float c_l1,
                                                    float c_ssim, const float* __restrict__ go,
-                                                   float* __restrict__ grad) {
+                                                   float* __restrict__ grad, PhotoFinal fin) {
     __shared__ __attribute__((aligned(16))) f2 hA[kReg][kTile];      // windowed (d_mu1, d_sigma1^2) after the horizontal pass
+    // syn3r_photo_loss_step: the forward's per-tile sums become loss3 HERE (k_photo_final's fixed-order double sums, by the block
+    // that is dispatched first) instead of in a single-block launch between the two passes: the gradient does not read the loss
+    if (fin.partial && blockIdx.x == 0) photo_final(fin);
     __shared__ __attribute__((aligned(16))) float hC[kReg][kTile];   // windowed d_sigma12
     const PhotoTile tl_ = photo_tile((W + kTile - 1) / kTile, (H + kTile - 1) / kTile);
     const int c = tl_.c, x0 = tl_.x0, y0 = tl_.y0;
@@ -600,23 +601,47 @@ extern "C" size_t syn3r_photo_loss_workspace_bytes(int C, int H, int W) {
     return 3 * n * sizeof(float) + ((2 * blocks * sizeof(float) + 255) / 256) * 256;
 }
 
-extern "C" int syn3r_photo_loss(const float* image, const float* target, int C, int H, int W, float lambda_dssim,
-                                float weight, float* loss3, void* ws, size_t ws_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    SYN3R_REQUIRE(C > 0 && C <= 65535 && SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W), "photo_loss: bad sizes C=%d H=%d W=%d", C, H, W);
-    SYN3R_REQUIRE(image && target && loss3 && ws, "photo_loss: null pointer");
-    SYN3R_REQUIRE(lambda_dssim >= 0.0f && lambda_dssim <= 1.0f, "photo_loss: lambda_dssim must be in [0, 1]");
-    SYN3R_REQUIRE(ws_bytes >= syn3r_photo_loss_workspace_bytes(C, H, W), "photo_loss: workspace too small");
+// forward pass (k_photo_fwd) of both entries; `final_launch`: loss3 by k_photo_final (syn3r_photo_loss) or left to the backward
+static int photo_forward(const char* who, const float* image, const float* target, int C, int H, int W, float lambda_dssim,
+                         float weight, float* loss3, void* ws, size_t ws_bytes, hipStream_t stream, bool final_launch, PhotoFinal* fin) {
+    SYN3R_REQUIRE(C > 0 && C <= 65535 && SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W), "%s: bad sizes C=%d H=%d W=%d", who, C, H, W);
+    SYN3R_REQUIRE(image && target && loss3 && ws, "%s: null pointer", who);
+    SYN3R_REQUIRE(lambda_dssim >= 0.0f && lambda_dssim <= 1.0f, "%s: lambda_dssim must be in [0, 1]", who);
+    SYN3R_REQUIRE(ws_bytes >= syn3r_photo_loss_workspace_bytes(C, H, W), "%s: workspace too small", who);
     const size_t n = (size_t)C * H * W;
     float* maps = (float*)ws;
     float* partial = maps + 3 * n;
     const long long tiles = (long long)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile) * C;
-    SYN3R_REQUIRE(tiles < (1ll << 31), "photo_loss: %lld tiles exceed the grid limit", tiles);
+    SYN3R_REQUIRE(tiles < (1ll << 31), "%s: %lld tiles exceed the grid limit", who, tiles);
     const dim3 grid((unsigned)tiles);
     const int vec = W % 4 == 0 && (((uintptr_t)image | (uintptr_t)target) & 15) == 0;      // aligned 16-byte row runs
     SYN3R_LAUNCH(k_photo_fwd, grid, dim3(kPhotoThreads), 0, stream, image, target, H, W, C, make_window(), vec, maps, partial);
-    SYN3R_LAUNCH(k_photo_final, dim3(1), dim3(256), 0, stream, (const float*)partial,
-                 (long long)grid.x, 1.0 / (double)n, lambda_dssim, weight, loss3);
+    const PhotoFinal f{partial, (long long)grid.x, 1.0 / (double)n, lambda_dssim, weight, loss3};
+    if (final_launch) SYN3R_LAUNCH(k_photo_final, dim3(1), dim3(256), 0, stream, f);
+    if (fin) *fin = f;
+    return SYN3R_OK;
+}
+
+static int photo_backward(const char* who, const float* image, const float* target, int C, int H, int W, float lambda_dssim,
+                          float weight, const float* grad_loss, const void* ws, float* grad_image, hipStream_t stream, PhotoFinal fin) {
+    SYN3R_REQUIRE(C > 0 && C <= 65535 && SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W), "%s: bad sizes", who);
+    SYN3R_REQUIRE(image && target && ws && grad_image, "%s: null pointer", who);
+    const double n = (double)C * H * W;
+    const long long tiles = (long long)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile) * C;
+    SYN3R_REQUIRE(tiles < (1ll << 31), "%s: %lld tiles exceed the grid limit", who, tiles);
+    const dim3 grid((unsigned)tiles);
+    const int vec = W % 4 == 0 && ((uintptr_t)ws & 15) == 0;
+    SYN3R_LAUNCH(k_photo_bwd, grid, dim3(kPhotoThreads), 0, stream, image, target, H, W, C, make_window(), vec, (const float*)ws,
+                 (float)((double)weight * (1.0 - (double)lambda_dssim) / n), (float)((double)weight * (double)lambda_dssim / n),
+                 grad_loss, grad_image, fin);
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_photo_loss(const float* image, const float* target, int C, int H, int W, float lambda_dssim,
+                                float weight, float* loss3, void* ws, size_t ws_bytes, void* stream_) {
+    const int rc = photo_forward("photo_loss", image, target, C, H, W, lambda_dssim, weight, loss3, ws, ws_bytes, (hipStream_t)stream_,
+                                 true, nullptr);
+    if (rc) return rc;
     SYN3R_LAUNCH_CHECK("photo_loss launch");
     return SYN3R_OK;
 }
@@ -624,17 +649,23 @@ extern "C" int syn3r_photo_loss(const float* image, const float* target, int C, 
 extern "C" int syn3r_photo_loss_backward(const float* image, const float* target, int C, int H, int W,
                                          float lambda_dssim, float weight, const float* grad_loss, const void* ws,
                                          float* grad_image, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    SYN3R_REQUIRE(C > 0 && C <= 65535 && SYN3R_SIDE_OK(H) && SYN3R_SIDE_OK(W), "photo_loss_backward: bad sizes");
-    SYN3R_REQUIRE(image && target && ws && grad_image, "photo_loss_backward: null pointer");
-    const double n = (double)C * H * W;
-    const long long tiles = (long long)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile) * C;
-    SYN3R_REQUIRE(tiles < (1ll << 31), "photo_loss: %lld tiles exceed the grid limit", tiles);
-    const dim3 grid((unsigned)tiles);
-    const int vec = W % 4 == 0 && ((uintptr_t)ws & 15) == 0;
-    SYN3R_LAUNCH(k_photo_bwd, grid, dim3(kPhotoThreads), 0, stream, image, target, H, W, C, make_window(), vec, (const float*)ws,
-                 (float)((double)weight * (1.0 - (double)lambda_dssim) / n), (float)((double)weight * (double)lambda_dssim / n),
-                 grad_loss, grad_image);
+    const int rc = photo_backward("photo_loss_backward", image, target, C, H, W, lambda_dssim, weight, grad_loss, ws, grad_image,
+                                  (hipStream_t)stream_, PhotoFinal{});
+    if (rc) return rc;
     SYN3R_LAUNCH_CHECK("photo_loss_backward launch");
+    return SYN3R_OK;
+}
+
+extern "C" int syn3r_photo_loss_step(const float* image, const float* target, int C, int H, int W, float lambda_dssim,
+                                     float weight, const float* grad_loss, float* loss3, float* grad_image, void* ws,
+                                     size_t ws_bytes, void* stream_) {
+    PhotoFinal fin{};
+    int rc = photo_forward("photo_loss_step", image, target, C, H, W, lambda_dssim, weight, loss3, ws, ws_bytes, (hipStream_t)stream_,
+                           false, &fin);
+    if (rc) return rc;
+    rc = photo_backward("photo_loss_step", image, target, C, H, W, lambda_dssim, weight, grad_loss, ws, grad_image,
+                        (hipStream_t)stream_, fin);
+    if (rc) return rc;
+    SYN3R_LAUNCH_CHECK("photo_loss_step launch");
     return SYN3R_OK;
 }

@@ -88,6 +88,27 @@ def photometric_loss(image: torch.Tensor, target: torch.Tensor, lambda_dssim: fl
     return (loss, parts) if return_parts else loss
 
 
+def photometric_loss_step(image: torch.Tensor, target: torch.Tensor, lambda_dssim: float = 0.2, weight: float = 1.0,
+                          grad_loss: torch.Tensor = None):
+    """Value AND image gradient of `photometric_loss` without autograd (`syn3r_photo_loss_step`: the two tile passes, the
+    scalar sums formed by the gradient pass' first block instead of a launch of their own).  Returns (loss - a view of
+    parts[0] -, parts [loss, L1, SSIM], grad_image); `grad_loss`: device scalar, default 1.  Same bits as
+    `_PhotoLoss.forward` + `.backward`."""
+    dev = L.require_gpu(image, target)
+    if image.shape != target.shape or image.dim() != 3 or image.dtype != torch.float32 or target.dtype != torch.float32:
+        raise ValueError("photometric_loss_step: image and target must be float32 [C,H,W] tensors of the same shape")
+    image, target = image.detach().contiguous(), target.detach().contiguous()
+    lib = L.load()
+    C_, H_, W_ = image.shape
+    ws = L.workspace(dev, lib.syn3r_photo_loss_workspace_bytes(C_, H_, W_), "photo_step")     # the maps die with the call
+    parts = torch.empty(3, dtype=torch.float32, device=dev)
+    grad = torch.empty_like(image)
+    go = grad_loss.to(torch.float32).contiguous() if grad_loss is not None else None
+    L.check(lib.syn3r_photo_loss_step(L.ptr(image), L.ptr(target), C_, H_, W_, float(lambda_dssim), float(weight), L.ptr(go),
+                                      L.ptr(parts), L.ptr(grad), L.ptr(ws), ws.numel(), L.stream_ptr(dev)), "photo_loss_step")
+    return parts[0], parts, grad
+
+
 def image_metrics(image: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """Device tensor [PSNR (dB, peak 1), SSIM] of two float32 [C,H,W] images in [0,1]: the MSE from `syn3r_image_mse`
     (deterministic two-level sum) and the SSIM the fused photometric-loss kernel computes (published 3DGS window).

@@ -557,49 +557,41 @@ class GSTrainer:
 
     def _explicit_step(self, cam: Camera) -> Tuple[torch.Tensor, dict]:
         """One optimisation step WITHOUT autograd: raw parameters in, raw-parameter gradients out.  The activations and
-        their chain rule are one HIP launch each (`syn3r_gaussian_activate[_backward]`, replacing three torch operators and
-        their ~10 autograd kernels), the rasteriser's and the loss' forward / backward are called directly, and no
-        screen-space `means2D` tensor is allocated per render.  Same kernels, same arithmetic as the autograd path
+        their chain rule run INSIDE the rasteriser's projection kernels (`syn3r_raster_preprocess_raw` / `_backward_raw`, round 6:
+        `syn3r_gaussian_activate[_backward]`'s arithmetic, two launches and six intermediate tensors less per iteration; the
+        autograd path keeps torch's three operators), the loss' value and gradient are `syn3r_photo_loss_step`'s two launches,
+        and no screen-space `means2D` tensor is allocated per render.  Same arithmetic as the autograd path
         (`tests/test_trainer_gpu.py` holds one step of each against the oracle and against each other)."""
         from ..raster import _Rasterize
-        from .train_ops import _L1Loss, _PhotoLoss
-        g, lib = self.gaussians, L.load()
+        from .train_ops import _L1Loss, photometric_loss_step
+        g = self.gaussians
         dev = g._xyz.device
-        N = g._xyz.shape[0]
-        stream = L.stream_ptr(dev)
         # this step discards the rasteriser's confidence gradient (slot 6 of its backward): the per-Gaussian confidence is data here,
         # as in the call sites (model/diffusionGS.py:139,1640); a trainable one has to take the autograd path
         conf = g.confidence
         if conf is not None and getattr(conf, "requires_grad", False):
             raise ValueError("_explicit_step: a confidence tensor that requires grad needs train_step(explicit=False)")
-        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         with torch.no_grad():
-            sc, ro, op = new(N, 3), new(N, 4), new(N, 1)
-            L.check(lib.syn3r_gaussian_activate(N, L.ptr(g._scaling), L.ptr(g._rotation), L.ptr(g._opacity), L.ptr(sc), L.ptr(ro),
-                                                L.ptr(op), stream), "gaussian_activate")
             st = GaussianRasterizationSettings(
                 image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
                 tanfovy=math.tan(cam.FoVy * 0.5), bg=self.background, scale_modifier=1.0,
                 viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=g.active_sh_degree,
                 campos=cam.camera_center, prefiltered=False, debug=False)
             rctx = self._Ctx()
-            color, radii, depth, alpha = _Rasterize.forward(rctx, g._xyz, None, g._features, op, sc, ro, g.confidence, st)
-            lctx = self._Ctx()
+            rctx.raw_params = True          # log-scales / raw quaternions / logits in, THEIR gradients out (syn3r_raster_*_raw)
+            color, radii, depth, alpha = _Rasterize.forward(rctx, g._xyz, None, g._features, g._opacity, g._scaling, g._rotation,
+                                                            g.confidence, st)
             w = float(cam.cam_confidence)
             if self.opt.lambda_dssim > 0.0:
-                loss, _ = _PhotoLoss.forward(lctx, color, cam.original_image, self.opt.lambda_dssim, w)
-                d_color = _PhotoLoss.backward(lctx, self._one(dev), None)[0]
+                loss, _, d_color = photometric_loss_step(color, cam.original_image, self.opt.lambda_dssim, w)
             else:
+                lctx = self._Ctx()
                 loss = _L1Loss.forward(lctx, color, cam.original_image, w)
                 d_color = _L1Loss.backward(lctx, self._one(dev))[0]
             grads = _Rasterize.backward(rctx, d_color, None, None, None)
             if len(grads) != 8:      # (means3D, means2D, sh, opacity, scales, rotations, confidence, settings): the order this step reads
                 raise RuntimeError(f"_Rasterize.backward returned {len(grads)} gradients, the explicit step reads 8")
-            d_m3, d_m2, d_sh, d_op, d_sc, d_ro, _, _ = grads
-            d_ls, d_rr, d_lg = new(N, 3), new(N, 4), new(N, 1)
-            L.check(lib.syn3r_gaussian_activate_backward(N, L.ptr(g._rotation), L.ptr(sc), L.ptr(ro), L.ptr(op), L.ptr(d_sc),
-                                                         L.ptr(d_ro), L.ptr(d_op), L.ptr(d_ls), L.ptr(d_rr), L.ptr(d_lg), stream),
-                    "gaussian_activate_backward")
+            d_m3, d_m2, d_sh, d_lg, d_ls, d_rr, _, _ = grads
             g._xyz.grad, g._features.grad, g._opacity.grad, g._scaling.grad, g._rotation.grad = d_m3, d_sh, d_lg.reshape(g._opacity.shape), d_ls, d_rr
         out = {"render": color, "depth": depth, "alpha": alpha, "viewspace_grad": d_m2, "visibility_filter": None,      # visible = radii > 0: add_densification_stats takes it from `radii` on the device
                "radii": radii}

@@ -136,7 +136,12 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, confidence, settings):
+        """`ctx.raw_params = True` (set by a caller that drives forward / backward itself: GSTrainer._explicit_step): `scales`,
+        `rotations`, `opacities` are the trainer's PARAMETERS (log-scales, unnormalised quaternions, logits); the activations
+        run inside the projection kernel (`syn3r_raster_preprocess_raw`) and backward returns the gradients of the parameters
+        (`syn3r_raster_backward_raw`)."""
         s: GaussianRasterizationSettings = settings
+        raw = bool(getattr(ctx, "raw_params", False))
         dev = L.require_gpu(means3D, shs, opacities, scales, rotations)
         lib = L.load()
         N = means3D.shape[0]
@@ -167,10 +172,11 @@ class _Rasterize(torch.autograd.Function):
                 raise err
         use_async = use_async and key in _capacity
         P = C.c_longlong(0)
-        rc = lib.syn3r_raster_preprocess(N, int(s.sh_degree), M, L.ptr(m3), L.ptr(sc), L.ptr(ro), L.ptr(op), L.ptr(sh),
-                                         L.ptr(cf), float(s.scale_modifier), view, proj, campos, float(s.tanfovx),
-                                         float(s.tanfovy), H, W, L.ptr(radii), L.ptr(geom), geom.numel(),
-                                         None if use_async else C.byref(P), stream)
+        preprocess = lib.syn3r_raster_preprocess_raw if raw else lib.syn3r_raster_preprocess
+        rc = preprocess(N, int(s.sh_degree), M, L.ptr(m3), L.ptr(sc), L.ptr(ro), L.ptr(op), L.ptr(sh),
+                        L.ptr(cf), float(s.scale_modifier), view, proj, campos, float(s.tanfovx),
+                        float(s.tanfovy), H, W, L.ptr(radii), L.ptr(geom), geom.numel(),
+                        None if use_async else C.byref(P), stream)
         L.check(rc, "syn3r_raster_preprocess")
         if use_async:
             P = _capacity[key]                          # capacity; the kernels read the live count on the device
@@ -233,7 +239,8 @@ class _Rasterize(torch.autograd.Function):
         d_m3, d_sc, d_ro, d_op, d_sh, d_m2 = new(N, 3), new(N, 3), new(N, 4), new(N), new(N, M, 3), new(N, 3)
         d_cf = new(N) if ctx.has_conf else None
         ws = L.workspace(dev, lib.syn3r_raster_backward_workspace_bytes(N), "raster_bwd")
-        rc = lib.syn3r_raster_backward(
+        backward = lib.syn3r_raster_backward_raw if getattr(ctx, "raw_params", False) else lib.syn3r_raster_backward
+        rc = backward(
             N, int(s.sh_degree), M, ctx.P, L.ptr(m3), L.ptr(sc), L.ptr(ro), L.ptr(op), L.ptr(sh),
             L.ptr(cf) if ctx.has_conf else None, float(s.scale_modifier), view, proj, campos, float(s.tanfovx),
             float(s.tanfovy), H, W, bg, L.ptr(radii), L.ptr(geom), geom.numel(), ctx.plist, L.ptr(image), image.numel(),

@@ -174,6 +174,27 @@ def test_photometric_loss_full_frame_and_errors(gpu):
         photometric_loss(a.detach()[0], a.detach()[0])
 
 
+@pytest.mark.parametrize("shape,lam", [((3, 37, 53), 0.2), ((3, 270, 480), 0.2), ((1, 16, 16), 1.0), ((3, 20, 70), 0.0)])
+def test_photometric_loss_step_equals_forward_then_backward(shape, lam, gpu):
+    """`syn3r_photo_loss_step` (value and gradient, the scalar sums formed by the gradient pass' first block) leaves the bits of
+    `syn3r_photo_loss` + `syn3r_photo_loss_backward` in the three scalars and in the image gradient - with and without an
+    upstream gradient."""
+    from syn3r_amd.gs.train_ops import photometric_loss, photometric_loss_step
+    g = torch.Generator().manual_seed(3 + shape[1])
+    a = torch.rand(shape, generator=g).to(gpu)
+    b = (a + 0.2 * torch.randn(shape, generator=g).to(gpu)).clamp(0, 1)
+    for up in (None, 1.5):
+        x = a.clone().requires_grad_(True)
+        loss, parts = photometric_loss(x, b, lambda_dssim=lam, weight=0.7, return_parts=True)
+        (loss if up is None else loss * up).backward()
+        go = None if up is None else torch.tensor(up, device=gpu)
+        l2, p2, grad = photometric_loss_step(a, b, lam, 0.7, grad_loss=go)
+        assert torch.equal(p2, parts) and torch.equal(l2, loss.detach())
+        assert torch.equal(grad, x.grad)
+    with pytest.raises(ValueError):
+        photometric_loss_step(a[0], b[0])
+
+
 def test_densification_stats_vs_masked_torch(gpu):
     """syn3r_densification_stats == the published GaussianModel.add_densification_stats (boolean-mask indexing) bit for bit."""
     from syn3r_amd import _lib as L

@@ -233,3 +233,58 @@ def test_training_with_density_control_changes_the_set_and_keeps_fitting(gpu):
     counts.clear()
     tr.finetune(0, 1, iterations=40, disable_densification=True)
     assert counts == [] and gm._xyz.shape[0] == n_now
+
+
+@pytest.mark.parametrize("with_conf", [False, True])
+def test_raw_parameter_rasteriser_entries_equal_activate_then_rasterise(with_conf, gpu):
+    """`syn3r_raster_preprocess_raw` / `syn3r_raster_backward_raw` (the activations and their chain rule inside the projection
+    kernels: what the explicit training step calls) leave BIT FOR BIT what `syn3r_gaussian_activate` -> `syn3r_raster_preprocess`
+    ... `syn3r_raster_backward` -> `syn3r_gaussian_activate_backward` leave in the image, depth, alpha and radii; the parameter
+    gradients agree to the noise of the blend backward's floating-point atomics (their order differs from launch to launch:
+    2e-5 of the largest entry, the bar of the explicit-vs-autograd test above), culled rows are exactly zero on both routes."""
+    from syn3r_amd import _lib as L
+    from syn3r_amd.gs import Camera, GSTrainer
+    from syn3r_amd.raster import GaussianRasterizationSettings, _Rasterize
+    N, H, W = 5000, 88, 120
+    gm, K = make_scene(N, H, W, 11, gpu)
+    w2c = np.eye(4, dtype=np.float32)
+    w2c[2, 3] = -3.0                                  # depths 2..6 -> -1..3: a quarter of the Gaussians are behind the near plane (culled rows on both routes)
+    cam = Camera.from_w2c(w2c, K, H, W, image=torch.rand(3, H, W), data_device=gpu)
+    conf = torch.rand(N, device=gpu) if with_conf else None
+    st = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.zeros(3, device=gpu), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center, prefiltered=False, debug=False)
+    lib, stream = L.load(), L.stream_ptr(gpu)
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=gpu)
+    g_color = torch.randn(3, H, W, device=gpu)
+    g_depth, g_alpha = torch.randn(1, H, W, device=gpu), torch.randn(1, H, W, device=gpu)
+    with torch.no_grad():
+        # two launches around the activated-tensor entries
+        sc, ro, op = new(N, 3), new(N, 4), new(N, 1)
+        L.check(lib.syn3r_gaussian_activate(N, L.ptr(gm._scaling), L.ptr(gm._rotation), L.ptr(gm._opacity), L.ptr(sc), L.ptr(ro),
+                                            L.ptr(op), stream), "gaussian_activate")
+        c0 = GSTrainer._Ctx()
+        out0 = _Rasterize.forward(c0, gm._xyz, None, gm._features, op, sc, ro, conf, st)
+        d_m3, d_m2, d_sh, d_op, d_sc, d_ro, d_cf, _ = _Rasterize.backward(c0, g_color, None, g_depth, g_alpha)
+        d_ls, d_rr, d_lg = new(N, 3), new(N, 4), new(N, 1)
+        L.check(lib.syn3r_gaussian_activate_backward(N, L.ptr(gm._rotation), L.ptr(sc), L.ptr(ro), L.ptr(op), L.ptr(d_sc),
+                                                     L.ptr(d_ro), L.ptr(d_op), L.ptr(d_ls), L.ptr(d_rr), L.ptr(d_lg), stream),
+                "gaussian_activate_backward")
+        ref = [d_m3, d_m2, d_sh, d_lg.reshape(-1), d_ls, d_rr] + ([d_cf] if with_conf else [])
+        # the raw-parameter entries
+        c1 = GSTrainer._Ctx()
+        c1.raw_params = True
+        out1 = _Rasterize.forward(c1, gm._xyz, None, gm._features, gm._opacity, gm._scaling, gm._rotation, conf, st)
+        r_m3, r_m2, r_sh, r_lg, r_ls, r_rr, r_cf, _ = _Rasterize.backward(c1, g_color, None, g_depth, g_alpha)
+        got = [r_m3, r_m2, r_sh, r_lg.reshape(-1), r_ls, r_rr] + ([r_cf] if with_conf else [])
+    assert int((out0[1] > 0).sum()) > N // 4 and int((out0[1] == 0).sum()) > 0          # visible and culled Gaussians both
+    for a, b in zip(out0, out1):
+        assert torch.equal(a, b)
+    culled = out0[1] == 0
+    for name, a, b in zip(("xyz", "means2D", "sh", "opacity logit", "log scale", "raw rotation", "confidence"), ref, got):
+        assert a.shape == b.shape, name
+        scale = float(a.abs().max()) + 1e-20
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (name, float((a - b).abs().max()), scale)
+        assert float(a[culled].abs().max()) == 0.0 and float(b[culled].abs().max()) == 0.0, name
+    assert float(d_ls.abs().max()) > 0 and float(d_rr.abs().max()) > 0 and float(d_lg.abs().max()) > 0
