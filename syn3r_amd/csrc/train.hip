@@ -217,26 +217,35 @@ __device__ __forceinline__ float block_sum_photo(float v, float* red) {
     return t;
 }
 
-// 20 consecutive values of image row y from column x (x % 4 == 0; zero outside the image).  vec: W % 4 == 0 and the plane is
-// 16-byte aligned, so a group of four is inside the image or outside it as a whole.
-__device__ __forceinline__ void photo_load20(float (&v)[20], const float* __restrict__ plane, int y, int x, int H, int W, bool vec) {
+// 20 consecutive values of image row y from column x (x % 4 == 0; zero outside the image).  VEC: W % 4 == 0 and the plane is
+// 16-byte aligned, so a group of four is inside the image or outside it as a whole.  Every load is UNCONDITIONAL from an address
+// clamped into the plane and the zero is a select afterwards: a load behind its own `inside ? load : 0` branch waits for the one
+// before it (hipcc does not move loads across the exec-mask branches: the ten loads of a row run were a chain of ten latencies).
+template <bool VEC>
+__device__ __forceinline__ void photo_load20(float (&v)[20], const float* __restrict__ plane, int y, int x, int H, int W) {
     const bool row = y >= 0 && y < H;
-    const float* src = plane + (size_t)(row ? y : 0) * W;
+    const float* src = plane + (size_t)min(max(y, 0), H - 1) * W;
+    if constexpr (VEC) {
+        float4 t[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        const int xq = x + 4 * q;
-        if (vec) {
-            const float4 t = (row && xq >= 0 && xq < W) ? *(const float4*)(src + xq) : make_float4(0.f, 0.f, 0.f, 0.f);
-            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-        } else {
+        for (int q = 0; q < 5; ++q) t[q] = *(const float4*)(src + min(max(x + 4 * q, 0), W - 4));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * q + e] = (row && xq + e >= 0 && xq + e < W) ? src[xq + e] : 0.0f;
+        for (int q = 0; q < 5; ++q) {
+            const bool in = row && x + 4 * q >= 0 && x + 4 * q < W;
+            v[4 * q] = in ? t[q].x : 0.0f; v[4 * q + 1] = in ? t[q].y : 0.0f; v[4 * q + 2] = in ? t[q].z : 0.0f; v[4 * q + 3] = in ? t[q].w : 0.0f;
         }
+    } else {
+        float t[20];
+#pragma unroll
+        for (int e = 0; e < 20; ++e) t[e] = src[min(max(x + e, 0), W - 1)];
+#pragma unroll
+        for (int e = 0; e < 20; ++e) v[e] = (row && x + e >= 0 && x + e < W) ? t[e] : 0.0f;
     }
 }
 
+template <bool VEC>
 __global__ void __launch_bounds__(kPhotoThreads) k_photo_fwd(const float* __restrict__ img, const float* __restrict__ gt, int H,
-                                                   int W, int C, SsimWindow win, int vec, float* __restrict__ maps,
+                                                   int W, int C, SsimWindow win, float* __restrict__ maps,
                                                    float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) f2 hA[kReg][kTile], hB[kReg][kTile];   // (mu1, mu2), (E[p^2], E[q^2]) after the horizontal pass
     __shared__ __attribute__((aligned(16))) float hC[kReg][kTile];                 // E[pq]
@@ -252,8 +261,8 @@ __global__ void __launch_bounds__(kPhotoThreads) k_photo_fwd(const float* __rest
         const int ry = i / (kTile / kRun), tx = (i - ry * (kTile / kRun)) * kRun;
         const int y = y0 + ry - kHalo;
         float p[20], q[20];
-        photo_load20(p, a, y, x0 + tx - 8, H, W, vec != 0);
-        photo_load20(q, b, y, x0 + tx - 8, H, W, vec != 0);
+        photo_load20<VEC>(p, a, y, x0 + tx - 8, H, W);
+        photo_load20<VEC>(q, b, y, x0 + tx - 8, H, W);
         f2 pq[kSpan], sq[kSpan];
         float pr[kSpan];
 #pragma unroll
@@ -365,8 +374,9 @@ __device__ __forceinline__ void photo_final(const PhotoFinal f) {
 }
 __global__ void __launch_bounds__(256) k_photo_final(PhotoFinal f) { photo_final(f); }
 
+template <bool VEC>
 __global__ void __launch_bounds__(kPhotoThreads) k_photo_bwd(const float* __restrict__ img, const float* __restrict__ gt, int H,
-                                                   int W, int C, SsimWindow win, int vec, const float* __restrict__ maps, float c_l1,
+                                                   int W, int C, SsimWindow win, const float* __restrict__ maps, float c_l1,
                                                    float c_ssim, const float* __restrict__ go,
                                                    float* __restrict__ grad, PhotoFinal fin) {
     __shared__ __attribute__((aligned(16))) f2 hA[kReg][kTile];      // windowed (d_mu1, d_sigma1^2) after the horizontal pass
@@ -383,18 +393,17 @@ __global__ void __launch_bounds__(kPhotoThreads) k_photo_bwd(const float* __rest
     float pv[kRun], qv[kRun];
 #pragma unroll
     for (int j = 0; j < kRun; ++j) {
-        const bool in = x0 + vtx < W && y0 + vty + j < H;
-        const size_t o = (size_t)c * plane + (size_t)(y0 + vty + j) * W + x0 + vtx;
-        pv[j] = in ? img[o] : 0.0f;
-        qv[j] = in ? gt[o] : 0.0f;
+        const size_t o = (size_t)c * plane + (size_t)min(y0 + vty + j, H - 1) * W + min(x0 + vtx, W - 1);     // (clamped: rows / columns past the image are not written)
+        pv[j] = img[o];
+        qv[j] = gt[o];
     }
     for (int i = threadIdx.x; i < kPhotoItems; i += kPhotoThreads) {
         const int ry = i / (kTile / kRun), tx = (i - ry * (kTile / kRun)) * kRun;
         const int y = y0 + ry - kHalo;
         float u0[20], u1[20], u2[20];
-        photo_load20(u0, m0, y, x0 + tx - 8, H, W, vec != 0);
-        photo_load20(u1, m0 + n, y, x0 + tx - 8, H, W, vec != 0);
-        photo_load20(u2, m0 + 2 * n, y, x0 + tx - 8, H, W, vec != 0);
+        photo_load20<VEC>(u0, m0, y, x0 + tx - 8, H, W);
+        photo_load20<VEC>(u1, m0 + n, y, x0 + tx - 8, H, W);
+        photo_load20<VEC>(u2, m0 + 2 * n, y, x0 + tx - 8, H, W);
         f2 mA[kRun];
         float mC[kRun];
 #pragma unroll
@@ -614,8 +623,9 @@ static int photo_forward(const char* who, const float* image, const float* targe
     const long long tiles = (long long)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile) * C;
     SYN3R_REQUIRE(tiles < (1ll << 31), "%s: %lld tiles exceed the grid limit", who, tiles);
     const dim3 grid((unsigned)tiles);
-    const int vec = W % 4 == 0 && (((uintptr_t)image | (uintptr_t)target) & 15) == 0;      // aligned 16-byte row runs
-    SYN3R_LAUNCH(k_photo_fwd, grid, dim3(kPhotoThreads), 0, stream, image, target, H, W, C, make_window(), vec, maps, partial);
+    const bool vec = W % 4 == 0 && (((uintptr_t)image | (uintptr_t)target) & 15) == 0;      // aligned 16-byte row runs
+    if (vec) SYN3R_LAUNCH(k_photo_fwd<true>, grid, dim3(kPhotoThreads), 0, stream, image, target, H, W, C, make_window(), maps, partial);
+    else SYN3R_LAUNCH(k_photo_fwd<false>, grid, dim3(kPhotoThreads), 0, stream, image, target, H, W, C, make_window(), maps, partial);
     const PhotoFinal f{partial, (long long)grid.x, 1.0 / (double)n, lambda_dssim, weight, loss3};
     if (final_launch) SYN3R_LAUNCH(k_photo_final, dim3(1), dim3(256), 0, stream, f);
     if (fin) *fin = f;
@@ -630,10 +640,12 @@ static int photo_backward(const char* who, const float* image, const float* targ
     const long long tiles = (long long)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile) * C;
     SYN3R_REQUIRE(tiles < (1ll << 31), "%s: %lld tiles exceed the grid limit", who, tiles);
     const dim3 grid((unsigned)tiles);
-    const int vec = W % 4 == 0 && ((uintptr_t)ws & 15) == 0;
-    SYN3R_LAUNCH(k_photo_bwd, grid, dim3(kPhotoThreads), 0, stream, image, target, H, W, C, make_window(), vec, (const float*)ws,
-                 (float)((double)weight * (1.0 - (double)lambda_dssim) / n), (float)((double)weight * (double)lambda_dssim / n),
-                 grad_loss, grad_image, fin);
+    const bool vec = W % 4 == 0 && ((uintptr_t)ws & 15) == 0;
+    const float c_l1 = (float)((double)weight * (1.0 - (double)lambda_dssim) / n), c_ssim = (float)((double)weight * (double)lambda_dssim / n);
+    if (vec) SYN3R_LAUNCH(k_photo_bwd<true>, grid, dim3(kPhotoThreads), 0, stream, image, target, H, W, C, make_window(), (const float*)ws,
+                          c_l1, c_ssim, grad_loss, grad_image, fin);
+    else SYN3R_LAUNCH(k_photo_bwd<false>, grid, dim3(kPhotoThreads), 0, stream, image, target, H, W, C, make_window(), (const float*)ws,
+                      c_l1, c_ssim, grad_loss, grad_image, fin);
     return SYN3R_OK;
 }
 
