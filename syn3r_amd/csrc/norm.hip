@@ -41,7 +41,25 @@ __global__ void k_gn_stats(const __half* __restrict__ x, const __half* __restric
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-    for (int r = r_begin + rl; r < r_end; r += rpb) {
+    // four rows of a thread are requested together (one load per trip left the pass waiting out a memory latency per row); the
+    // sums take the rows in the same order
+    constexpr int UN = 4;
+    int r = r_begin + rl;
+    for (; r + (UN - 1) * rpb < r_end; r += UN * rpb) {
+        half8 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) v[u] = *(const half8*)(base + (size_t)(r + u * rpb) * stride);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)v[u][e];
+                s[e] += f;
+                q[e] += f * f;
+            }
+        }
+    }
+    for (; r < r_end; r += rpb) {
         half8 v = *(const half8*)(base + (size_t)r * stride);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -161,8 +179,7 @@ __global__ void k_gn_apply(const __half* __restrict__ x, const __half* __restric
     const size_t off = (size_t)sample * R * C + (size_t)cv * 8;
     int stride;
     const __half* src = gn_src(x, x2, C, C1, cv, (size_t)sample * R, stride);
-    for (int r = r_begin + rl; r < r_end; r += rpb) {
-        half8 v = *(const half8*)(src + (size_t)r * stride);
+    auto apply = [&](half8 v) {
         half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -170,8 +187,19 @@ __global__ void k_gn_apply(const __half* __restrict__ x, const __half* __restric
             if (SILU) f = f / (1.0f + __expf(-f));
             o[e] = (_Float16)f;
         }
-        *(half8*)(y + off + (size_t)r * C) = o;
+        return o;
+    };
+    // four rows of a thread are requested together (one load per trip: a memory latency per row)
+    constexpr int UN = 4;
+    int r = r_begin + rl;
+    for (; r + (UN - 1) * rpb < r_end; r += UN * rpb) {
+        half8 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) v[u] = *(const half8*)(src + (size_t)(r + u * rpb) * stride);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) *(half8*)(y + off + (size_t)(r + u * rpb) * C) = apply(v[u]);
     }
+    for (; r < r_end; r += rpb) *(half8*)(y + off + (size_t)r * C) = apply(*(const half8*)(src + (size_t)r * stride));
 }
 
 // ---------------------------------------------------------------- LayerNorm
@@ -179,13 +207,18 @@ __global__ void k_gn_apply(const __half* __restrict__ x, const __half* __restric
 // 8 channels: C = 320 -> 8 lanes x 5 vectors, every lane busy (one wavefront per row would idle 24 of 64).
 constexpr int LN_MAXV = 8;
 
-template <int LPR>
+// NV > 0: the row is EXACTLY NV vectors per lane (C = 8 * LPR * NV: 640 / 1280 / 320 of the UNet are 5 x 16 / 32 / 8) - no per-vector
+// guard, so a lane's loads are issued together; behind `if (cv < cvec)` branches each load waits for the one before it (hipcc keeps
+// loads inside their exec-mask regions: five latencies in a row per pass).  NV == 0: any C, guarded.  Same arithmetic, same order.
+template <int LPR, int NV>
 __global__ void __launch_bounds__(256) k_layernorm(const __half* __restrict__ x, __half* __restrict__ y,
                                                    __half* __restrict__ xsum, const __half* __restrict__ addvec,
                                                    int rows_per_vec, long long M, int C,
                                                    const __half* __restrict__ gamma, const __half* __restrict__ beta,
                                                    float eps) {
     constexpr int RPW = 64 / LPR;
+    constexpr bool EXACT = NV > 0;
+    constexpr int KV = EXACT ? NV : LN_MAXV;
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
@@ -194,21 +227,46 @@ __global__ void __launch_bounds__(256) k_layernorm(const __half* __restrict__ x,
     const int cvec = C >> 3;
     const __half* src = x + row * C;
     const __half* add = addvec ? addvec + (row / rows_per_vec) * C : nullptr;
-    float v[LN_MAXV][8];
+    float v[KV][8];
     float s = 0.f;
+    if constexpr (EXACT) {
+        half8 h[KV];
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
-        int cv = sub + LPR * k;
-        if (cv < cvec) {
-            half8 h = *(const half8*)(src + cv * 8);
-            if (add) {
-                half8 a = *(const half8*)(add + cv * 8);
+        for (int k = 0; k < KV; ++k) h[k] = *(const half8*)(src + (sub + LPR * k) * 8);
+        if (add) {
+            half8 a[KV];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) h[e] = h[e] + a[e];   // fp16 add, as the reference's tensor add
-                if (xsum && live) *(half8*)(xsum + row * C + cv * 8) = h;
+            for (int k = 0; k < KV; ++k) a[k] = *(const half8*)(add + (sub + LPR * k) * 8);
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[k][e] = h[k][e] + a[k][e];   // fp16 add, as the reference's tensor add
             }
+            if (xsum && live) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { v[k][e] = (float)h[e]; s += v[k][e]; }
+                for (int k = 0; k < KV; ++k) *(half8*)(xsum + row * C + (sub + LPR * k) * 8) = h[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[k][e] = (float)h[k][e]; s += v[k][e]; }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            int cv = sub + LPR * k;
+            if (cv < cvec) {
+                half8 h = *(const half8*)(src + cv * 8);
+                if (add) {
+                    half8 a = *(const half8*)(add + cv * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = h[e] + a[e];   // fp16 add, as the reference's tensor add
+                    if (xsum && live) *(half8*)(xsum + row * C + cv * 8) = h;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[k][e] = (float)h[e]; s += v[k][e]; }
+            }
         }
     }
 #pragma unroll
@@ -216,9 +274,9 @@ __global__ void __launch_bounds__(256) k_layernorm(const __half* __restrict__ x,
     const float mean = s / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < KV; ++k) {
         int cv = sub + LPR * k;
-        if (cv < cvec) {
+        if (EXACT || cv < cvec) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { float d = v[k][e] - mean; q += d * d; }
         }
@@ -227,14 +285,27 @@ __global__ void __launch_bounds__(256) k_layernorm(const __half* __restrict__ x,
     for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
     const float rstd = rsqrtf(q / (float)C + eps);
     if (!live) return;
+    if constexpr (EXACT) {
+        half8 g[KV], b[KV];
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
-        int cv = sub + LPR * k;
-        if (cv < cvec) {
-            half8 g = *(const half8*)(gamma + cv * 8), b = *(const half8*)(beta + cv * 8), o;
+        for (int k = 0; k < KV; ++k) { g[k] = *(const half8*)(gamma + (sub + LPR * k) * 8); b[k] = *(const half8*)(beta + (sub + LPR * k) * 8); }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (_Float16)((v[k][e] - mean) * rstd * (float)g[e] + (float)b[e]);
-            *(half8*)(y + row * C + cv * 8) = o;
+        for (int k = 0; k < KV; ++k) {
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)((v[k][e] - mean) * rstd * (float)g[k][e] + (float)b[k][e]);
+            *(half8*)(y + row * C + (sub + LPR * k) * 8) = o;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            int cv = sub + LPR * k;
+            if (cv < cvec) {
+                half8 g = *(const half8*)(gamma + cv * 8), b = *(const half8*)(beta + cv * 8), o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)((v[k][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+                *(half8*)(y + row * C + cv * 8) = o;
+            }
         }
     }
 }
@@ -362,14 +433,17 @@ extern "C" int syn3r_layernorm_f16(const void* x, void* y, void* xsum, const voi
     long long rows_per_block = 4 * (64 / lpr);
     long long blocks = (M + rows_per_block - 1) / rows_per_block;
     SYN3R_REQUIRE(blocks < (1ll << 31), "layernorm: too many rows");
-#define LN_LAUNCH(L_)                                                                                                   \
-    SYN3R_LAUNCH(k_layernorm<L_>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const __half*)x,          \
+    const bool exact5 = cvec == 5 * lpr;                           // 320 / 640 / 1280 / 2560: unguarded, batched loads
+#define LN_LAUNCH(L_, NV_)                                                                                              \
+    SYN3R_LAUNCH((k_layernorm<L_, NV_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const __half*)x,   \
                  (__half*)y, (__half*)xsum, (const __half*)addvec, rows_per_vec, M, C, (const __half*)gamma,              \
                  (const __half*)beta, eps)
-    if (lpr == 8) LN_LAUNCH(8);
-    else if (lpr == 16) LN_LAUNCH(16);
-    else if (lpr == 32) LN_LAUNCH(32);
-    else LN_LAUNCH(64);
+#define LN_PICK(L_) do { if (exact5) LN_LAUNCH(L_, 5); else LN_LAUNCH(L_, 0); } while (0)
+    if (lpr == 8) LN_PICK(8);
+    else if (lpr == 16) LN_PICK(16);
+    else if (lpr == 32) LN_PICK(32);
+    else LN_PICK(64);
+#undef LN_PICK
 #undef LN_LAUNCH
     SYN3R_LAUNCH_CHECK("layernorm launch");
     return SYN3R_OK;

@@ -360,13 +360,27 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
     const size_t blk0 = (size_t)blockIdx.x * 256 * 48;                // first float of the block's rows
     const int rows = min(256, N - (int)blockIdx.x * 256);
     if constexpr (STAGED) {
+        // the twelve loads of a thread are issued TOGETHER (a full block: every block but the last); behind a per-load `row < rows`
+        // branch each would wait for the one before it (hipcc keeps a load inside its exec-mask region)
+        if (rows == 256) {
+            float4 v4[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            const int e = (threadIdx.x + 256 * k) * 4, row = e / 48, col = e - row * 48;
-            if (row < rows) {
-                const float4 v4 = *(const float4*)(shs + blk0 + e);
+            for (int k = 0; k < 12; ++k) v4[k] = *(const float4*)(shs + blk0 + (threadIdx.x + 256 * k) * 4);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int e = (threadIdx.x + 256 * k) * 4, row = e / 48, col = e - row * 48;
                 float* d = &shl[row * kShLd + col];
-                d[0] = v4.x; d[1] = v4.y; d[2] = v4.z; d[3] = v4.w;
+                d[0] = v4[k].x; d[1] = v4[k].y; d[2] = v4[k].z; d[3] = v4[k].w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int e = (threadIdx.x + 256 * k) * 4, row = e / 48, col = e - row * 48;
+                if (row < rows) {
+                    const float4 v4 = *(const float4*)(shs + blk0 + e);
+                    float* d = &shl[row * kShLd + col];
+                    d[0] = v4.x; d[1] = v4.y; d[2] = v4.z; d[3] = v4.w;
+                }
             }
         }
         __syncthreads();
