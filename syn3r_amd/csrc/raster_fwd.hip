@@ -356,12 +356,13 @@ __global__ void __launch_bounds__(256) k_tile_ranges(long long P_cap, const unsi
 //   k_super_sort                    a block per super-tile sorts its list (1 015 keys on average, 3 201 at most at 200 000 Gaussians)
 //                                   in LDS - a bitonic network on 8-byte keys; longer lists are sorted in LDS-sized pieces and merged
 //                                   through global memory - and leaves, in order, the ids and the rectangles clipped to the
-//                                   super-tile (4 x 4 bits);
-//   k_tile_count / k_tile_write     a block per tile (four wavefronts, a quarter of the super-tile's list each, coalesced, 2 B per
-//                                   entry) keeps the entries whose rectangle holds the tile: count, one single-block scan over the
-//                                   tiles (k_tile_offsets: ranges, pair count, overflow flag, the blend kernels' tile order), write.
+//                                   super-tile (4 x 4 bits); its wavefronts then count, per tile of the super-tile, the entries
+//                                   whose rectangle holds the tile (round 6: until then a launch of its own, a block per tile);
+//   k_tile_offsets / k_tile_write   one single-block scan over the tiles (ranges, pair count, overflow flag, the blend kernels' tile
+//                                   order), then a block per tile (four wavefronts, a quarter of the super-tile's list each,
+//                                   coalesced, 2 B per entry) writes the entries whose rectangle holds the tile.
 // Same lists as the (tile << 32 | depth) key sort, entry for entry - equal depths in index order, as a stable sort leaves them
-// (tests/test_raster_gpu.py, test_raster_full_gpu.py against the oracle's sort); seven launches where there were twenty-seven.
+// (tests/test_raster_gpu.py, test_raster_full_gpu.py against the oracle's sort); five launches where there were twenty-seven.
 // Shapes it does not take (more than 512 super-tiles: images beyond ~4K) keep the argsort and the pair sort.
 constexpr int kBinThreads = 512;          // Gaussians per round of a binning block
 constexpr int kOffThreads = 1024;         // k_tile_offsets: one block
@@ -609,16 +610,63 @@ __device__ __forceinline__ void bitonic_merge(unsigned long long* buf, int m, in
     bitonic_dists(buf, m, q >> 1);
 }
 
-__global__ void __launch_bounds__(kSuperSortThreads) k_super_sort(int N, const float* __restrict__ means2D, const int* __restrict__ radii,
+__device__ __forceinline__ bool rect_has(unsigned r, int rx, int ry) {
+    return rx >= (int)(r & 15u) && rx < (int)((r >> 4) & 15u) && ry >= (int)((r >> 8) & 15u) && ry < (int)(r >> 12);
+}
+
+constexpr int kBinUnroll = 8;
+// k_tile_write: a block per tile, its four wavefronts a quarter of the super-tile's list each (the longest list sets the kernel's
+// time: a wavefront per tile left the tiles of the busiest super-tile walking ~8 000 entries while the rest of the chip had finished).
+__device__ __forceinline__ void tile_quarter(unsigned b, unsigned e, int q, unsigned& qb, unsigned& qe) {
+    const unsigned len = (e - b + 3u) / 4u;
+    qb = min(e, b + (unsigned)q * len); qe = min(e, qb + len);
+}
+
+// The per-tile, per-quarter entry counts of super-tile (sx, sy) (tcount[4 t + q], what k_tile_offsets scans and k_tile_write starts
+// from) by the block that has just ordered the list: wavefront w takes tiles w, w + 16, ... of the super-tile and walks the clipped
+// rectangles (2 B per entry: in LDS where the list was sorted there, else as written a moment ago by this block - visible after
+// the barrier: one workgroup, one CU), quarter by quarter.  Until round 6 a launch of its own (k_tile_count, a block per tile:
+// 10 us + a launch at 1080p).
+__device__ __forceinline__ void super_tile_counts(int sx, int sy, int ss, int gx, int gy, unsigned n, const unsigned short* srect_b,
+                                                  unsigned* __restrict__ tcount) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, side = 1 << ss;
+    const unsigned len = (n + 3u) / 4u;                        // tile_quarter's split of [0, n)
+    // (tile, quarter) items over the block's 16 wavefronts: 2 x 2-tile super-tiles (the LLFF sizes, lists of ~10 000) keep all of
+    // them busy, 4 x 4 gives a wavefront the four quarters of one tile.  Per-lane counts on the vector unit and one cross-lane sum
+    // per item (the scalar unit is shared by the CU's wavefronts: per-chunk ballot masks doubled this kernel's time); four chunks
+    // of 64 entries are requested before the first is tested (the long lists are read from global memory).
+    for (int it = wv; it < side * side * 4; it += kSuperSortThreads / 64) {
+        const int ti = it >> 2, q = it & 3;
+        const int rx = ti & (side - 1), ry = ti >> ss;
+        const int tx = (sx << ss) + rx, ty = (sy << ss) + ry;
+        if (tx >= gx || ty >= gy) continue;                    // (wave-uniform)
+        const unsigned lo = min(n, (unsigned)q * len), hi = min(n, lo + len);
+        unsigned cnt = 0;
+        for (unsigned i0 = lo; i0 < hi; i0 += 256) {
+            unsigned short r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = srect_b[min(i0 + u * 64 + lane, hi - 1u)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cnt += (i0 + u * 64 + lane < hi && rect_has(r[u], rx, ry)) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (lane == 0) tcount[4 * ((size_t)ty * gx + tx) + q] = cnt;
+    }
+}
+
+// (8 wavefronts per SIMD = two blocks per CU: 510 blocks at 1080p are resident at once - at 72 registers only one block fits and the
+// kernel runs its blocks in two rounds, 36 -> 70 us)
+__global__ void __launch_bounds__(kSuperSortThreads, 8) k_super_sort(int N, const float* __restrict__ means2D, const int* __restrict__ radii,
                                                                   int gx, int gy, int ss, int sgx, const unsigned* __restrict__ sstart, unsigned cap,
                                                                   unsigned long long* __restrict__ skeys, unsigned* __restrict__ sid,
-                                                                  unsigned short* __restrict__ srect) {
+                                                                  unsigned short* __restrict__ srect, unsigned* __restrict__ tcount) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];   // kSortLds keys
     const int s_ = blockIdx.x, sx = s_ % sgx, sy = s_ / sgx;
     unsigned b, e;
     super_range(s_, sstart, cap, b, e);
     const int n = (int)(e - b);
-    if (n == 0) return;
+    if (n == 0) { super_tile_counts(sx, sy, ss, gx, gy, 0u, srect, tcount); return; }     // (zeros for its tiles)
     unsigned long long* gk = skeys + b;
     const unsigned long long INF = ~0ull;
     int m = 1;
@@ -663,48 +711,42 @@ __global__ void __launch_bounds__(kSuperSortThreads) k_super_sort(int N, const f
         }
         sorted = gk;
     }
+    if (sorted == sk) {
+        // (n <= kSortLds = 4 x kSuperSortThreads) the clipped rectangles also go to LDS - over the keys, once every thread has read
+        // its ids - where the tile counts read them: 2 B per entry and tile from global memory, one dependent load per 64 entries,
+        // made the longest list's block the kernel's time (36 -> 74 us)
+        unsigned short clip[kSortLds / kSuperSortThreads];
+#pragma unroll
+        for (int u = 0; u < kSortLds / kSuperSortThreads; ++u) {
+            const int i = threadIdx.x + u * kSuperSortThreads;
+            clip[u] = 0;
+            if (i < n) {
+                const unsigned id = (unsigned)sk[i];
+                const BinRect q = bin_rect((int)id, N, means2D, radii, gx, gy);
+                clip[u] = clip_rect(q, sx, sy, ss);
+                sid[b + i] = id;
+                srect[b + i] = clip[u];
+            }
+        }
+        __syncthreads();
+        unsigned short* sr = (unsigned short*)sk;
+#pragma unroll
+        for (int u = 0; u < kSortLds / kSuperSortThreads; ++u) {
+            const int i = threadIdx.x + u * kSuperSortThreads;
+            if (i < n) sr[i] = clip[u];
+        }
+        __syncthreads();
+        super_tile_counts(sx, sy, ss, gx, gy, (unsigned)n, sr, tcount);
+        return;
+    }
     for (int i = threadIdx.x; i < n; i += kSuperSortThreads) {
         const unsigned id = (unsigned)sorted[i];
         const BinRect q = bin_rect((int)id, N, means2D, radii, gx, gy);
         sid[b + i] = id;
         srect[b + i] = clip_rect(q, sx, sy, ss);
     }
-}
-
-__device__ __forceinline__ bool rect_has(unsigned r, int rx, int ry) {
-    return rx >= (int)(r & 15u) && rx < (int)((r >> 4) & 15u) && ry >= (int)((r >> 8) & 15u) && ry < (int)(r >> 12);
-}
-
-constexpr int kBinUnroll = 8;
-// A block per tile, its four wavefronts a quarter of the super-tile's list each (the longest list sets the kernel's time: a
-// wavefront per tile left the tiles of the busiest super-tile walking ~8 000 entries while the rest of the chip had finished).
-__device__ __forceinline__ void tile_quarter(unsigned b, unsigned e, int q, unsigned& qb, unsigned& qe) {
-    const unsigned len = (e - b + 3u) / 4u;
-    qb = min(e, b + (unsigned)q * len); qe = min(e, qb + len);
-}
-
-__global__ void __launch_bounds__(256) k_tile_count(int gx, int tiles, int ss, int sgx, const unsigned* __restrict__ sstart, unsigned cap,
-                                                    const unsigned short* __restrict__ srect, unsigned* __restrict__ tcount) {
-    const int t = blockIdx.x, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tx = t % gx, ty = t / gx;
-    unsigned b, e;
-    super_range((ty >> ss) * sgx + (tx >> ss), sstart, cap, b, e);
-    tile_quarter(b, e, q, b, e);
-    const int rx = tx & ((1 << ss) - 1), ry = ty & ((1 << ss) - 1);
-    unsigned cnt = 0;
-    for (unsigned i0 = b; i0 < e; i0 += 64 * kBinUnroll) {       // kBinUnroll chunks of 64 entries requested before any is tested
-        unsigned short r[kBinUnroll];
-#pragma unroll
-        for (int u = 0; u < kBinUnroll; ++u) {
-            const unsigned i = i0 + u * 64 + lane;
-            r[u] = i < e ? srect[i] : (unsigned short)0;          // 0: an empty rectangle
-        }
-#pragma unroll
-        for (int u = 0; u < kBinUnroll; ++u) cnt += rect_has(r[u], rx, ry) ? 1u : 0u;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if (lane == 0) tcount[4 * t + q] = cnt;
+    __syncthreads();                 // the block's rectangles are in memory for the block
+    super_tile_counts(sx, sy, ss, gx, gy, (unsigned)n, srect + b, tcount);
 }
 
 // ranges[t] = (start, end) of tile t's list, clipped to the capacity; header[0] = the pair count, header[1] = 1 if it (or the
@@ -1092,9 +1134,7 @@ extern "C" int syn3r_raster_render(int N, int H, int W, const float* bg, const i
         SYN3R_LAUNCH(k_super_append, dim3(bp.nchunks), dim3(kBinThreads), 0, stream, N, (const float*)g.depths, (const float*)g.means2D, radii,
                      gx, gy, bp.ss, bp.sgx, bp.nsuper, bp.rounds, bp.nchunks, (const unsigned*)counters, sstart, (unsigned)P, skeys, g.header);
         SYN3R_LAUNCH(k_super_sort, dim3(bp.nsuper), dim3(kSuperSortThreads), kSortLds * 8, stream, N, (const float*)g.means2D, radii, gx, gy,
-                     bp.ss, bp.sgx, (const unsigned*)sstart, (unsigned)P, skeys, sid, srect);
-        SYN3R_LAUNCH(k_tile_count, dim3((unsigned)tiles), dim3(256), 0, stream, gx, (int)tiles, bp.ss, bp.sgx,
-                     (const unsigned*)sstart, (unsigned)P, (const unsigned short*)srect, im.tile_counts);
+                     bp.ss, bp.sgx, (const unsigned*)sstart, (unsigned)P, skeys, sid, srect, im.tile_counts);
         // the blend kernels take the tiles longest list first: with one block per tile in image order they ended on the few long
         // tiles of the last dispatch round (k_render 170 -> 130 us, k_render_bwd 463 -> 380 us at 200 000 Gaussians / 1080p;
         // SYN3R_TILE_ORDER=0 in tuning builds restores the image order)
