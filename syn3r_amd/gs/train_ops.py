@@ -10,19 +10,32 @@ import torch
 from .. import _lib as L
 
 
+def _l1_forward(image: torch.Tensor, target: torch.Tensor, weight: float):
+    L.require_gpu(image, target)
+    if image.shape != target.shape or image.dtype != torch.float32 or target.dtype != torch.float32:
+        raise ValueError("l1_loss: image and target must be float32 tensors of the same shape")
+    image, target = image.contiguous(), target.contiguous()
+    lib = L.load()
+    n = image.numel()
+    loss = torch.empty((), dtype=torch.float32, device=image.device)
+    ws = L.workspace(image.device, lib.syn3r_l1_loss_workspace_bytes(n), "l1")
+    L.check(lib.syn3r_l1_loss(L.ptr(image), L.ptr(target), n, float(weight), L.ptr(loss), L.ptr(ws), ws.numel(),
+                              L.stream_ptr(image.device)), "l1_loss")
+    return loss, image, target
+
+
+def _l1_backward(image: torch.Tensor, target: torch.Tensor, weight: float, grad_loss):
+    go = grad_loss.to(torch.float32).contiguous() if grad_loss is not None else None      # device scalar; None = 1
+    grad = torch.empty_like(image)
+    L.check(L.load().syn3r_l1_loss_backward(L.ptr(image), L.ptr(target), image.numel(), float(weight), L.ptr(go),
+                                            L.ptr(grad), L.stream_ptr(image.device)), "l1_loss_backward")
+    return grad
+
+
 class _L1Loss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image: torch.Tensor, target: torch.Tensor, weight: float):
-        L.require_gpu(image, target)
-        if image.shape != target.shape or image.dtype != torch.float32 or target.dtype != torch.float32:
-            raise ValueError("l1_loss: image and target must be float32 tensors of the same shape")
-        image, target = image.contiguous(), target.contiguous()
-        lib = L.load()
-        n = image.numel()
-        loss = torch.empty((), dtype=torch.float32, device=image.device)
-        ws = L.workspace(image.device, lib.syn3r_l1_loss_workspace_bytes(n), "l1")
-        L.check(lib.syn3r_l1_loss(L.ptr(image), L.ptr(target), n, float(weight), L.ptr(loss), L.ptr(ws), ws.numel(),
-                                  L.stream_ptr(image.device)), "l1_loss")
+        loss, image, target = _l1_forward(image, target, weight)
         ctx.save_for_backward(image, target)
         ctx.weight = float(weight)
         return loss
@@ -31,12 +44,13 @@ class _L1Loss(torch.autograd.Function):
     def backward(ctx, grad_loss: torch.Tensor):
         L.join_active_trace()
         image, target = ctx.saved_tensors
-        lib = L.load()
-        go = grad_loss.to(torch.float32).contiguous()
-        grad = torch.empty_like(image)
-        L.check(lib.syn3r_l1_loss_backward(L.ptr(image), L.ptr(target), image.numel(), ctx.weight, L.ptr(go),
-                                           L.ptr(grad), L.stream_ptr(image.device)), "l1_loss_backward")
-        return grad, None, None
+        return _l1_backward(image, target, ctx.weight, grad_loss), None, None
+
+
+def l1_loss_step(image: torch.Tensor, target: torch.Tensor, weight: float = 1.0, grad_loss: torch.Tensor = None):
+    """Value and image gradient of `l1_loss` without autograd (the two launches `_L1Loss` makes): (loss, grad_image)."""
+    loss, image, target = _l1_forward(image.detach(), target.detach(), weight)
+    return loss, _l1_backward(image, target, weight, grad_loss)
 
 
 def l1_loss(image: torch.Tensor, target: torch.Tensor, weight: float = 1.0) -> torch.Tensor:

@@ -541,20 +541,6 @@ class GSTrainer:
         cams = self.scene.getTrainCameras()
         return cams[int(self._rng.integers(len(cams)))]
 
-    class _Ctx:
-        """What an autograd.Function's `ctx` offers, for calling the rasteriser's and the loss' forward / backward
-        directly (the explicit training step below): no graph, no autograd-engine thread."""
-        saved_tensors = ()
-
-        def save_for_backward(self, *t):
-            self.saved_tensors = t
-
-        def mark_non_differentiable(self, *a):
-            pass
-
-        def set_materialize_grads(self, v):
-            pass
-
     def _explicit_step(self, cam: Camera) -> Tuple[torch.Tensor, dict]:
         """One optimisation step WITHOUT autograd: raw parameters in, raw-parameter gradients out.  The activations and
         their chain rule run INSIDE the rasteriser's projection kernels (`syn3r_raster_preprocess_raw` / `_backward_raw`, round 6:
@@ -562,12 +548,11 @@ class GSTrainer:
         autograd path keeps torch's three operators), the loss' value and gradient are `syn3r_photo_loss_step`'s two launches,
         and no screen-space `means2D` tensor is allocated per render.  Same arithmetic as the autograd path
         (`tests/test_trainer_gpu.py` holds one step of each against the oracle and against each other)."""
-        from ..raster import _Rasterize
-        from .train_ops import _L1Loss, photometric_loss_step
+        from ..raster import rasterize_backward, rasterize_forward
+        from .train_ops import l1_loss_step, photometric_loss_step
         g = self.gaussians
-        dev = g._xyz.device
-        # this step discards the rasteriser's confidence gradient (slot 6 of its backward): the per-Gaussian confidence is data here,
-        # as in the call sites (model/diffusionGS.py:139,1640); a trainable one has to take the autograd path
+        # this step discards the rasteriser's confidence gradient: the per-Gaussian confidence is data here, as in the call sites
+        # (model/diffusionGS.py:139,1640); a trainable one has to take the autograd path
         conf = g.confidence
         if conf is not None and getattr(conf, "requires_grad", False):
             raise ValueError("_explicit_step: a confidence tensor that requires grad needs train_step(explicit=False)")
@@ -577,21 +562,15 @@ class GSTrainer:
                 tanfovy=math.tan(cam.FoVy * 0.5), bg=self.background, scale_modifier=1.0,
                 viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=g.active_sh_degree,
                 campos=cam.camera_center, prefiltered=False, debug=False)
-            rctx = self._Ctx()
-            rctx.raw_params = True          # log-scales / raw quaternions / logits in, THEIR gradients out (syn3r_raster_*_raw)
-            color, radii, depth, alpha = _Rasterize.forward(rctx, g._xyz, None, g._features, g._opacity, g._scaling, g._rotation,
-                                                            g.confidence, st)
+            # log-scales / raw quaternions / logits in, THEIR gradients out (syn3r_raster_*_raw)
+            color, radii, depth, alpha, rstate = rasterize_forward(g._xyz, g._features, g._opacity, g._scaling, g._rotation,
+                                                                   g.confidence, st, raw_params=True)
             w = float(cam.cam_confidence)
             if self.opt.lambda_dssim > 0.0:
                 loss, _, d_color = photometric_loss_step(color, cam.original_image, self.opt.lambda_dssim, w)
             else:
-                lctx = self._Ctx()
-                loss = _L1Loss.forward(lctx, color, cam.original_image, w)
-                d_color = _L1Loss.backward(lctx, self._one(dev))[0]
-            grads = _Rasterize.backward(rctx, d_color, None, None, None)
-            if len(grads) != 8:      # (means3D, means2D, sh, opacity, scales, rotations, confidence, settings): the order this step reads
-                raise RuntimeError(f"_Rasterize.backward returned {len(grads)} gradients, the explicit step reads 8")
-            d_m3, d_m2, d_sh, d_lg, d_ls, d_rr, _, _ = grads
+                loss, d_color = l1_loss_step(color, cam.original_image, w)
+            d_m3, d_m2, d_sh, d_lg, d_ls, d_rr, _ = rasterize_backward(rstate, d_color)
             g._xyz.grad, g._features.grad, g._opacity.grad, g._scaling.grad, g._rotation.grad = d_m3, d_sh, d_lg.reshape(g._opacity.shape), d_ls, d_rr
         out = {"render": color, "depth": depth, "alpha": alpha, "viewspace_grad": d_m2, "visibility_filter": None,      # visible = radii > 0: add_densification_stats takes it from `radii` on the device
                "radii": radii}

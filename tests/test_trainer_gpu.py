@@ -243,8 +243,8 @@ def test_raw_parameter_rasteriser_entries_equal_activate_then_rasterise(with_con
     gradients agree to the noise of the blend backward's floating-point atomics (their order differs from launch to launch:
     2e-5 of the largest entry, the bar of the explicit-vs-autograd test above), culled rows are exactly zero on both routes."""
     from syn3r_amd import _lib as L
-    from syn3r_amd.gs import Camera, GSTrainer
-    from syn3r_amd.raster import GaussianRasterizationSettings, _Rasterize
+    from syn3r_amd.gs import Camera
+    from syn3r_amd.raster import GaussianRasterizationSettings, rasterize_backward, rasterize_forward
     N, H, W = 5000, 88, 120
     gm, K = make_scene(N, H, W, 11, gpu)
     w2c = np.eye(4, dtype=np.float32)
@@ -264,19 +264,16 @@ def test_raw_parameter_rasteriser_entries_equal_activate_then_rasterise(with_con
         sc, ro, op = new(N, 3), new(N, 4), new(N, 1)
         L.check(lib.syn3r_gaussian_activate(N, L.ptr(gm._scaling), L.ptr(gm._rotation), L.ptr(gm._opacity), L.ptr(sc), L.ptr(ro),
                                             L.ptr(op), stream), "gaussian_activate")
-        c0 = GSTrainer._Ctx()
-        out0 = _Rasterize.forward(c0, gm._xyz, None, gm._features, op, sc, ro, conf, st)
-        d_m3, d_m2, d_sh, d_op, d_sc, d_ro, d_cf, _ = _Rasterize.backward(c0, g_color, None, g_depth, g_alpha)
+        *out0, s0 = rasterize_forward(gm._xyz, gm._features, op, sc, ro, conf, st)
+        d_m3, d_m2, d_sh, d_op, d_sc, d_ro, d_cf = rasterize_backward(s0, g_color, g_depth, g_alpha)
         d_ls, d_rr, d_lg = new(N, 3), new(N, 4), new(N, 1)
         L.check(lib.syn3r_gaussian_activate_backward(N, L.ptr(gm._rotation), L.ptr(sc), L.ptr(ro), L.ptr(op), L.ptr(d_sc),
                                                      L.ptr(d_ro), L.ptr(d_op), L.ptr(d_ls), L.ptr(d_rr), L.ptr(d_lg), stream),
                 "gaussian_activate_backward")
         ref = [d_m3, d_m2, d_sh, d_lg.reshape(-1), d_ls, d_rr] + ([d_cf] if with_conf else [])
         # the raw-parameter entries
-        c1 = GSTrainer._Ctx()
-        c1.raw_params = True
-        out1 = _Rasterize.forward(c1, gm._xyz, None, gm._features, gm._opacity, gm._scaling, gm._rotation, conf, st)
-        r_m3, r_m2, r_sh, r_lg, r_ls, r_rr, r_cf, _ = _Rasterize.backward(c1, g_color, None, g_depth, g_alpha)
+        *out1, s1 = rasterize_forward(gm._xyz, gm._features, gm._opacity, gm._scaling, gm._rotation, conf, st, raw_params=True)
+        r_m3, r_m2, r_sh, r_lg, r_ls, r_rr, r_cf = rasterize_backward(s1, g_color, g_depth, g_alpha)
         got = [r_m3, r_m2, r_sh, r_lg.reshape(-1), r_ls, r_rr] + ([r_cf] if with_conf else [])
     assert int((out0[1] > 0).sum()) > N // 4 and int((out0[1] == 0).sum()) > 0          # visible and culled Gaussians both
     for a, b in zip(out0, out1):
