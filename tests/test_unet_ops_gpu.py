@@ -206,8 +206,10 @@ def test_groupnorm(samples, rows, C, silu, gpu):
     close(out, ref.permute(0, 2, 1).reshape(samples * rows, C), tol=3e-3)
 
 
-@pytest.mark.parametrize("M,C", [(1000, 320), (37, 1280), (513, 64), (64, 640)])
+@pytest.mark.parametrize("M,C", [(1000, 320), (37, 1280), (513, 64), (64, 640), (257, 200), (70, 2560), (33, 1288)])
 def test_layernorm(M, C, gpu):
+    """(C = 320 / 640 / 1280 / 2560: the exact five-vectors-per-lane kernels of round 6; 64, 200, 1288: the guarded one, 200 and 1288
+    with a ragged last vector group)"""
     from syn3r_amd.unet import ops
     g = torch.Generator().manual_seed(M)
     x, ga, be = rnd(g, M, C, dev=gpu), rnd(g, C, dev=gpu), rnd(g, C, dev=gpu)
